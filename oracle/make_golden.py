@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running THE REFERENCE's own code (this container only).
+
+Test infrastructure.  Imports the reference's three hot-path files
+(archs/XXNet_final_attenfusion_arch.py, archs/recurrent_sub_modules.py,
+archs/fusion_modules.py) and losses/losses.py straight from /root/reference
+-- with import stubs for the packages the image lacks (torchvision, the
+basicsr.utils logger) and WITHOUT copying or editing any reference source --
+runs them on closed-form inputs/weights (oracle.refid_oracle.hash_fill) and
+stores inputs' recipe + expected outputs as small fixtures.
+
+The fixtures are data; they travel to the GPU box, the reference does not.
+Run:  python oracle/make_golden.py            (writes tests/golden/)
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+from oracle import refid_oracle as O  # noqa: E402
+
+
+def import_reference():
+    """SURVEY.md 8(c) recipe: pre-seed sys.modules so only the hot-path files load."""
+    sys.dont_write_bytecode = True
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        sys.modules[name] = m
+        return m
+
+    pkg("basicsr", f"{REF}/basicsr")
+    pkg("basicsr.models", f"{REF}/basicsr/models")
+    pkg("basicsr.models.archs", f"{REF}/basicsr/models/archs")
+    pkg("basicsr.models.losses", f"{REF}/basicsr/models/losses")
+    utils = types.ModuleType("basicsr.utils")
+    import logging
+    utils.get_root_logger = lambda *a, **k: logging.getLogger("basicsr")
+    sys.modules["basicsr.utils"] = utils
+    tv = types.ModuleType("torchvision")
+    tvo = types.ModuleType("torchvision.ops")
+    tv.ops = tvo
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = tvo
+    arch = importlib.import_module("basicsr.models.archs.XXNet_final_attenfusion_arch")
+    losses = importlib.import_module("basicsr.models.losses.losses")
+    return arch, losses
+
+
+def build_ref(arch, img_chn, base):
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):      # the ctor prints
+        net = arch.FinalBidirectionAttenfusion(img_chn=img_chn, ev_chn=2, num_encoders=3,
+                                               base_num_channels=base, num_block=1,
+                                               num_residual_blocks=2)
+    return net
+
+
+def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wanted, out_dir,
+             store_output="full"):
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)
+    net = build_ref(arch, img_chn, base)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(P.keys()), "state-dict key order/naming mismatch"
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), (k, sd[k].shape, P[k].shape)
+    net.load_state_dict(P, strict=True)
+    x, ev, gt = O.make_inputs(B, T, H, W, img_chn, seed=seed, mode="hash")
+
+    rec = {}
+    calls = {}
+
+    def hook(tag, pick=None, when=None):
+        def fn(mod, inp, out):
+            n = calls.get(tag, 0)
+            calls[tag] = n + 1
+            o = out if pick is None else out[pick]
+            if when is None or n in when:
+                key = tag if when is None else f"{tag}_call{n}"
+                rec[key] = o.detach().clone()
+            rec["_last_" + tag] = o.detach().clone()
+        return fn
+
+    hs = []
+    if taps_wanted:
+        hs.append(net.head_img.register_forward_hook(hook("head")))
+        hs.append(net.head.register_forward_hook(hook("e")))
+        for i in range(3):
+            hs.append(net.img_encoders[i].register_forward_hook(hook(f"x_block{i}")))
+            hs.append(net.encoders_backward[i].register_forward_hook(hook(f"bstate{i}", 1, ())))
+            hs.append(net.encoders_forward[i].register_forward_hook(hook(f"fwd_out{i}", 0, (0, T - 1))))
+            hs.append(net.encoders_forward[i].register_forward_hook(hook(f"fwd_state{i}", 1, (0, T - 1))))
+            hs.append(net.decoders[i].register_forward_hook(hook(f"dec_state{i}", 1, ())))
+        hs.append(net.encoders_forward[1].atten_fuse.register_forward_hook(hook("egaca_out", None, ())))
+        hs.append(net.encoders_forward[1].atten_fuse.se_1.register_forward_hook(hook("egaca_se", None, ())))
+        hs.append(net.resblocks[1].register_forward_hook(hook("bottleneck", None, ())))
+
+    out = {}
+    net.train()
+    if train:
+        # the reference train step: twoImage_event_recurrent_model.py:273-310 with the
+        # shipped optimiser settings (options/train/GoPro/*.yml: AdamW 2e-4, wd 1e-4, betas .9/.99)
+        opt = torch.optim.AdamW([{"params": list(net.parameters())}], lr=2e-4, weight_decay=1e-4,
+                                betas=(0.9, 0.99))
+        cri = losses.CharbonnierLoss(loss_weight=1, reduction="mean")
+        opt.zero_grad()
+        pred = net(x=x, event=ev)
+        l_total = cri(pred, gt)
+        l_total = l_total + 0 * sum(p.sum() for p in net.parameters())
+        l_total.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.01)
+        # (grads are now clipped in place; store the unclipped ones via the norm)
+        coef = min(1.0, 0.01 / (float(gnorm) + 1e-6))
+        named = dict(net.named_parameters())
+        out["loss"] = l_total.detach().numpy()
+        out["grad_norm"] = np.float32(float(gnorm))
+        pick = ["head.conv2d.weight", "head_img.conv2d.bias", "pred.conv2d.weight",
+                "encoders_forward.0.recurrent_block.forward_trunk.main.0.weight",
+                "encoders_backward.2.recurrent_block.forward_trunk.main.2.0.conv2.bias",
+                "encoders_forward.1.atten_fuse.beta", "encoders_forward.1.atten_fuse.gamma",
+                "encoders_backward.1.atten_fuse.norm1_e.weight",
+                "encoders_forward.1.atten_fuse.conv2_e.weight",
+                "encoders_forward.1.atten_fuse.se_1.1.weight",
+                "encoders_forward.2.fuse_two_dir.conv2d.weight",
+                "encoders_forward.0.down.weight",
+                "decoders.0.transposed_conv2d.weight", "decoders.2.transposed_conv2d.bias",
+                "img_encoders.1.identity.weight", "resblocks.0.conv1.weight",
+                # three of the 13 parameters that only ever get zero gradients
+                "encoders_forward.1.conv.conv2d.weight", "encoders_backward.2.down.weight",
+                "encoders_forward.1.atten_fuse.se_2.1.bias"]
+        for k in pick:
+            g = named[k].grad.detach() / coef                # undo the in-place clip
+            if g.numel() > 50000:                            # keep fixtures small
+                out["gradsub7/" + k] = g.flatten()[::7].numpy().astype(np.float32)
+            else:
+                out["grad/" + k] = g.numpy().astype(np.float32)
+        # per-parameter gradient L2 norms for ALL parameters (cheap, pins every wgrad)
+        out["grad_norms_all"] = np.array([float(named[k].grad.norm()) / coef for k in P.keys()],
+                                         dtype=np.float64)
+        opt.step()
+        for k in ["pred.conv2d.weight", "encoders_forward.1.conv.conv2d.weight",
+                  "encoders_forward.0.recurrent_block.forward_trunk.main.0.bias"]:
+            out["after_step/" + k] = named[k].detach().numpy().astype(np.float32)
+        pred = pred.detach()
+    else:
+        net.eval()
+        with torch.no_grad():
+            pred = net(x=x, event=ev)
+    for h in hs:
+        h.remove()
+
+    if store_output == "full":
+        out["out"] = pred.numpy().astype(np.float32)
+    else:   # strided sample + moments
+        out["out_sub"] = pred[..., ::store_output, ::store_output].numpy().astype(np.float32)
+        out["out_mean_abs"] = np.float64(pred.double().abs().mean().item())
+        out["out_sum"] = np.float64(pred.double().sum().item())
+    if taps_wanted:
+        ren = {"head": "head", "x_block0": "x_block0", "x_block1": "x_block1", "x_block2": "x_block2"}
+        for k, v in ren.items():
+            out["tap/" + v] = rec[k].numpy()
+        out["tap/e"] = rec["e"].reshape(B, T, -1, H, W).numpy()
+        for i in range(3):
+            out[f"tap/final_bstate{i}"] = rec[f"_last_bstate{i}"].numpy()
+            for t in (0, T - 1):
+                out[f"tap/fwd_out{i}_t{t}"] = rec[f"fwd_out{i}_call{t}"].numpy()
+                out[f"tap/fwd_state{i}_t{t}"] = rec[f"fwd_state{i}_call{t}"].numpy()
+            out[f"tap/dec_state{i}_tlast"] = rec[f"_last_dec_state{i}"].numpy()
+        out["tap/egaca_out"] = rec["_last_egaca_out"].numpy()
+        out["tap/egaca_se"] = rec["_last_egaca_se"].numpy()
+        out["tap/bottleneck_tlast"] = rec["_last_bottleneck"].numpy()
+    out["meta"] = np.array([img_chn, base, B, T, H, W, seed], dtype=np.int64)
+    path = os.path.join(out_dir, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB), "
+          f"out mean|.|={pred.abs().mean():.4f}")
+
+
+def main():
+    out_dir = os.path.join(REPO, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.set_num_threads(8)
+    arch, losses = import_reference()
+    # dense taps + full train step, blur-VFI (26 ch) and sharp-VFI (5-D x, 6 ch)
+    run_case(arch, losses, "tiny26_train", 26, 8, 2, 3, 32, 32, 1, True, True, out_dir)
+    run_case(arch, losses, "tiny6_train", 6, 8, 2, 3, 32, 32, 2, True, True, out_dir)
+    # non-square, H/8 odd: 40x24 -> 5x3 at the bottleneck
+    run_case(arch, losses, "odd26_fwd", 26, 8, 1, 2, 40, 24, 3, False, False, out_dir)
+    # full-width network end to end with a train step
+    run_case(arch, losses, "full26_train", 26, 32, 1, 5, 64, 64, 4, True, False, out_dir)
+    # BASELINE config 1: img_chn=3, 128x128, 5-bin voxel -> T=4, forward only
+    run_case(arch, losses, "config1_fwd", 3, 32, 1, 4, 128, 128, 5, False, False, out_dir,
+             store_output=4)
+    # negative fixture: H=100 must raise in the reference
+    net = build_ref(arch, 26, 8)
+    x, ev, _ = O.make_inputs(1, 2, 104, 96, 26, seed=6)
+    try:
+        net(x=x[:, :, :100, :], event=ev[:, :, :, :100, :])
+        raised = False
+    except Exception as ex:  # noqa: BLE001
+        raised = True
+        print("H=100 raises in the reference:", type(ex).__name__)
+    np.savez(os.path.join(out_dir, "negative.npz"), h100_raises=np.array(raised))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""The CPU oracle (oracle/refid_oracle.py) against the fixtures produced by the
+reference's own code (oracle/make_golden.py -> tests/golden/*.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refid_oracle as O
+
+RTOL, ATOL = 1e-4, 1e-5     # oracle vs reference: same torch ops, only graph structure differs
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    img_chn, base, B, T, H, W, seed = [int(v) for v in z["meta"]]
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)
+    x, ev, gt = O.make_inputs(B, T, H, W, img_chn, seed=seed, mode="hash")
+    return z, P, x, ev, gt, base
+
+
+def test_param_inventory_matches_reference_counts():
+    # 15 928 355 / 15 912 355 / 15 909 955 parameters, 183 tensors
+    for chn, n in ((26, 15928355), (6, 15912355), (3, 15909955)):
+        sh = O.param_shapes(chn)
+        assert len(sh) == 183
+        assert sum(int(np.prod(s)) for s in sh.values()) == n
+
+
+@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train"])
+def test_forward_taps_and_train_step(golden_dir, name):
+    z, P, x, ev, gt, base = _load(golden_dir, name)
+    taps = {}
+    with torch.no_grad():
+        out = O.forward(P, x, ev, taps=taps)
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=RTOL, atol=ATOL)
+    n_taps = 0
+    for k in z.files:
+        if k.startswith("tap/"):
+            np.testing.assert_allclose(taps[k[4:]].numpy(), z[k], rtol=RTOL, atol=ATOL, err_msg=k)
+            n_taps += 1
+    assert n_taps >= 25
+    st = O.TrainState(P)
+    loss, gnorm, grads, _ = O.train_step(P, st, x, ev, gt)
+    np.testing.assert_allclose(loss.numpy(), z["loss"], rtol=1e-5)
+    np.testing.assert_allclose(float(gnorm), float(z["grad_norm"]), rtol=1e-4)
+    keys = list(P.keys())
+    gn = np.array([float(grads[k].norm()) for k in keys])
+    np.testing.assert_allclose(gn, z["grad_norms_all"], rtol=2e-4, atol=1e-7)
+    zero = [k for k, v in zip(keys, z["grad_norms_all"]) if v == 0.0]
+    assert len(zero) == 13          # 13 tensors only ever see zero gradients
+    for k in z.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(grads[k[5:]].numpy(), z[k], rtol=1e-3, atol=1e-6, err_msg=k)
+        if k.startswith("gradsub7/"):
+            np.testing.assert_allclose(grads[k[9:]].flatten()[::7].numpy(), z[k], rtol=1e-3, atol=1e-6)
+        if k.startswith("after_step/"):
+            np.testing.assert_allclose(P[k[11:]].numpy(), z[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_full_width_train_step(golden_dir):
+    z, P, x, ev, gt, base = _load(golden_dir, "full26_train")
+    st = O.TrainState(P)
+    loss, gnorm, grads, pred = O.train_step(P, st, x, ev, gt)
+    np.testing.assert_allclose(pred.numpy(), z["out"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(loss.numpy(), z["loss"], rtol=1e-5)
+    np.testing.assert_allclose(float(gnorm), float(z["grad_norm"]), rtol=1e-4)
+    gn = np.array([float(grads[k].norm()) for k in P.keys()])
+    np.testing.assert_allclose(gn, z["grad_norms_all"], rtol=5e-4, atol=1e-7)
+    for k in z.files:
+        if k.startswith("after_step/"):
+            np.testing.assert_allclose(P[k[11:]].numpy(), z[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_odd_sizes_and_config1(golden_dir):
+    z, P, x, ev, gt, _ = _load(golden_dir, "odd26_fwd")
+    with torch.no_grad():
+        out = O.forward(P, x, ev)
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=RTOL, atol=ATOL)
+    z, P, x, ev, gt, _ = _load(golden_dir, "config1_fwd")      # BASELINE config 1
+    with torch.no_grad():
+        out = O.forward(P, x, ev)
+    assert tuple(out.shape) == (1, 4, 3, 128, 128)
+    np.testing.assert_allclose(out[..., ::4, ::4].numpy(), z["out_sub"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out.double().abs().mean().item(), float(z["out_mean_abs"]), rtol=1e-5)
+
+
+def test_h_not_multiple_of_8_raises(golden_dir):
+    assert bool(np.load(os.path.join(golden_dir, "negative.npz"))["h100_raises"])
+    P = O.make_params(26, base_num_channels=8)
+    x, ev, _ = O.make_inputs(1, 2, 100, 96, 26)
+    with pytest.raises(RuntimeError):
+        O.forward(P, x, ev)
+
+
+def test_psnr_known_answers():
+    # metrics/psnr_ssim.py:48-63 + utils/img_util.py:90-117 restated; hand-computed answers
+    a = torch.full((3, 8, 8), 0.5)
+    b = a + 10.0 / 255.0
+    ia, ib = O.tensor2img_u8(a), O.tensor2img_u8(b)
+    assert int(ia[0, 0, 0]) == 128 and int(ib[0, 0, 0]) == 138     # round(127.5)=128 (banker's: 128)
+    assert abs(O.psnr_u8(ia, ib) - 20 * np.log10(255.0 / 10.0)) < 1e-9
+    assert O.psnr_u8(ia, ia) == float("inf")
+    assert int(O.tensor2img_u8(torch.full((3, 2, 2), 1.7))[0, 0, 0]) == 255
+    assert int(O.tensor2img_u8(torch.full((3, 2, 2), -0.3))[0, 0, 0]) == 0
+
+
+def test_cosine_lr_matches_torch():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=2e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=1e-7)
+    for i in range(1, 20):
+        opt.step(); sch.step()
+        assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(2e-4, i, 50, 1e-7)) < 1e-12

@@ -1,0 +1,153 @@
+/*
+ * refid_hip.h -- C ABI of the MI355X-native REFID hot path (librefid_hip.so).
+ *
+ * The reference (AHupuJR/REFID) is pure Python/PyTorch and has no FFI of its own:
+ * every arithmetic op on its hot path is a torch.nn call that lands in cuDNN/ATen
+ * ("Native / CUDA kernel inventory: empty").  The entry points
+ * below are therefore the operator-level boundary a maintainer would bind instead of
+ * those torch.nn calls; each one cites the reference call site(s) it replaces
+ * (paths relative to /root/reference/basicsr/models/archs unless noted).
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers, ints, floats; no torch types.
+ *  - activations are NHWC fp32 ("pixel-major": channel is the fastest axis), every
+ *    tensor is described by a base pointer and a pixel pitch `ld` (floats) so channel
+ *    slices of wider buffers can be addressed; base pointers and pitches are multiples
+ *    of 4 floats (16 B).
+ *  - every function is asynchronous on the caller's `stream` (a hipStream_t passed as
+ *    void*), allocates nothing, keeps no global mutable state and is re-entrant.
+ *  - return value: 0 = ok, non-zero = error; refid_last_error() returns a thread-local
+ *    message for the last failing call on this thread.
+ */
+#ifndef REFID_HIP_H
+#define REFID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REFID_ABI_VERSION 1
+
+const char* refid_last_error(void);
+int refid_abi_version(void);
+
+/* Device facts used by the host-side scheduler (CU count etc.); -1 on failure. */
+int refid_device_cu_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Fused convolution tile:   out = mask( post( pre(conv(src) + bias) + res ) )
+ *
+ *   src   = in_a                    (c_b == 0)
+ *         = [in_a | in_b]           channel concatenation WITHOUT materialising the cat
+ *   pre   = LeakyReLU(slope_pre)    (1.0 = identity, 0.0 = ReLU)
+ *   post  = LeakyReLU(slope_post)   applied after the residual add
+ *   mask  = multiply by (mask_src > 0 ? 1 : slope_mask)   (activation derivative, backward)
+ *
+ * Replaces (forward): nn.Conv2d + LeakyReLU/ReLU + residual adds + torch.cat at
+ *   recurrent_sub_modules.py:41-49 (ImageEncoderConvBlock), :74-84 (ConvLayer),
+ *   :270-296 (EvR level: conv, cat+fuse_two_dir, down), :386-408 (decoder: ConvTranspose2d,
+ *   cat), :488-503 (ResidualBlock), :659-678 + :719-726 + :755-758 (EvR hidden-state
+ *   update trunk), fusion_modules.py:300-331 (the 1x1 convs of EGACA),
+ *   XXNet_final_attenfusion_arch.py:147-149,215 (heads, pred).
+ * Replaces (backward): the autograd conv-backward "input gradient" of the same calls
+ *   (SURVEY.md Appendix A.2): dgrad is the same tile run on the transposed/flipped
+ *   packed weights (refid_pack_conv_weights with role=REFID_ROLE_DGRAD).
+ *
+ * mode 0: ordinary conv, kh x kw, stride 1 or 2, zero padding `pad`.
+ * mode 1: ConvTranspose2d(k=2,s=2) forward as a 1x1 GEMM with 4*Co columns and a
+ *         pixel-shuffle store (column j -> (dy,dx)=(j/Co/2, j/Co%2), channel j%Co);
+ *         `cout` is 4*Co, (h,w) the INPUT size, output is (2h,2w).
+ * mode 2: input-gradient of conv4x4/stride2/pad1 (`conv_down`): four output-parity
+ *         classes, each a 2x2-tap conv over the (h,w) gradient, stored at (2y+py,2x+px).
+ * ---------------------------------------------------------------------------------- */
+typedef struct refid_conv_desc {
+    const float* in_a;  const float* in_b;      /* NHWC sources                         */
+    int ld_a, ld_b;                             /* pixel pitch (floats)                 */
+    int c_a, c_b;                               /* channels taken from each source      */
+    const float* w_packed;                      /* see refid_pack_conv_weights          */
+    const float* bias;                          /* [cout] or NULL                       */
+    float* out;          int ld_out;
+    const float* res;    int ld_res;            /* NULL = none                          */
+    const float* mask;   int ld_mask;           /* NULL = none                          */
+    int n, h, w;                                /* input batch / height / width         */
+    int ho, wo;                                 /* GEMM pixel grid (output h,w; mode 1/2: = h,w) */
+    int cout;                                   /* GEMM columns computed by this call   */
+    int cout_pad;                               /* rows per tap in w_packed             */
+    int co_base;                                /* first row of w_packed / bias used    */
+    int kh, kw, stride, pad;
+    int mode;
+    float slope_pre, slope_post, slope_mask;
+} refid_conv_desc;
+
+int refid_conv2d(const refid_conv_desc* d, void* stream);
+
+/* Channel-chunk width (KC) and row padding (BN) the conv tile for this geometry wants
+ * its packed weights in. */
+int refid_conv_kc(int kh, int kw, int stride, int mode);
+int refid_conv_bn(int kh, int kw, int stride, int mode, int cout);
+
+/* ------------------------------------------------------------------------------------
+ * Weight gradient + bias gradient of the same convolutions (autograd's conv-backward
+ * "weight gradient"):
+ *   dW[o][i][ky][kx] (+)= sum_{n,y,x} g[n,y,x,o] * src[n, y*s+ky-pad, x*s+kx-pad, i]
+ *   db[o]            (+)= sum_{n,y,x} g[n,y,x,o]
+ * written in the reference's own parameter layout (OIHW for Conv2d; for
+ * ConvTranspose2d pass g := the layer input, src := the output gradient, which yields
+ * IOHW).  Two stages: partial products per pixel split into `slabs`, then a reduction
+ * that ACCUMULATES into dw/db (gradients of weights shared over the T steps add up,
+ * SURVEY.md A.2 first row).
+ * ---------------------------------------------------------------------------------- */
+typedef struct refid_wgrad_desc {
+    const float* g;      int ld_g;   int c_o;   /* output-gradient, (n,ho,wo,c_o)       */
+    const float* in_a;   const float* in_b;     /* conv input sources, (n,h,w,c_a|c_b)  */
+    int ld_a, ld_b;
+    int c_a, c_b;
+    float* dw;                                  /* (c_o, c_a+c_b, kh, kw) accumulated   */
+    float* db;                                  /* (c_o) accumulated, or NULL           */
+    float* slabs;                               /* workspace, refid_wgrad_workspace_bytes */
+    int n, h, w, ho, wo;
+    int kh, kw, stride, pad;
+    int i_base, i_total;                        /* dw second-dim offset / full size (slices) */
+} refid_wgrad_desc;
+
+size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d);
+int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight packing: reference layouts (Conv2d OIHW, ConvTranspose2d IOHW) -> the tile's
+ * [chunk][tap][row][KC] layout, rows/chunks zero padded.
+ *   role FWD   : rows = O, k = I, taps in order
+ *   role DGRAD : rows = I, k = O, taps flipped (stride-1 convs), or 2x2/s2 (convT input
+ *                gradient), or the four parity classes of conv4x4/s2 (mode 2)
+ *   role CONVT : ConvTranspose2d forward (mode 1): rows = (dy,dx,Co), k = Ci
+ * ---------------------------------------------------------------------------------- */
+enum { REFID_ROLE_FWD = 0, REFID_ROLE_DGRAD = 1, REFID_ROLE_CONVT = 2, REFID_ROLE_CONVT_DGRAD = 3,
+       REFID_ROLE_DOWN_DGRAD = 4 };
+size_t refid_packed_weight_floats(int role, int o, int i, int kh, int kw, int kc, int bn);
+int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int i, int kh, int kw,
+                            int kc, int bn, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Layout / elementwise helpers on the boundary.
+ * ---------------------------------------------------------------------------------- */
+/* NCHW (n,c,h,w) -> NHWC (n,h,w,c_pad), channels >= c zero filled.  Replaces the
+ * einops.rearrange calls at XXNet_final_attenfusion_arch.py:140-143 (layout change only). */
+int refid_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad, void* stream);
+/* NHWC (n,h,w,ld) first c channels -> NCHW (n,c,h,w) with an output batch stride (so a
+ * (B,T,3,H,W) stack is written in place: XXNet_final_attenfusion_arch.py:218). */
+int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch_stride,
+                       int n, int c, int h, int w, void* stream);
+/* out = a + b (skip sums: XXNet_final_attenfusion_arch.py:16-17,199-203,211,215;
+ * recurrent_sub_modules.py:278). count = number of floats, multiple of 4. */
+int refid_add(const float* a, const float* b, float* out, long long count, void* stream);
+/* out = (acc ? out : 0) + g * (y > 0 ? 1 : slope): activation derivative. */
+int refid_act_bwd(const float* g, const float* y, float* out, float slope, int accumulate,
+                  long long count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REFID_HIP_H */

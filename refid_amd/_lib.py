@@ -1,0 +1,92 @@
+"""ctypes binding of librefid_hip.so (the C ABI declared in include/refid_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point fails, the
+caller gets an exception.  Build it with ``python -m refid_amd.build``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librefid_hip.so")
+
+
+class RefidHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("in_a", C.c_void_p), ("in_b", C.c_void_p),
+        ("ld_a", C.c_int), ("ld_b", C.c_int),
+        ("c_a", C.c_int), ("c_b", C.c_int),
+        ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("ld_out", C.c_int),
+        ("res", C.c_void_p), ("ld_res", C.c_int),
+        ("mask", C.c_void_p), ("ld_mask", C.c_int),
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int),
+        ("ho", C.c_int), ("wo", C.c_int),
+        ("cout", C.c_int), ("cout_pad", C.c_int), ("co_base", C.c_int),
+        ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("mode", C.c_int),
+        ("slope_pre", C.c_float), ("slope_post", C.c_float), ("slope_mask", C.c_float),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("g", C.c_void_p), ("ld_g", C.c_int), ("c_o", C.c_int),
+        ("in_a", C.c_void_p), ("in_b", C.c_void_p),
+        ("ld_a", C.c_int), ("ld_b", C.c_int),
+        ("c_a", C.c_int), ("c_b", C.c_int),
+        ("dw", C.c_void_p), ("db", C.c_void_p), ("slabs", C.c_void_p),
+        ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("ho", C.c_int), ("wo", C.c_int),
+        ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("i_base", C.c_int), ("i_total", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RefidHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RefidHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU/eager fallback). "
+            "Run `python -m refid_amd.build`.")
+    L = C.CDLL(LIB_PATH)
+    L.refid_last_error.restype = C.c_char_p
+    L.refid_abi_version.restype = C.c_int
+    L.refid_device_cu_count.restype = C.c_int
+    L.refid_conv2d.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
+    L.refid_conv_kc.argtypes = [C.c_int] * 4
+    L.refid_conv_bn.argtypes = [C.c_int] * 5
+    L.refid_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
+    L.refid_wgrad_workspace_bytes.restype = C.c_size_t
+    L.refid_conv2d_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]
+    L.refid_packed_weight_floats.argtypes = [C.c_int] * 7
+    L.refid_packed_weight_floats.restype = C.c_size_t
+    L.refid_pack_conv_weights.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+    L.refid_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.refid_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong] + [C.c_int] * 4 + [C.c_void_p]
+    L.refid_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    L.refid_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_longlong, C.c_void_p]
+    _bind_extra(L)
+    if L.refid_abi_version() != 1:
+        raise RefidHipError("librefid_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _bind_extra(L):
+    """Entry points added after the first milestone (kept separate so a stale .so fails loudly)."""
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().refid_last_error().decode("utf-8", "replace")
+        raise RefidHipError(f"{what} failed (rc={rc}): {msg}")

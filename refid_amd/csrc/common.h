@@ -1,0 +1,34 @@
+// Shared helpers for the REFID HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/refid_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void refid_set_error(const char* fmt, ...);
+
+#define REFID_CHECK(cond, ...)                    \
+    do {                                          \
+        if (!(cond)) {                            \
+            refid_set_error(__VA_ARGS__);         \
+            return 1;                             \
+        }                                         \
+    } while (0)
+
+#define REFID_LAUNCH_CHECK(what)                                                   \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            refid_set_error("%s: launch failed: %s", what, hipGetErrorString(e__)); \
+            return 2;                                                              \
+        }                                                                          \
+    } while (0)
+
+__device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

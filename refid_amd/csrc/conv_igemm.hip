@@ -1,0 +1,374 @@
+// Fused implicit-GEMM convolution tile on the gfx950 fp32 matrix cores.
+//
+//   out = mask( post( pre(conv(src) + bias) + res ) ),   src = in_a or [in_a | in_b]
+//
+// One kernel template serves every dense convolution on the REFID hot path, forward and
+// input-gradient:
+//   mode 0  KxK conv, stride 1/2          (3x3, 5x5, 1x1, 4x4s2 `conv_down`, 2x2s2 = convT dgrad)
+//   mode 1  ConvTranspose2d(2,2) forward  (1x1 GEMM, 4*Co columns, pixel-shuffle store)
+//   mode 2  conv_down input gradient      (4 output-parity classes of 2x2 taps)
+//
+// Mapping to the hardware (MI355X, CDNA4):
+//   * GEMM view: M = output pixels, N = output channels, K = taps x input channels.
+//     D[pixel][cout] is accumulated with v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//   * A workgroup (256 threads = 4 waves, one per SIMD) owns TH x 32 output pixels x BN
+//     output channels; a wave owns MT x NT tiles of 32 pixels x 32 channels (MT*NT*16
+//     accumulator VGPRs).
+//   * K is walked in chunks of KC = 8*NSUB input channels.  Per chunk the input HALO tile
+//     ((TH-1)*S+KH) x (31*S+KW) pixels x KC channels is staged once in LDS and re-used by
+//     all KH*KW taps (the 9x / 25x / 16x re-use never touches L2/HBM); the weight tile
+//     [tap][BN][KC] is staged next to it.
+//   * LDS image is [channel-quad][pixel][4 floats]: lane (i = l&31, kh = l>>5) fetches its
+//     four K values of pixel i with ONE ds_read_b128 from plane (2*sub+kh); the four
+//     MFMAs that follow consume k-pairs (c, c+4).  Consecutive pixels are consecutive
+//     16-byte slots, so the b128 lane groups are conflict-free.
+//   * The next chunk is prefetched global->VGPR while the current chunk's MFMAs run and is
+//     written to LDS after them (register double buffering, 2 barriers per chunk); several
+//     workgroups per CU cover each other's barrier bubbles.
+//   * NHWC activations: a halo pixel's KC channels are one contiguous 32..128-byte piece.
+//   * Epilogue is fused: bias, LeakyReLU, residual add, second LeakyReLU, activation-
+//     derivative mask; stores are 128-byte contiguous runs per pixel (32 channels).
+#include "common.h"
+
+namespace {
+
+struct ConvKArgs {
+    const float* inA; const float* inB;
+    int ldA, ldB, Ca, Ctot;
+    const float* w; const float* bias;
+    float* out; int ldO;
+    const float* res; int ldR;
+    const float* mask; int ldM;
+    int N, H, W, Ho, Wo;
+    int Cout, CoutPad, coBase;
+    int pad, nchunks, tilesX, tilesY;
+    float slopePre, slopePost, slopeMask;
+    long long wClsStride;
+};
+
+template <int KH_, int KW_, int S_, int WM_, int WN_, int MT_, int NT_, int NSUB_, int MODE_>
+struct Cfg {
+    static constexpr int KH = KH_, KW = KW_, S = S_, WM = WM_, WN = WN_, MT = MT_, NT = NT_;
+    static constexpr int NSUB = NSUB_, MODE = MODE_;
+    static constexpr int TW = 32;
+    static constexpr int TH = WM * MT;
+    static constexpr int BN = WN * NT * 32;
+    static constexpr int NTAPS = (MODE == 2) ? 4 : KH * KW;
+    static constexpr int HH = (MODE == 2) ? TH + 2 : (TH - 1) * S + KH;
+    static constexpr int HWD = (MODE == 2) ? TW + 2 : (TW - 1) * S + KW;
+    static constexpr int HP = HH * HWD;
+    static constexpr int NQ = NSUB * 2;          // channel quads per chunk
+    static constexpr int KC = NSUB * 8;
+    static constexpr int A_TOTAL = HP * NQ;
+    static constexpr int B_TOTAL = NTAPS * BN * NQ;
+    static constexpr int A_ITEMS = (A_TOTAL + 255) / 256;
+    static constexpr int B_ITEMS = (B_TOTAL + 255) / 256;
+    static constexpr int LDS_BYTES = (A_TOTAL + B_TOTAL) * 16;
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(256 % NQ == 0, "thread -> channel-quad mapping must be static");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* sA = reinterpret_cast<f32x4*>(smem);
+    f32x4* sB = sA + C::A_TOTAL;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    const int li = lane & 31, kh = lane >> 5;
+
+    int bt = blockIdx.x;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int n = bt / a.tilesY;
+    const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+    const int n0 = blockIdx.y * C::BN;
+    const int cls = (C::MODE == 2) ? blockIdx.z : 0;
+    const int py = cls >> 1, px = cls & 1;
+    const int iy0 = (C::MODE == 2) ? oy0 - 1 : oy0 * C::S - a.pad;
+    const int ix0 = (C::MODE == 2) ? ox0 - 1 : ox0 * C::S - a.pad;
+
+    // ---- loader set-up (pixel offsets do not change across K chunks) --------------------
+    const int q = tid % C::NQ;                  // this thread's channel quad within a chunk
+    long long apix[C::A_ITEMS];                 // pixel index or -1
+#pragma unroll
+    for (int it = 0; it < C::A_ITEMS; ++it) {
+        const int hp = tid / C::NQ + it * (256 / C::NQ);
+        const int hy = hp / C::HWD, hx = hp % C::HWD;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        const bool ok = (hp < C::HP) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        apix[it] = ok ? ((long long)(n * a.H + iy) * a.W + ix) : -1;
+    }
+    const float* wbase = a.w + (long long)cls * a.wClsStride;
+
+    f32x4 ra[C::A_ITEMS], rb[C::B_ITEMS];
+
+    auto load_chunk = [&](int ch) {
+        const int c = ch * C::KC + q * 4;
+        const bool fromA = c < a.Ca;
+        const float* src = fromA ? a.inA : a.inB;
+        const int ld = fromA ? a.ldA : a.ldB;
+        const int cc = fromA ? c : c - a.Ca;
+        const bool cok = c < a.Ctot;
+#pragma unroll
+        for (int it = 0; it < C::A_ITEMS; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && apix[it] >= 0) v = *reinterpret_cast<const f32x4*>(src + apix[it] * ld + cc);
+            ra[it] = v;
+        }
+        const float* wc = wbase + (long long)ch * (C::NTAPS * a.CoutPad * C::KC);
+#pragma unroll
+        for (int it = 0; it < C::B_ITEMS; ++it) {
+            const int r = tid / C::NQ + it * (256 / C::NQ);
+            const int co = r % C::BN, tap = r / C::BN;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < C::NTAPS * C::BN)
+                v = *reinterpret_cast<const f32x4*>(
+                    wc + ((long long)(tap * a.CoutPad + a.coBase + n0 + co)) * C::KC + q * 4);
+            rb[it] = v;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::A_ITEMS; ++it) {
+            const int hp = tid / C::NQ + it * (256 / C::NQ);
+            if (hp < C::HP) sA[q * C::HP + hp] = ra[it];
+        }
+#pragma unroll
+        for (int it = 0; it < C::B_ITEMS; ++it) {
+            const int r = tid / C::NQ + it * (256 / C::NQ);
+            const int co = r % C::BN, tap = r / C::BN;
+            if (r < C::NTAPS * C::BN) sB[(q * C::NTAPS + tap) * C::BN + co] = rb[it];
+        }
+    };
+
+    // ---- accumulators ---------------------------------------------------------------------
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < C::NT; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+
+    constexpr int HS = (C::MODE == 2) ? 1 : C::S;       // halo stride per output pixel
+    int hpb[C::MT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) hpb[m] = ((wm * C::MT + m) * HS) * C::HWD + li * HS;
+
+    int tapoff2[4];
+    if (C::MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ta = t >> 1, tb = t & 1;
+            const int dy = (ta == 0) ? 1 : (py ? 2 : 0);
+            const int dx = (tb == 0) ? 1 : (px ? 2 : 0);
+            tapoff2[t] = dy * C::HWD + dx;
+        }
+    }
+    const int bcol = wn * C::NT * 32 + li;
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const bool more = ch + 1 < a.nchunks;
+        if (more) load_chunk(ch + 1);
+
+#pragma unroll
+        for (int sub = 0; sub < C::NSUB; ++sub) {
+            const f32x4* pA = sA + (sub * 2 + kh) * C::HP;
+            const f32x4* pB = sB + (sub * 2 + kh) * C::NTAPS * C::BN + bcol;
+#pragma unroll
+            for (int t = 0; t < C::NTAPS; ++t) {
+                const int toff = (C::MODE == 2) ? tapoff2[t] : (t / C::KW) * C::HWD + (t % C::KW);
+                f32x4 af[C::MT], bf[C::NT];
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) af[m] = pA[hpb[m] + toff];
+#pragma unroll
+                for (int nn = 0; nn < C::NT; ++nn) bf[nn] = pB[t * C::BN + nn * 32];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                        for (int nn = 0; nn < C::NT; ++nn)
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][kk], bf[nn][kk],
+                                                                             acc[m][nn], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---- fused epilogue -------------------------------------------------------------------
+    const int Co1 = (C::MODE == 1) ? (a.Cout >> 2) : a.Cout;   // real channels (mode 1)
+    const int OW = (C::MODE == 0) ? a.Wo : 2 * a.Wo;
+    const int OH = (C::MODE == 0) ? a.Ho : 2 * a.Ho;
+#pragma unroll
+    for (int nn = 0; nn < C::NT; ++nn) {
+        const int j = n0 + wn * C::NT * 32 + nn * 32 + li;        // GEMM column
+        if (j >= a.Cout) continue;
+        int ch = j, sy = 0, sx = 0;
+        if (C::MODE == 1) { const int qd = j / Co1; ch = j - qd * Co1; sy = qd >> 1; sx = qd & 1; }
+        if (C::MODE == 2) { sy = py; sx = px; }
+        const float bv = a.bias ? a.bias[(C::MODE == 1) ? ch : a.coBase + j] : 0.f;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            const int oy = oy0 + wm * C::MT + m;
+            if (oy >= a.Ho) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (ox >= a.Wo) continue;
+                long long op;
+                if (C::MODE == 0) op = (long long)(n * OH + oy) * OW + ox;
+                else op = (long long)(n * OH + 2 * oy + sy) * OW + 2 * ox + sx;
+                float v = acc[m][nn][r] + bv;
+                v = lrelu(v, a.slopePre);
+                if (a.res) v += a.res[op * a.ldR + ch];
+                v = lrelu(v, a.slopePost);
+                if (a.mask) v *= (a.mask[op * a.ldM + ch] > 0.f) ? 1.f : a.slopeMask;
+                a.out[op * a.ldO + ch] = v;
+            }
+        }
+    }
+}
+
+template <class C>
+int launch(const ConvKArgs& ka, int ncls, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) { refid_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return 2; }
+        attr_set = true;
+    }
+    ConvKArgs a = ka;
+    a.tilesX = cdiv(a.Wo, C::TW);
+    a.tilesY = cdiv(a.Ho, C::TH);
+    a.nchunks = cdiv(a.Ctot, C::KC);
+    dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, C::BN), ncls);
+    hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
+    REFID_LAUNCH_CHECK("conv_igemm");
+    return 0;
+}
+
+// tile families: <KH,KW,S, WM,WN,MT,NT, NSUB, MODE>
+using C3_64 = Cfg<3, 3, 1, 4, 1, 2, 2, 1, 0>;     // 8x32 px x 64 ch
+using C3_128 = Cfg<3, 3, 1, 2, 2, 2, 2, 1, 0>;    // 4x32 px x 128 ch
+using C3_32 = Cfg<3, 3, 1, 4, 1, 2, 1, 1, 0>;     // 8x32 px x 32 ch
+using C5_32 = Cfg<5, 5, 1, 4, 1, 2, 1, 1, 0>;
+using C1_64 = Cfg<1, 1, 1, 4, 1, 2, 2, 4, 0>;
+using C1_128 = Cfg<1, 1, 1, 2, 2, 2, 2, 4, 0>;
+using C1_32 = Cfg<1, 1, 1, 4, 1, 2, 1, 4, 0>;
+using C4S2_64 = Cfg<4, 4, 2, 4, 1, 2, 2, 1, 0>;
+using C2S2_64 = Cfg<2, 2, 2, 4, 1, 2, 2, 1, 0>;
+using C2S2_128 = Cfg<2, 2, 2, 2, 2, 2, 2, 1, 0>;
+using CT_128 = Cfg<1, 1, 1, 2, 2, 2, 2, 4, 1>;    // convT 2x2 forward
+using CT_64 = Cfg<1, 1, 1, 4, 1, 2, 2, 4, 1>;
+using CD_64 = Cfg<3, 3, 1, 4, 1, 2, 2, 2, 2>;     // conv_down dgrad
+using CD_128 = Cfg<3, 3, 1, 2, 2, 2, 2, 2, 2>;
+
+enum Family { F_3x3, F_5x5, F_1x1, F_4x4s2, F_2x2s2, F_convT, F_downDgrad, F_none };
+
+Family family_of(int kh, int kw, int stride, int mode) {
+    if (mode == 1) return F_convT;
+    if (mode == 2) return F_downDgrad;
+    if (kh == 3 && kw == 3 && stride == 1) return F_3x3;
+    if (kh == 5 && kw == 5 && stride == 1) return F_5x5;
+    if (kh == 1 && kw == 1 && stride == 1) return F_1x1;
+    if (kh == 4 && kw == 4 && stride == 2) return F_4x4s2;
+    if (kh == 2 && kw == 2 && stride == 2) return F_2x2s2;
+    return F_none;
+}
+
+}  // namespace
+
+extern "C" int refid_conv_kc(int kh, int kw, int stride, int mode) {
+    switch (family_of(kh, kw, stride, mode)) {
+        case F_3x3: case F_5x5: case F_4x4s2: case F_2x2s2: return 8;
+        case F_1x1: case F_convT: return 32;
+        case F_downDgrad: return 16;
+        default: return -1;
+    }
+}
+
+extern "C" int refid_conv_bn(int kh, int kw, int stride, int mode, int cout) {
+    switch (family_of(kh, kw, stride, mode)) {
+        case F_3x3: case F_1x1: return cout <= 32 ? 32 : (cout <= 64 ? 64 : 128);
+        case F_5x5: return 32;
+        case F_4x4s2: return 64;
+        case F_2x2s2: case F_downDgrad: case F_convT: return cout <= 64 ? 64 : 128;
+        default: return -1;
+    }
+}
+
+extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    REFID_CHECK(d != nullptr, "conv2d: null descriptor");
+    const Family f = family_of(d->kh, d->kw, d->stride, d->mode);
+    REFID_CHECK(f != F_none, "conv2d: unsupported geometry k=%dx%d stride=%d mode=%d", d->kh, d->kw,
+                d->stride, d->mode);
+    REFID_CHECK(d->in_a && d->w_packed && d->out, "conv2d: null tensor pointer");
+    REFID_CHECK(d->c_a > 0 && d->c_a % 4 == 0 && d->c_b % 4 == 0 && d->c_b >= 0,
+                "conv2d: channel counts must be multiples of 4 (c_a=%d c_b=%d)", d->c_a, d->c_b);
+    REFID_CHECK(d->ld_a % 4 == 0 && (d->c_b == 0 || d->ld_b % 4 == 0),
+                "conv2d: pixel pitches must be multiples of 4 floats");
+    REFID_CHECK(d->c_b == 0 || d->in_b != nullptr, "conv2d: c_b > 0 but in_b is null");
+    REFID_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
+                "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
+                d->wo, d->cout);
+    const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
+    REFID_CHECK(d->cout_pad % bn == 0 && d->co_base % 32 == 0 &&
+                    d->co_base + round_up(d->cout, bn) <= d->cout_pad,
+                "conv2d: cout_pad=%d / co_base=%d incompatible with tile width %d (cout=%d)", d->cout_pad,
+                d->co_base, bn, d->cout);
+    if (d->mode == 0) {
+        const int eh = (d->h + 2 * d->pad - d->kh) / d->stride + 1;
+        const int ew = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+        REFID_CHECK(eh == d->ho && ew == d->wo, "conv2d: output size %dx%d does not match geometry (%dx%d)",
+                    d->ho, d->wo, eh, ew);
+    } else {
+        REFID_CHECK(d->ho == d->h && d->wo == d->w, "conv2d: mode %d needs ho,wo == h,w", d->mode);
+        REFID_CHECK(d->mode != 1 || d->cout % 4 == 0, "conv2d: mode 1 needs cout = 4*Co");
+    }
+    ConvKArgs a;
+    a.inA = d->in_a; a.inB = d->in_b; a.ldA = d->ld_a; a.ldB = d->ld_b;
+    a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
+    a.w = d->w_packed; a.bias = d->bias;
+    a.out = d->out; a.ldO = d->ld_out;
+    a.res = d->res; a.ldR = d->ld_res;
+    a.mask = d->mask; a.ldM = d->ld_mask;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
+    a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
+    a.pad = d->pad; a.nchunks = 0; a.tilesX = a.tilesY = 0;
+    a.slopePre = d->slope_pre; a.slopePost = d->slope_post; a.slopeMask = d->slope_mask;
+    const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode);
+    a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
+    switch (f) {
+        case F_3x3:
+            if (bn == 32) return launch<C3_32>(a, 1, st);
+            if (bn == 64) return launch<C3_64>(a, 1, st);
+            return launch<C3_128>(a, 1, st);
+        case F_5x5: return launch<C5_32>(a, 1, st);
+        case F_1x1:
+            if (bn == 32) return launch<C1_32>(a, 1, st);
+            if (bn == 64) return launch<C1_64>(a, 1, st);
+            return launch<C1_128>(a, 1, st);
+        case F_4x4s2: return launch<C4S2_64>(a, 1, st);
+        case F_2x2s2: return bn == 64 ? launch<C2S2_64>(a, 1, st) : launch<C2S2_128>(a, 1, st);
+        case F_convT: return bn == 64 ? launch<CT_64>(a, 1, st) : launch<CT_128>(a, 1, st);
+        case F_downDgrad: return bn == 64 ? launch<CD_64>(a, 4, st) : launch<CD_128>(a, 4, st);
+        default: break;
+    }
+    refid_set_error("conv2d: no tile for this geometry");
+    return 1;
+}

@@ -1,0 +1,343 @@
+// Weight-gradient (and bias-gradient) of the REFID convolutions on the fp32 matrix cores.
+//
+//   dW[o][i][ky][kx] += sum_{n,y,x} g[n,y,x,o] * src[n, y*S+ky-pad, x*S+kx-pad, i]
+//   db[o]            += sum_{n,y,x} g[n,y,x,o]
+//
+// GEMM view: M = output channels (o), N = input channels (i), K = output pixels; one
+// accumulator tile per tap.  v_mfma_f32_32x32x2_f32 consumes two adjacent pixels per
+// instruction: lane (r = l&31, kh = l>>5) supplies g[pixel 2q+kh][o = r] and
+// src[pixel' (2q+kh)*S + tap][i = r] -- both are plain conflict-free ds_read_b32 from the
+// NHWC LDS images (32 consecutive channels per half-wave).
+//
+// A workgroup owns a (COT x CIT) channel tile for ALL taps and walks a strided subset of
+// the pixel tiles (split-K over pixels); per pixel tile the gradient tile and the input
+// HALO tile are staged once in LDS and re-used by every tap.  Partial sums go to private
+// slabs [split][tap][o][i] with plain coalesced stores (no atomics, deterministic); a
+// second kernel reduces the slabs and ACCUMULATES into the parameter-layout gradient,
+// because weights are shared over the T recurrent steps.
+#include "common.h"
+
+namespace {
+
+struct WgKArgs {
+    const float* g; int ldG, Co;
+    const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
+    float* slabs; float* bslabs;
+    int N, H, W, Ho, Wo, pad;
+    int tilesX, tilesY, ntiles, nsplit;
+    int CoP, CiP;
+};
+
+template <int KH_, int KW_, int S_, int TPW_, int SM_, int SN_, int WR_, int WC_, int WT_, int TH_, int TW_>
+struct WCfg {
+    static constexpr int KH = KH_, KW = KW_, S = S_, TPW = TPW_, SM = SM_, SN = SN_;
+    static constexpr int WR = WR_, WC = WC_, WT = WT_, TH = TH_, TW = TW_;
+    static constexpr int NTAPS = KH * KW;
+    static constexpr int COT = WR * SM * 32, CIT = WC * SN * 32;
+    static constexpr int PX = TH * TW;
+    static constexpr int HH = (TH - 1) * S + KH, HWD = (TW - 1) * S + KW, HP = HH * HWD;
+    static constexpr int G4 = COT / 4, X4 = CIT / 4;
+    static constexpr int G_TOTAL = PX * G4, X_TOTAL = HP * X4;
+    static constexpr int G_ITEMS = (G_TOTAL + 255) / 256, X_ITEMS = (X_TOTAL + 255) / 256;
+    static constexpr int LDS_BYTES = (G_TOTAL + X_TOTAL) * 16 + COT * 4;
+    static_assert(WR * WC * WT == 4, "4 waves");
+    static_assert(WT * TPW >= NTAPS, "tap groups must cover the kernel");
+    static_assert(TW % 2 == 0 && 256 % G4 == 0 && 256 % X4 == 0, "static thread->channel mapping");
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* sG4 = reinterpret_cast<f32x4*>(smem);
+    f32x4* sX4 = sG4 + C::G_TOTAL;
+    float* sBias = reinterpret_cast<float*>(sX4 + C::X_TOTAL);
+    const float* sG = reinterpret_cast<const float*>(sG4);
+    const float* sX = reinterpret_cast<const float*>(sX4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tg = wave % C::WT;                       // tap group
+    const int wc = (wave / C::WT) % C::WC;
+    const int wr = wave / (C::WT * C::WC);
+    const int co0 = blockIdx.z * C::COT, ci0 = blockIdx.y * C::CIT;
+    const int split = blockIdx.x;
+
+    // static thread -> channel mapping of the loaders
+    const int gq = tid % C::G4, xq = tid % C::X4;
+    const int gco = co0 + gq * 4;
+    const bool gcok = gco < a.Co;
+    const int xc = ci0 + xq * 4;
+    const bool xFromA = xc < a.Ca;
+    const bool xcok = xc < a.Ctot;
+    const float* xsrc = xFromA ? a.inA : a.inB;
+    const int xld = xFromA ? a.ldA : a.ldB;
+    const int xcc = xFromA ? xc : xc - a.Ca;
+
+    int tdy[C::TPW], tdx[C::TPW];
+    bool tok[C::TPW];
+#pragma unroll
+    for (int tt = 0; tt < C::TPW; ++tt) {
+        const int tap = tg * C::TPW + tt;
+        tok[tt] = tap < C::NTAPS;
+        tdy[tt] = tap / C::KW; tdx[tt] = tap % C::KW;
+    }
+
+    f32x16 acc[C::TPW][C::SM][C::SN];
+#pragma unroll
+    for (int tt = 0; tt < C::TPW; ++tt)
+#pragma unroll
+        for (int sm = 0; sm < C::SM; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < C::SN; ++sn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[tt][sm][sn][r] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 rg[C::G_ITEMS], rx[C::X_ITEMS];
+
+    auto load_tile = [&](int pt) {
+        int t = pt;
+        const int tx = t % a.tilesX; t /= a.tilesX;
+        const int ty = t % a.tilesY;
+        const int n = t / a.tilesY;
+        const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+        const int iy0 = oy0 * C::S - a.pad, ix0 = ox0 * C::S - a.pad;
+#pragma unroll
+        for (int it = 0; it < C::G_ITEMS; ++it) {
+            const int p = tid / C::G4 + it * (256 / C::G4);
+            const int oy = oy0 + p / C::TW, ox = ox0 + p % C::TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gcok && p < C::PX && oy < a.Ho && ox < a.Wo)
+                v = *reinterpret_cast<const f32x4*>(a.g + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
+            rg[it] = v;
+            bsum += v;
+        }
+#pragma unroll
+        for (int it = 0; it < C::X_ITEMS; ++it) {
+            const int hp = tid / C::X4 + it * (256 / C::X4);
+            const int iy = iy0 + hp / C::HWD, ix = ix0 + hp % C::HWD;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (xcok && hp < C::HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const f32x4*>(xsrc + ((long long)(n * a.H + iy) * a.W + ix) * xld + xcc);
+            rx[it] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::G_ITEMS; ++it) {
+            const int p = tid / C::G4 + it * (256 / C::G4);
+            if (p < C::PX) sG4[p * C::G4 + gq] = rg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < C::X_ITEMS; ++it) {
+            const int hp = tid / C::X4 + it * (256 / C::X4);
+            if (hp < C::HP) sX4[hp * C::X4 + xq] = rx[it];
+        }
+    };
+
+    int pt = split;
+    if (pt < a.ntiles) {
+        load_tile(pt);
+        store_tile();
+    }
+    __syncthreads();
+
+    const int aoff = wr * C::SM * 32 + li;
+    const int boff = wc * C::SN * 32 + li;
+
+    for (; pt < a.ntiles; pt += a.nsplit) {
+        const bool more = pt + a.nsplit < a.ntiles;
+        if (more) load_tile(pt + a.nsplit);
+
+        for (int row = 0; row < C::TH; ++row) {
+#pragma unroll 4
+            for (int qk = 0; qk < C::TW / 2; ++qk) {
+                const int pcol = 2 * qk + kh;
+                float av[C::SM];
+#pragma unroll
+                for (int sm = 0; sm < C::SM; ++sm) av[sm] = sG[(row * C::TW + pcol) * C::COT + aoff + sm * 32];
+#pragma unroll
+                for (int tt = 0; tt < C::TPW; ++tt) {
+                    if (C::WT > 1 && !tok[tt]) continue;
+                    const int hp = (row * C::S + tdy[tt]) * C::HWD + pcol * C::S + tdx[tt];
+                    float bv[C::SN];
+#pragma unroll
+                    for (int sn = 0; sn < C::SN; ++sn) bv[sn] = sX[hp * C::CIT + boff + sn * 32];
+#pragma unroll
+                    for (int sm = 0; sm < C::SM; ++sm)
+#pragma unroll
+                        for (int sn = 0; sn < C::SN; ++sn)
+                            acc[tt][sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sm], bv[sn],
+                                                                                  acc[tt][sm][sn], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- write the partial slab: [split][tap][co][ci], 128-byte runs along ci -------------
+#pragma unroll
+    for (int tt = 0; tt < C::TPW; ++tt) {
+        const int tap = tg * C::TPW + tt;
+        if (tap >= C::NTAPS) continue;
+        float* sl = a.slabs + ((long long)(split * C::NTAPS + tap) * a.CoP) * a.CiP;
+#pragma unroll
+        for (int sm = 0; sm < C::SM; ++sm)
+#pragma unroll
+            for (int sn = 0; sn < C::SN; ++sn) {
+                const int ci = ci0 + wc * C::SN * 32 + sn * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wr * C::SM * 32 + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    sl[(long long)co * a.CiP + ci] = acc[tt][sm][sn][r];
+                }
+            }
+    }
+    // ---- bias partial: only the first input-channel tile column owns it -------------------
+    if (a.bslabs != nullptr && blockIdx.y == 0) {
+        if (tid < C::COT) sBias[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
+        __syncthreads();
+        if (tid < C::COT) a.bslabs[(long long)split * a.CoP + co0 + tid] = sBias[tid];
+    }
+}
+
+struct RedArgs {
+    const float* slabs; const float* bslabs; float* dw; float* db;
+    int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal;
+};
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
+    // threads <-> (tap, co, ci), ci fastest (coalesced slab reads)
+    const long long total = (long long)a.ntaps * a.Co * a.Ci;
+    const long long slabStride = (long long)a.ntaps * a.CoP * a.CiP;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long r = e;
+        const int ci = r % a.Ci; r /= a.Ci;
+        const int co = r % a.Co;
+        const int tap = r / a.Co;
+        const float* p = a.slabs + ((long long)tap * a.CoP + co) * a.CiP + ci;
+        float s = 0.f;
+        for (int k = 0; k < a.nsplit; ++k) s += p[k * slabStride];
+        float* d = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * a.ntaps + tap;
+        *d += s;
+    }
+    if (a.db != nullptr && blockIdx.x == 0) {
+        for (int co = threadIdx.x; co < a.Co; co += 256) {
+            float s = 0.f;
+            for (int k = 0; k < a.nsplit; ++k) s += a.bslabs[(long long)k * a.CoP + co];
+            a.db[co] += s;
+        }
+    }
+}
+
+// <KH,KW,S, TPW, SM,SN, WR,WC,WT, TH,TW>
+using W3 = WCfg<3, 3, 1, 9, 1, 1, 2, 2, 1, 2, 32>;
+using W1 = WCfg<1, 1, 1, 1, 2, 2, 2, 2, 1, 2, 32>;
+using W4S2 = WCfg<4, 4, 2, 8, 1, 1, 2, 1, 2, 2, 16>;
+using W5 = WCfg<5, 5, 1, 7, 1, 1, 1, 1, 4, 2, 32>;
+using W2S2 = WCfg<2, 2, 2, 4, 1, 1, 2, 2, 1, 2, 16>;
+
+struct Plan { int cot, cit, th, tw, ntaps; bool ok; };
+
+Plan plan_of(int kh, int kw, int s) {
+    if (kh == 3 && kw == 3 && s == 1) return {W3::COT, W3::CIT, W3::TH, W3::TW, 9, true};
+    if (kh == 1 && kw == 1 && s == 1) return {W1::COT, W1::CIT, W1::TH, W1::TW, 1, true};
+    if (kh == 4 && kw == 4 && s == 2) return {W4S2::COT, W4S2::CIT, W4S2::TH, W4S2::TW, 16, true};
+    if (kh == 5 && kw == 5 && s == 1) return {W5::COT, W5::CIT, W5::TH, W5::TW, 25, true};
+    if (kh == 2 && kw == 2 && s == 2) return {W2S2::COT, W2S2::CIT, W2S2::TH, W2S2::TW, 4, true};
+    return {0, 0, 0, 0, 0, false};
+}
+
+struct Geo { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
+
+Geo geo_of(const refid_wgrad_desc* d, const Plan& p) {
+    Geo g;
+    g.ncoT = cdiv(d->c_o, p.cot);
+    g.nciT = cdiv(d->c_a + d->c_b, p.cit);
+    g.tilesX = cdiv(d->wo, p.tw);
+    g.tilesY = cdiv(d->ho, p.th);
+    g.ntiles = g.tilesX * g.tilesY * d->n;
+    int want = cdiv(768, g.ncoT * g.nciT);           // ~3 workgroups per CU on 256 CUs
+    if (want < 1) want = 1;
+    if (want > g.ntiles) want = g.ntiles;
+    g.nsplit = want;
+    g.CoP = g.ncoT * p.cot;
+    g.CiP = g.nciT * p.cit;
+    return g;
+}
+
+template <class C>
+int launch_w(const WgKArgs& a, const Geo& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<C>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) { refid_set_error("wgrad: LDS attribute: %s", hipGetErrorString(e)); return 2; }
+        attr_set = true;
+    }
+    dim3 grid(g.nsplit, g.nciT, g.ncoT);
+    hipLaunchKernelGGL(wgrad_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
+    REFID_LAUNCH_CHECK("wgrad");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
+    if (!d) return 0;
+    const Plan p = plan_of(d->kh, d->kw, d->stride);
+    if (!p.ok) return 0;
+    const Geo g = geo_of(d, p);
+    return ((size_t)g.nsplit * p.ntaps * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP) * sizeof(float);
+}
+
+extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    REFID_CHECK(d != nullptr, "wgrad: null descriptor");
+    const Plan p = plan_of(d->kh, d->kw, d->stride);
+    REFID_CHECK(p.ok, "wgrad: unsupported geometry k=%dx%d stride=%d", d->kh, d->kw, d->stride);
+    REFID_CHECK(d->g && d->in_a && d->dw && d->slabs, "wgrad: null tensor pointer");
+    REFID_CHECK(d->c_o > 0 && d->c_o % 4 == 0 && d->c_a > 0 && d->c_a % 4 == 0 && d->c_b >= 0 && d->c_b % 4 == 0,
+                "wgrad: channel counts must be multiples of 4 (c_o=%d c_a=%d c_b=%d)", d->c_o, d->c_a, d->c_b);
+    REFID_CHECK(d->ld_g % 4 == 0 && d->ld_a % 4 == 0 && (d->c_b == 0 || (d->in_b && d->ld_b % 4 == 0)),
+                "wgrad: bad pitches / missing in_b");
+    const int eh = (d->h + 2 * d->pad - d->kh) / d->stride + 1;
+    const int ew = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
+    REFID_CHECK(eh == d->ho && ew == d->wo, "wgrad: output size %dx%d does not match geometry (%dx%d)", d->ho,
+                d->wo, eh, ew);
+    REFID_CHECK(d->i_total >= d->i_base + d->c_a + d->c_b, "wgrad: i_base/i_total inconsistent");
+    const Geo g = geo_of(d, p);
+    WgKArgs a;
+    a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;
+    a.inA = d->in_a; a.inB = d->in_b; a.ldA = d->ld_a; a.ldB = d->ld_b;
+    a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
+    a.slabs = d->slabs;
+    a.bslabs = d->db ? d->slabs + (size_t)g.nsplit * p.ntaps * g.CoP * g.CiP : nullptr;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pad = d->pad;
+    a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
+    a.CoP = g.CoP; a.CiP = g.CiP;
+    int rc;
+    if (d->kh == 3) rc = launch_w<W3>(a, g, st);
+    else if (d->kh == 1) rc = launch_w<W1>(a, g, st);
+    else if (d->kh == 4) rc = launch_w<W4S2>(a, g, st);
+    else if (d->kh == 5) rc = launch_w<W5>(a, g, st);
+    else rc = launch_w<W2S2>(a, g, st);
+    if (rc) return rc;
+    RedArgs r;
+    r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
+    r.nsplit = g.nsplit; r.ntaps = p.ntaps; r.Co = d->c_o; r.Ci = a.Ctot; r.CoP = g.CoP; r.CiP = g.CiP;
+    r.iBase = d->i_base; r.iTotal = d->i_total;
+    const long long total = (long long)p.ntaps * r.Co * r.Ci;
+    long long nb = (total + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)nb), dim3(256), 0, st, r);
+    REFID_LAUNCH_CHECK("wgrad_reduce");
+    return 0;
+}

@@ -1,0 +1,217 @@
+// Error plumbing, device queries, layout conversion, weight packing and small
+// elementwise kernels of the REFID C ABI.
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void refid_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* refid_last_error(void) { return g_err; }
+extern "C" int refid_abi_version(void) { return REFID_ABI_VERSION; }
+
+extern "C" int refid_device_cu_count(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return -1;
+    return p.multiProcessorCount;
+}
+
+namespace {
+
+// ---- NCHW -> NHWC (padded) : one block transposes a 32-pixel x C strip through LDS ----------
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
+                                                          float* __restrict__ dst, int C, int HW,
+                                                          int Cpad) {
+    // grid.x = pixel blocks of 64, grid.y = n
+    __shared__ float tile[64][65];
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // ty in 0..3
+    for (int c0 = 0; c0 < Cpad; c0 += 64) {
+        // read: coalesced along pixels
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc, p = p0 + tx;
+            tile[cc][tx] = (c < C && p < HW) ? src[((long long)n * C + c) * HW + p] : 0.f;
+        }
+        __syncthreads();
+        // write: coalesced along channels
+        for (int pp = ty; pp < 64; pp += 4) {
+            const int c = c0 + tx, p = p0 + pp;
+            if (c < Cpad && p < HW) dst[((long long)n * HW + p) * Cpad + c] = tile[tx][pp];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld,
+                                                          float* __restrict__ dst,
+                                                          long long dstBatchStride, int C, int HW) {
+    __shared__ float tile[64][65];
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        for (int pp = ty; pp < 64; pp += 4) {
+            const int c = c0 + tx, p = p0 + pp;
+            tile[pp][tx] = (c < C && p < HW) ? src[((long long)n * HW + p) * ld + c] : 0.f;
+        }
+        __syncthreads();
+        for (int cc = ty; cc < 64; cc += 4) {
+            const int c = c0 + cc, p = p0 + tx;
+            if (c < C && p < HW) dst[(long long)n * dstBatchStride + (long long)c * HW + p] = tile[tx][cc];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b,
+                                                 f32x4* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        out[i] = a[i] + b[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ y,
+                                                     f32x4* __restrict__ out, float slope, int acc,
+                                                     long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 gv = g[i], yv = y[i];
+        f32x4 o = acc ? out[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] += gv[k] * (yv[k] > 0.f ? 1.f : slope);
+        out[i] = o;
+    }
+}
+
+// ---- weight packing --------------------------------------------------------------------------
+// packed[cls][chunk][tap][row][k] = W[src index] or 0.
+struct PackArgs {
+    const float* w; float* dst;
+    int role, O, I, KH, KW, KC, rows, rowsPad, K, nchunks, ntaps, ncls;
+};
+
+__device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap, int row, int k) {
+    const int KK = p.KH * p.KW;
+    switch (p.role) {
+        case REFID_ROLE_FWD:            // rows = O, k = I ; W[o][i][tap]
+            return p.w[((long long)row * p.I + k) * KK + tap];
+        case REFID_ROLE_DGRAD:          // rows = I, k = O ; flipped taps
+            return p.w[((long long)k * p.I + row) * KK + (KK - 1 - tap)];
+        case REFID_ROLE_CONVT: {        // W is (I=Ci, O=Co, 2, 2); rows = (q, co), k = ci
+            const int Co = p.O;
+            const int qd = row / Co, co = row - qd * Co;
+            return p.w[((long long)k * Co + co) * 4 + qd];
+        }
+        case REFID_ROLE_CONVT_DGRAD:    // rows = ci, k = co, tap = dy*2+dx
+            return p.w[((long long)row * p.O + k) * 4 + tap];
+        case REFID_ROLE_DOWN_DGRAD: {   // W (O,I,4,4); rows = i, k = o; class (py,px), tap (ta,tb)
+            const int py = cls >> 1, px = cls & 1, ta = tap >> 1, tb = tap & 1;
+            const int ky = (ta == 0) ? (py ? 2 : 1) : (py ? 0 : 3);
+            const int kx = (tb == 0) ? (px ? 2 : 1) : (px ? 0 : 3);
+            return p.w[((long long)k * p.I + row) * 16 + ky * 4 + kx];
+        }
+    }
+    return 0.f;
+}
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackArgs p) {
+    const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long r = e;
+        const int kk = r % p.KC; r /= p.KC;
+        const int row = r % p.rowsPad; r /= p.rowsPad;
+        const int tap = r % p.ntaps; r /= p.ntaps;
+        const int chunk = r % p.nchunks;
+        const int cls = r / p.nchunks;
+        const int k = chunk * p.KC + kk;
+        float v = 0.f;
+        if (row < p.rows && k < p.K) v = pack_fetch(p, cls, tap, row, k);
+        p.dst[e] = v;
+    }
+}
+
+int pack_geometry(int role, int o, int i, int kh, int kw, int kc, int bn, PackArgs* p) {
+    p->role = role; p->O = o; p->I = i; p->KH = kh; p->KW = kw; p->KC = kc;
+    p->ncls = 1;
+    switch (role) {
+        case REFID_ROLE_FWD: p->rows = o; p->K = i; p->ntaps = kh * kw; break;
+        case REFID_ROLE_DGRAD: p->rows = i; p->K = o; p->ntaps = kh * kw; break;
+        case REFID_ROLE_CONVT: p->rows = 4 * o; p->K = i; p->ntaps = 1; break;
+        case REFID_ROLE_CONVT_DGRAD: p->rows = i; p->K = o; p->ntaps = 4; break;
+        case REFID_ROLE_DOWN_DGRAD: p->rows = i; p->K = o; p->ntaps = 4; p->ncls = 4; break;
+        default: return 1;
+    }
+    p->rowsPad = round_up(p->rows, bn);
+    p->nchunks = cdiv(p->K, kc);
+    return 0;
+}
+
+int grid_for(long long n) {
+    long long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+extern "C" size_t refid_packed_weight_floats(int role, int o, int i, int kh, int kw, int kc, int bn) {
+    PackArgs p;
+    if (pack_geometry(role, o, i, kh, kw, kc, bn, &p)) return 0;
+    return (size_t)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
+}
+
+extern "C" int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int i, int kh,
+                                       int kw, int kc, int bn, void* stream) {
+    PackArgs p;
+    REFID_CHECK(w && packed, "pack: null pointer");
+    REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack: unknown role %d", role);
+    REFID_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),
+                "pack: convT roles need a 2x2 kernel");
+    REFID_CHECK(role != REFID_ROLE_DOWN_DGRAD || (kh == 4 && kw == 4), "pack: down-dgrad needs a 4x4 kernel");
+    p.w = w; p.dst = packed;
+    const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    REFID_LAUNCH_CHECK("pack_conv_weights");
+    return 0;
+}
+
+extern "C" int refid_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad,
+                                  void* stream) {
+    REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc: bad arguments");
+    dim3 grid(cdiv(h * w, 64), n);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, c, h * w, c_pad);
+    REFID_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch_stride, int n,
+                                  int c, int h, int w, void* stream) {
+    REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && ld >= c, "nhwc_to_nchw: bad arguments");
+    dim3 grid(cdiv(h * w, 64), n);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, dst,
+                       dst_batch_stride, c, h * w);
+    REFID_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int refid_add(const float* a, const float* b, float* out, long long count, void* stream) {
+    REFID_CHECK(a && b && out && count > 0 && count % 4 == 0, "add: bad arguments (count=%lld)", count);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)a, (const f32x4*)b, (f32x4*)out, count / 4);
+    REFID_LAUNCH_CHECK("add");
+    return 0;
+}
+
+extern "C" int refid_act_bwd(const float* g, const float* y, float* out, float slope, int accumulate,
+                             long long count, void* stream) {
+    REFID_CHECK(g && y && out && count > 0 && count % 4 == 0, "act_bwd: bad arguments (count=%lld)", count);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)g, (const f32x4*)y, (f32x4*)out, slope, accumulate, count / 4);
+    REFID_LAUNCH_CHECK("act_bwd");
+    return 0;
+}

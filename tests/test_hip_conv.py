@@ -1,0 +1,257 @@
+"""GPU parity of the fused conv tile / wgrad C-ABI entry points against torch CPU fp64
+(the same torch.nn.functional ops the oracle is made of).  Tolerance: fp32 round-off of
+a K-long dot product, rtol 1e-4 / atol 1e-5 on O(1) data (north-star bar is 1e-3/1e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 2e-5
+
+
+def _ops():
+    from refid_amd import ops
+    return ops
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().float().cuda()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).double().cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def lrelu(x, s):
+    return torch.where(x > 0, x, x * s)
+
+
+def run_fwd(N, H, W, Ca, Cb, Co, k, stride, pad, bias=True, res=False, slope_pre=1.0, slope_post=1.0,
+            mask=False, pad_ca=None):
+    ops = _ops()
+    Ci = Ca + Cb
+    xa = rnd(N, Ca, H, W, seed=1)
+    xb = rnd(N, Cb, H, W, seed=2) if Cb else None
+    w = rnd(Co, Ci, k, k, seed=3, scale=1.0 / np.sqrt(Ci * k * k))
+    b = rnd(Co, seed=4) if bias else None
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    ref = F.conv2d(x, w, b, stride, pad)
+    ref = lrelu(ref, slope_pre)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = rnd(N, Co, Ho, Wo, seed=5) if res else None
+    if res:
+        ref = ref + r
+    ref = lrelu(ref, slope_post)
+    m = rnd(N, Co, Ho, Wo, seed=6) if mask else None
+    if mask:
+        ref = ref * torch.where(m > 0, 1.0, 0.3)
+    kc, bn = ops.conv_kc(k, k, stride), ops.conv_bn(k, k, stride, 0, Co)
+    wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_FWD, bn, kc, k, k, Co, Ci)
+    copad = -(-Co // bn) * bn
+    a_dev = nhwc(xa)
+    if pad_ca:      # channel-padded source (e.g. 2 -> 4, 26 -> 28): extra channels are zero
+        buf = torch.zeros(N, H, W, pad_ca, device="cuda")
+        buf[..., :Ca] = a_dev
+        a_dev = buf
+    Cop = -(-Co // 4) * 4
+    outbuf = torch.full((N, Ho, Wo, Cop), 7.0, device="cuda")
+    out = outbuf[..., :Co]
+    ops.conv2d(a_dev, wp, out, kh=k, kw=k, stride=stride, pad=pad, cout=Co, cout_pad=copad,
+               in_b=nhwc(xb) if Cb else None, bias=b.float().cuda() if bias else None,
+               res=nhwc(r) if res else None, mask=nhwc(m) if mask else None,
+               slope_pre=slope_pre, slope_post=slope_post, slope_mask=0.3)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+    if Cop != Co:
+        assert float(outbuf[..., Co:].min()) == 7.0      # pad channels untouched
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co, k, s, p
+    (2, 16, 32, 32, 0, 64, 3, 1, 1),          # EvR L0 first conv
+    (1, 24, 40, 64, 64, 64, 3, 1, 1),         # trunk main.0 (two-source), ragged tiles
+    (1, 8, 8, 128, 128, 128, 3, 1, 1),        # 128-wide tile, tiny image
+    (1, 12, 20, 64, 0, 256, 3, 1, 1),         # two cout tiles
+    (2, 16, 16, 32, 32, 32, 3, 1, 1),         # decoder level 2 (32-wide tile)
+    (1, 16, 32, 32, 0, 3, 3, 1, 1),           # pred: 3 output channels
+    (1, 16, 24, 2, 0, 32, 5, 1, 2),           # event head: Cin=2 (padded to 4)
+    (1, 16, 24, 26, 0, 32, 5, 1, 2),          # image head: Cin=26 (padded to 28)
+    (2, 8, 16, 64, 64, 64, 1, 1, 0),          # fuse_two_dir
+    (1, 16, 16, 32, 0, 64, 1, 1, 0),          # identity 1x1
+    (1, 8, 8, 128, 0, 128, 1, 1, 0),
+    (1, 8, 8, 64, 0, 32, 1, 1, 0),
+    (2, 16, 32, 64, 0, 64, 4, 2, 1),          # conv_down
+    (1, 24, 40, 128, 0, 128, 4, 2, 1),
+    (1, 16, 16, 32, 0, 64, 2, 2, 0),          # 2x2 stride 2 (convT input gradient)
+    (1, 8, 16, 64, 0, 128, 2, 2, 0),
+])
+def test_conv_forward_geometries(cfg):
+    N, H, W, Ca, Cb, Co, k, s, p = cfg
+    pad_ca = (-(-Ca // 4) * 4) if Ca % 4 else None
+    run_fwd(N, H, W, Ca, Cb, Co, k, s, p, pad_ca=pad_ca)
+
+
+def test_conv_fused_epilogues():
+    run_fwd(1, 16, 32, 64, 0, 64, 3, 1, 1, slope_pre=0.04)                        # double LeakyReLU(.2)
+    run_fwd(1, 16, 32, 64, 0, 64, 3, 1, 1, res=True)                                # trunk residual
+    run_fwd(1, 8, 32, 128, 0, 128, 3, 1, 1, res=True, slope_post=0.0)               # ResidualBlock
+    run_fwd(1, 8, 32, 64, 64, 64, 3, 1, 1, slope_pre=0.1, bias=True)                # trunk main.0
+    run_fwd(1, 8, 32, 64, 0, 64, 3, 1, 1, bias=False, res=True, mask=True)          # dgrad-style epilogue
+
+
+def _pack_dgrad(ops, w, role, k, stride, mode, rows, kdim):
+    kc = ops.conv_kc(k, k, stride, mode)
+    bn = ops.conv_bn(k, k, stride, mode, rows)
+    o, i = (w.shape[1], w.shape[0]) if role in (ops.ROLE_CONVT, ops.ROLE_CONVT_DGRAD) else (w.shape[0], w.shape[1])
+    return ops.pack_conv_weights(w.float().cuda(), role, bn, kc, w.shape[2], w.shape[3], o, i), -(-rows // bn) * bn
+
+
+@pytest.mark.parametrize("cfg", [(1, 16, 32, 32, 64, 3), (1, 8, 24, 128, 64, 3), (2, 8, 8, 64, 128, 1),
+                                 (1, 8, 16, 256, 128, 3)])
+def test_conv_dgrad_stride1(cfg):
+    ops = _ops()
+    N, H, W, Ci, Co, k = cfg
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, k, k, seed=2, scale=0.1)
+    g = rnd(N, Co, H, W, seed=3)
+    F.conv2d(x, w, None, 1, k // 2).backward(g)
+    wp, rp = _pack_dgrad(ops, w, ops.ROLE_DGRAD, k, 1, 0, Ci, Co)
+    out = torch.empty(N, H, W, Ci, device="cuda")
+    ops.conv2d(nhwc(g), wp, out, kh=k, kw=k, stride=1, pad=k // 2, cout=Ci, cout_pad=rp)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_conv_dgrad_split_rows():
+    """dgrad of a two-source conv computed as two row ranges of the same packed weights."""
+    ops = _ops()
+    N, H, W, C = 1, 8, 32, 64
+    x = rnd(N, 2 * C, H, W, seed=1).requires_grad_(True)
+    w = rnd(C, 2 * C, 3, 3, seed=2, scale=0.1)
+    g = rnd(N, C, H, W, seed=3)
+    F.conv2d(x, w, None, 1, 1).backward(g)
+    wp, rp = _pack_dgrad(ops, w, ops.ROLE_DGRAD, 3, 1, 0, 2 * C, C)
+    gd = nhwc(g)
+    for base in (0, C):
+        out = torch.empty(N, H, W, C, device="cuda")
+        ops.conv2d(gd, wp, out, kh=3, kw=3, stride=1, pad=1, cout=C, cout_pad=rp, co_base=base)
+        np.testing.assert_allclose(nchw(out).numpy(), x.grad[:, base:base + C].numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 32, 64), (1, 24, 40, 128), (1, 8, 8, 256)])
+def test_conv_down_dgrad(cfg):
+    ops = _ops()
+    N, H, W, C = cfg
+    x = rnd(N, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(C, C, 4, 4, seed=2, scale=0.1)
+    y = F.conv2d(x, w, None, 2, 1)
+    g = rnd(*y.shape, seed=3)
+    y.backward(g)
+    wp, rp = _pack_dgrad(ops, w, ops.ROLE_DOWN_DGRAD, 4, 2, 2, C, C)
+    out = torch.empty(N, H, W, C, device="cuda")
+    ops.conv2d(nhwc(g), wp, out, kh=4, kw=4, stride=2, pad=1, mode=2, cout=C, cout_pad=rp)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", [(2, 8, 8, 256, 128), (1, 12, 20, 128, 64), (1, 16, 32, 64, 32)])
+def test_conv_transpose_fwd_and_dgrad(cfg):
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Ci, Co, 2, 2, seed=2, scale=0.1)
+    b = rnd(Co, seed=3)
+    y = F.conv_transpose2d(x, w, b, stride=2)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    wp, rp = _pack_dgrad(ops, w, ops.ROLE_CONVT, 1, 1, 1, 4 * Co, Ci)
+    out = torch.empty(N, 2 * H, 2 * W, Co, device="cuda")
+    ops.conv2d(nhwc(x.detach()), wp, out, kh=1, kw=1, stride=1, pad=0, mode=1, cout=4 * Co, cout_pad=rp,
+               bias=b.float().cuda())
+    np.testing.assert_allclose(nchw(out).numpy(), y.detach().numpy(), rtol=RTOL, atol=ATOL)
+    wd, rd = _pack_dgrad(ops, w, ops.ROLE_CONVT_DGRAD, 2, 2, 0, Ci, Co)
+    dx = torch.empty(N, H, W, Ci, device="cuda")
+    ops.conv2d(nhwc(g), wd, dx, kh=2, kw=2, stride=2, pad=0, cout=Ci, cout_pad=rd)
+    np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co, k, s, p
+    (2, 16, 32, 64, 0, 64, 3, 1, 1),
+    (1, 24, 40, 64, 64, 64, 3, 1, 1),
+    (1, 8, 8, 256, 256, 256, 3, 1, 1),
+    (1, 16, 32, 32, 32, 32, 3, 1, 1),
+    (1, 16, 24, 28, 0, 32, 5, 1, 2),
+    (2, 8, 16, 128, 128, 128, 1, 1, 0),
+    (1, 16, 16, 32, 0, 64, 1, 1, 0),
+    (2, 16, 32, 64, 0, 64, 4, 2, 1),
+    (1, 24, 40, 128, 0, 128, 4, 2, 1),
+    (1, 16, 16, 32, 0, 64, 2, 2, 0),
+])
+def test_conv_wgrad(cfg):
+    ops = _ops()
+    N, H, W, Ca, Cb, Co, k, s, p = cfg
+    x = rnd(N, Ca + Cb, H, W, seed=1)
+    w = rnd(Co, Ca + Cb, k, k, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, s, p)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    dw = torch.zeros(Co, Ca + Cb, k, k, device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    xa = nhwc(x[:, :Ca])
+    xb = nhwc(x[:, Ca:]) if Cb else None
+    for _ in range(2):      # accumulates: two calls -> 2x
+        ops.conv2d_wgrad(nhwc(g), xa, dw, kh=k, kw=k, stride=s, pad=p, in_b=xb, db=db)
+    scale = max(1.0, float(w.grad.abs().max()))
+    np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+    np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+
+
+def test_conv_transpose_wgrad():
+    ops = _ops()
+    N, H, W, Ci, Co = 1, 8, 16, 128, 64
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Ci, Co, 2, 2, seed=2).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, None, stride=2)
+    g = rnd(*y.shape, seed=3)
+    y.backward(g)
+    dw = torch.zeros(Ci, Co, 2, 2, device="cuda")
+    # roles swapped: "g" := layer input (low res), "src" := output gradient (high res) -> IOHW
+    ops.conv2d_wgrad(nhwc(x), nhwc(g), dw, kh=2, kw=2, stride=2, pad=0)
+    np.testing.assert_allclose(dw.double().cpu().numpy(), w.grad.numpy(), rtol=RTOL, atol=ATOL * 4)
+
+
+def test_layout_and_elementwise():
+    ops = _ops()
+    x = rnd(2, 26, 8, 24, seed=1).float()
+    d = ops.nchw_to_nhwc(x.cuda(), 28)
+    assert d.shape == (2, 8, 24, 28)
+    np.testing.assert_array_equal(d[..., :26].permute(0, 3, 1, 2).cpu().numpy(), x.numpy())
+    assert float(d[..., 26:].abs().max()) == 0.0
+    stack = torch.zeros(2, 3, 3, 8, 24, device="cuda")           # (B,T,3,H,W)
+    src = torch.rand(2, 8, 24, 4, device="cuda")
+    ops.nhwc_to_nchw(src[..., :3], 3, stack[:, 1], dst_batch_stride=3 * 3 * 8 * 24)
+    np.testing.assert_array_equal(stack[:, 1].cpu().numpy(), src[..., :3].permute(0, 3, 1, 2).cpu().numpy())
+    assert float(stack[:, 0].abs().max()) == 0.0 and float(stack[:, 2].abs().max()) == 0.0
+    a, b = torch.rand(2, 8, 8, 64, device="cuda"), torch.rand(2, 8, 8, 64, device="cuda") - 0.5
+    np.testing.assert_array_equal(ops.add(a, b).cpu().numpy(), (a + b).cpu().numpy())
+    o = ops.act_bwd(a, b, 0.1)
+    np.testing.assert_allclose(o.cpu().numpy(), (a * torch.where(b > 0, 1.0, 0.1)).cpu().numpy(), rtol=1e-6)
+    o2 = ops.act_bwd(a, b, 0.1, out=o.clone(), accumulate=True)
+    np.testing.assert_allclose(o2.cpu().numpy(), 2 * o.cpu().numpy(), rtol=1e-6)
+
+
+def test_errors_are_loud():
+    ops = _ops()
+    from refid_amd._lib import RefidHipError
+    x = torch.zeros(1, 8, 8, 64, device="cuda")
+    with pytest.raises(RefidHipError):
+        ops.conv2d(x, x, torch.zeros(1, 8, 8, 64, device="cuda"), kh=7, kw=7, cout=64, cout_pad=64)
+    with pytest.raises(RefidHipError):
+        ops.conv2d(x.cpu(), x, x, kh=3, kw=3, pad=1, cout=64, cout_pad=64)

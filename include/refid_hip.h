@@ -111,6 +111,8 @@ typedef struct refid_wgrad_desc {
     int n, h, w, ho, wo;
     int kh, kw, stride, pad;
     int i_base, i_total;                        /* dw second-dim offset / full size (slices) */
+    int o_real;                                 /* rows of dw/db actually written (<= c_o); the
+                                                   rest of g's channels is padding        */
 } refid_wgrad_desc;
 
 size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d);
@@ -130,12 +132,76 @@ size_t refid_packed_weight_floats(int role, int o, int i, int kh, int kw, int kc
 int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int i, int kh, int kw,
                             int kc, int bn, void* stream);
 
+/* Same as refid_pack_conv_weights with a per-OUTPUT-channel factor folded in (FWD/DGRAD
+ * roles).  Used to fold EGACA's beta / gamma (fusion_modules.py:287-288,319,331:
+ * `y = ev + img + x*beta`, `return y + x*gamma`) into conv3 / conv5 so the scaled branch
+ * and the residual add run in the conv tile's epilogue. */
+int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* packed, int role, int o,
+                                   int i, int kh, int kw, int kc, int bn, void* stream);
+int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
+/* After BPTT, turn the gradients accumulated for the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r])
+ * back into gradients of (W, b, scale):  dscale[r] += <W[r,:],G[r,:]> + b[r]*gb[r];
+ * G[r,:] *= scale[r]; gb[r] *= scale[r]. */
+int refid_fold_back(const float* w, const float* b, const float* scale, float* gw, float* gb,
+                    float* dscale, int rows, int k, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * EGACA non-GEMM pieces (fusion_modules.py:290-333) and LayerNorm2d (fusion_modules.py:97-134).
+ * c in {16,32,64,128}.  Parameter gradients ACCUMULATE (atomics) into dw/db.
+ * ---------------------------------------------------------------------------------- */
+int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float* b, float* out,
+                          int ld_out, long long npix, int c, float eps, void* stream);
+/* LayerNormFunction.backward, fusion_modules.py:110-122; gx (+)= ... when accumulate != 0 */
+int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
+                          int ld_gx, int accumulate, float* dw, float* db, long long npix, int c,
+                          float eps, void* stream);
+/* pre = dwconv3x3(in)+b ; act = GELU(pre) ; pool[n][c] = sum_pixels act   (fm:304-309 + se_1's
+ * AdaptiveAvgPool2d, fm:253-254; pool may be NULL).  w is the reference (c,1,3,3) tensor. */
+int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
+                             float* act, float* pool, int n, int h, int wd, int c, void* stream);
+/* gd = gradient w.r.t. `pre`; gin = input gradient; dw/db accumulate. */
+int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
+                        float* dw, float* db, int n, int h, int wd, int c, void* stream);
+/* se_1 (fm:253-260): m = pool*inv_hw ; z1 = relu(W1 m + b1) ; s = sigmoid(W2 z1 + b2) */
+int refid_se_fwd(const float* pool, float inv_hw, const float* w1, const float* b1, const float* w2,
+                 const float* b2, float* m, float* z1, float* s, int n, int c, void* stream);
+int refid_se_bwd(const float* gs, const float* s, const float* z1, const float* m, const float* w1,
+                 const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, int n, int c,
+                 void* stream);
+/* out[n,p,0:c] = xi*s[n] ; out[n,p,c:2c] = xe*s[n]   (fm:312-315, no cat temporary) */
+int refid_scale_cat(const float* xi, const float* xe, const float* s, float* out, int n, int hw, int c,
+                    void* stream);
+/* gs[n][c] = sum_p gxs[n,p,c]*xi + gxs[n,p,c+C]*xe  (dL/ds of the two products) */
+int refid_egaca_gs_reduce(const float* gxs, const float* xi, const float* xe, float* gs, int n, int hw,
+                          int c, void* stream);
+/* gdwe = (gxs_e*s + gm*inv_hw) * GELU'(dwe) ; gxi (+)= gxs_i*s */
+int refid_egaca_bwd_elem(const float* gxs, const float* s, const float* gm, float inv_hw, const float* dwe,
+                         float* gdwe, float* gxi, int accumulate_xi, int n, int hw, int c, void* stream);
+int refid_gelu_fwd(const float* in, float* out, long long count, void* stream);
+int refid_gelu_bwd(const float* g, const float* in, float* out, long long count, void* stream);
+/* db[c] += sum_p g[p][c]   (bias gradient where the wgrad call does not carry it) */
+int refid_colsum(const float* g, int ld_g, float* db, long long npix, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Train-step tail (twoImage_event_recurrent_model.py:273-310; losses/losses.py:28-30,143-173).
+ * ---------------------------------------------------------------------------------- */
+/* *loss_sum = sum sqrt((pred-gt)^2+eps); grad = (pred-gt)/sqrt(.)*grad_scale (grad may be NULL) */
+int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, long long count,
+                      float eps, float grad_scale, void* stream);
+int refid_grad_sqnorm(const float* g, double* out, long long count, void* stream);
+/* clip_grad_norm_(max_norm) (max_norm <= 0: off) + AdamW step over flat arenas; gradients are
+ * pre-multiplied by grad_scale (1/world_size after a SUM all-reduce). */
+int refid_clip_adamw(float* p, const float* g, float* m, float* v, const double* sqnorm, float max_norm,
+                     float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int step, long long count, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Layout / elementwise helpers on the boundary.
  * ---------------------------------------------------------------------------------- */
 /* NCHW (n,c,h,w) -> NHWC (n,h,w,c_pad), channels >= c zero filled.  Replaces the
  * einops.rearrange calls at XXNet_final_attenfusion_arch.py:140-143 (layout change only). */
-int refid_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad, void* stream);
+int refid_nchw_to_nhwc(const float* src, long long src_batch_stride, float* dst, int n, int c, int h, int w,
+                       int c_pad, void* stream);
 /* NHWC (n,h,w,ld) first c channels -> NCHW (n,c,h,w) with an output batch stride (so a
  * (B,T,3,H,W) stack is written in place: XXNet_final_attenfusion_arch.py:218). */
 int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch_stride,

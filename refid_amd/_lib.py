@@ -41,7 +41,7 @@ class WgradDesc(C.Structure):
         ("dw", C.c_void_p), ("db", C.c_void_p), ("slabs", C.c_void_p),
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("ho", C.c_int), ("wo", C.c_int),
         ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
-        ("i_base", C.c_int), ("i_total", C.c_int),
+        ("i_base", C.c_int), ("i_total", C.c_int), ("o_real", C.c_int),
     ]
 
 
@@ -70,7 +70,7 @@ def lib():
     L.refid_packed_weight_floats.argtypes = [C.c_int] * 7
     L.refid_packed_weight_floats.restype = C.c_size_t
     L.refid_pack_conv_weights.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
-    L.refid_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.refid_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
     L.refid_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong] + [C.c_int] * 4 + [C.c_void_p]
     L.refid_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     L.refid_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_longlong, C.c_void_p]
@@ -82,8 +82,26 @@ def lib():
 
 
 def _bind_extra(L):
-    """Entry points added after the first milestone (kept separate so a stale .so fails loudly)."""
-    pass
+    """EGACA / train-step entry points (a stale .so without them fails loudly here)."""
+    vp, i, f, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+    L.refid_pack_conv_weights_scaled.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
+    L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
+    L.refid_fold_back.argtypes = [vp] * 6 + [i, i, vp]
+    L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
+    L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, i, vp, vp, ll, i, f, vp]
+    L.refid_dwconv3x3_gelu_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
+    L.refid_dwconv3x3_bwd.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, i, vp]
+    L.refid_se_fwd.argtypes = [vp, f, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.refid_se_bwd.argtypes = [vp] * 11 + [i, i, vp]
+    L.refid_scale_cat.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    L.refid_egaca_gs_reduce.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    L.refid_egaca_bwd_elem.argtypes = [vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
+    L.refid_gelu_fwd.argtypes = [vp, vp, ll, vp]
+    L.refid_gelu_bwd.argtypes = [vp, vp, vp, ll, vp]
+    L.refid_colsum.argtypes = [vp, i, vp, ll, i, vp]
+    L.refid_charbonnier.argtypes = [vp, vp, vp, vp, ll, f, f, vp]
+    L.refid_grad_sqnorm.argtypes = [vp, vp, ll, vp]
+    L.refid_clip_adamw.argtypes = [vp, vp, vp, vp, vp, f, f, f, f, f, f, f, i, ll, vp]
 
 
 def check(rc, what):

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             const int r = tid / C::NQ + it * (256 / C::NQ);
             const int co = r % C::BN, tap = r / C::BN;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (r < C::NTAPS * C::BN)
+            if (r < C::NTAPS * C::BN && a.coBase + n0 + co < a.CoutPad)
                 v = *reinterpret_cast<const f32x4*>(
                     wc + ((long long)(tap * a.CoutPad + a.coBase + n0 + co)) * C::KC + q * 4);
             rb[it] = v;
@@ -327,10 +327,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
-    REFID_CHECK(d->cout_pad % bn == 0 && d->co_base % 32 == 0 &&
-                    d->co_base + round_up(d->cout, bn) <= d->cout_pad,
-                "conv2d: cout_pad=%d / co_base=%d incompatible with tile width %d (cout=%d)", d->cout_pad,
-                d->co_base, bn, d->cout);
+    REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
+                "conv2d: rows [%d, %d) exceed the packed weight's %d rows", d->co_base, d->co_base + d->cout,
+                d->cout_pad);
     if (d->mode == 0) {
         const int eh = (d->h + 2 * d->pad - d->kh) / d->stride + 1;
         const int ew = (d->w + 2 * d->pad - d->kw) / d->stride + 1;

@@ -312,7 +312,8 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     const int ew = (d->w + 2 * d->pad - d->kw) / d->stride + 1;
     REFID_CHECK(eh == d->ho && ew == d->wo, "wgrad: output size %dx%d does not match geometry (%dx%d)", d->ho,
                 d->wo, eh, ew);
-    REFID_CHECK(d->i_total >= d->i_base + d->c_a + d->c_b, "wgrad: i_base/i_total inconsistent");
+    REFID_CHECK(d->i_total > d->i_base && d->i_base >= 0 && d->o_real > 0 && d->o_real <= d->c_o,
+                "wgrad: i_base/i_total/o_real inconsistent");
     const Geo g = geo_of(d, p);
     WgKArgs a;
     a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;
@@ -332,7 +333,11 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     if (rc) return rc;
     RedArgs r;
     r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
-    r.nsplit = g.nsplit; r.ntaps = p.ntaps; r.Co = d->c_o; r.Ci = a.Ctot; r.CoP = g.CoP; r.CiP = g.CiP;
+    // channel-padded operands (e.g. 26 -> 28 image channels, 3 -> 4 output channels): only the
+    // real rows / columns of the parameter-layout gradient exist
+    r.nsplit = g.nsplit; r.ntaps = p.ntaps; r.Co = d->o_real;
+    r.Ci = a.Ctot < d->i_total - d->i_base ? a.Ctot : d->i_total - d->i_base;
+    r.CoP = g.CoP; r.CiP = g.CiP;
     r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total = (long long)p.ntaps * r.Co * r.Ci;
     long long nb = (total + 255) / 256;

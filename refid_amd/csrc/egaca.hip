@@ -1,0 +1,549 @@
+// EGACA (Event-Guided Adaptive Channel Attention) support kernels and the other
+// HBM-bound elementwise / reduction pieces of the REFID hot path.
+//
+// Reference: fusion_modules.py:97-134 (LayerNorm2d, hand-written backward :110-122) and
+// :290-333 (CrossmodalAtten_imgeventalladd.forward).  The 1x1 convolutions of EGACA run on
+// the fused conv tile (conv_igemm.hip); what is here is everything that is NOT a GEMM:
+//   per-pixel channel LayerNorm fwd/bwd, depthwise 3x3 (+bias) -> GELU (+ global-average-pool
+//   partial sums) fwd/bwd, the squeeze-excite MLP fwd/bwd, channel scaling + concat, GELU,
+//   column sums (bias gradients), and the beta/gamma fold-back.
+//
+// All of these are bandwidth-bound: every thread moves 16 bytes per access (float4 over 4
+// consecutive NHWC channels), a pixel's C channels are read by C/4 adjacent lanes (fully
+// coalesced 4*C-byte runs), reductions go wave-shuffle -> LDS -> one atomic per channel per
+// block.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_d(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// sum over the LPP lanes that share a pixel (LPP power of two <= 64, lanes contiguous)
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm2d forward: fm:100-108.  mean / biased variance over C per pixel, eps inside sqrt.
+template <int LPP>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    float* __restrict__ out, int ldo, long long npix, float eps) {
+    constexpr int C = LPP * 4, PPB = 256 / LPP;
+    const int q = threadIdx.x % LPP;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + q * 4);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + q * 4);
+    for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / LPP; p < npix; p += (long long)gridDim.x * PPB) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ldx + q * 4);
+        const float mu = group_sum<LPP>(v[0] + v[1] + v[2] + v[3]) * (1.f / C);
+        const f32x4 d = v - mu;
+        const float var = group_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+        const float rstd = 1.f / sqrtf(var + eps);
+        *reinterpret_cast<f32x4*>(out + p * ldo + q * 4) = wv * (d * rstd) + bv;
+    }
+}
+
+// LayerNorm2d backward: fm:110-122.  gx = rstd * (g*w - y*mean(g*w*y) - mean(g*w)),
+// dw += sum g*y, db += sum g.   gx accumulates into `gx` when acc != 0.
+template <int LPP>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, int ldg,
+                                                    const float* __restrict__ x, int ldx,
+                                                    const float* __restrict__ w, float* __restrict__ gx, int ldgx,
+                                                    int acc, float* __restrict__ dw, float* __restrict__ db,
+                                                    long long npix, float eps) {
+    constexpr int C = LPP * 4, PPB = 256 / LPP;
+    __shared__ float sdw[C], sdb[C];
+    const int q = threadIdx.x % LPP;
+    if (threadIdx.x < C) { sdw[threadIdx.x] = 0.f; sdb[threadIdx.x] = 0.f; }
+    __syncthreads();
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + q * 4);
+    f32x4 pdw = {0.f, 0.f, 0.f, 0.f}, pdb = {0.f, 0.f, 0.f, 0.f};
+    for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / LPP; p < npix; p += (long long)gridDim.x * PPB) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ldx + q * 4);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * ldg + q * 4);
+        const float mu = group_sum<LPP>(v[0] + v[1] + v[2] + v[3]) * (1.f / C);
+        const f32x4 d = v - mu;
+        const float var = group_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+        const float rstd = 1.f / sqrtf(var + eps);
+        const f32x4 y = d * rstd;
+        const f32x4 gh = gv * wv;
+        const float m1 = group_sum<LPP>(gh[0] + gh[1] + gh[2] + gh[3]) * (1.f / C);
+        const float m2 = group_sum<LPP>(gh[0] * y[0] + gh[1] * y[1] + gh[2] * y[2] + gh[3] * y[3]) * (1.f / C);
+        f32x4 r = (gh - y * m2 - m1) * rstd;
+        float* o = gx + p * ldgx + q * 4;
+        if (acc) r += *reinterpret_cast<const f32x4*>(o);
+        *reinterpret_cast<f32x4*>(o) = r;
+        pdw += gv * y;
+        pdb += gv;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { atomicAdd(&sdw[q * 4 + k], pdw[k]); atomicAdd(&sdb[q * 4 + k], pdb[k]); }
+    __syncthreads();
+    if (threadIdx.x < C) { atomicAdd(dw + threadIdx.x, sdw[threadIdx.x]); atomicAdd(db + threadIdx.x, sdb[threadIdx.x]); }
+}
+
+// ------------------------------------------------------------------------------------------
+// depthwise 3x3 (pad 1) + bias -> pre ; GELU(pre) -> act ; pool[n][c] += sum_pixels act
+// (fm:304-309 + the AdaptiveAvgPool2d of se_1, fm:253-260).  grid = (pixel chunks, N).
+template <int LPP>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ in, int ldi,
+                                                    const float* __restrict__ w, const float* __restrict__ b,
+                                                    float* __restrict__ pre, float* __restrict__ act,
+                                                    float* __restrict__ pool, int H, int W) {
+    constexpr int C = LPP * 4, PPB = 256 / LPP;
+    __shared__ float spool[C];
+    const int q = threadIdx.x % LPP, n = blockIdx.y;
+    if (threadIdx.x < C) spool[threadIdx.x] = 0.f;
+    __syncthreads();
+    float wr[4][9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wr[k][t] = w[(q * 4 + k) * 9 + t];
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + q * 4);
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    const int HW = H * W;
+    for (int p = blockIdx.x * PPB + threadIdx.x / LPP; p < HW; p += gridDim.x * PPB) {
+        const int y = p / W, x = p % W;
+        f32x4 a = bv;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = y + dy - 1;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int xx = x + dx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((long long)(n * H + yy) * W + xx) * ldi + q * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] += v[k] * wr[k][dy * 3 + dx];
+            }
+        }
+        f32x4 gl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gl[k] = gelu_f(a[k]);
+        const long long o = ((long long)n * HW + p) * C + q * 4;
+        *reinterpret_cast<f32x4*>(pre + o) = a;
+        *reinterpret_cast<f32x4*>(act + o) = gl;
+        psum += gl;
+    }
+    if (pool != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&spool[q * 4 + k], psum[k]);
+        __syncthreads();
+        if (threadIdx.x < C) atomicAdd(pool + n * C + threadIdx.x, spool[threadIdx.x]);
+    }
+}
+
+// depthwise 3x3 backward: gin = dgrad(gd), dw[c][tap] += sum gd*in(shifted), db[c] += sum gd.
+template <int LPP>
+__global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ in,
+                                                    int ldi, const float* __restrict__ w, float* __restrict__ gin,
+                                                    float* __restrict__ dw, float* __restrict__ db, int H, int W) {
+    constexpr int C = LPP * 4, PPB = 256 / LPP;
+    __shared__ float sdw[C * 9], sdb[C];
+    const int q = threadIdx.x % LPP, n = blockIdx.y;
+    for (int i = threadIdx.x; i < C * 9; i += 256) sdw[i] = 0.f;
+    if (threadIdx.x < C) sdb[threadIdx.x] = 0.f;
+    __syncthreads();
+    float wr[4][9], pw[4][9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { wr[k][t] = w[(q * 4 + k) * 9 + t]; pw[k][t] = 0.f; }
+    f32x4 pb = {0.f, 0.f, 0.f, 0.f};
+    const int HW = H * W;
+    for (int p = blockIdx.x * PPB + threadIdx.x / LPP; p < HW; p += gridDim.x * PPB) {
+        const int y = p / W, x = p % W;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gd + ((long long)n * HW + p) * C + q * 4);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                // dgrad: gin[y][x] += gd[y - dy + 1][x - dx + 1] * w[dy][dx]
+                const int gy = y - dy + 1, gxx = x - dx + 1;
+                if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(gd + ((long long)(n * H + gy) * W + gxx) * C + q * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] += gv[k] * wr[k][dy * 3 + dx];
+                }
+                // wgrad: dw[dy][dx] += gd[y][x] * in[y + dy - 1][x + dx - 1]
+                const int iy = y + dy - 1, ix = x + dx - 1;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const f32x4 iv = *reinterpret_cast<const f32x4*>(in + ((long long)(n * H + iy) * W + ix) * ldi + q * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pw[k][dy * 3 + dx] += g0[k] * iv[k];
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(gin + ((long long)n * HW + p) * C + q * 4) = a;
+        pb += g0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(q * 4 + k) * 9 + t], pw[k][t]);
+        atomicAdd(&sdb[q * 4 + k], pb[k]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(dw + i, sdw[i]);
+    if (threadIdx.x < C) atomicAdd(db + threadIdx.x, sdb[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------
+// squeeze-excite MLP (se_1, fm:253-260): s = sigmoid(W2 relu(W1 m + b1) + b2), m = pool/HW.
+// One block per sample.
+__global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ pool, float invHW,
+                                                    const float* __restrict__ W1, const float* __restrict__ b1,
+                                                    const float* __restrict__ W2, const float* __restrict__ b2,
+                                                    float* __restrict__ m, float* __restrict__ z1, float* __restrict__ s,
+                                                    int C) {
+    __shared__ float sm[256], sz[128];
+    const int n = blockIdx.x, Ch = C / 2;
+    for (int c = threadIdx.x; c < C; c += 256) { sm[c] = pool[n * C + c] * invHW; m[n * C + c] = sm[c]; }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Ch; j += 256) {
+        float a = b1[j];
+        for (int c = 0; c < C; ++c) a += W1[j * C + c] * sm[c];
+        a = a > 0.f ? a : 0.f;
+        sz[j] = a; z1[n * Ch + j] = a;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = b2[c];
+        for (int j = 0; j < Ch; ++j) a += W2[c * Ch + j] * sz[j];
+        s[n * C + c] = 1.f / (1.f + __expf(-a));
+    }
+}
+
+// SE backward, single block, loops over samples (deterministic accumulation):
+// given gs = dL/ds: gm = dL/dm ; dW1,db1,dW2,db2 += ...
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
+                                                    const float* __restrict__ z1, const float* __restrict__ m,
+                                                    const float* __restrict__ W1, const float* __restrict__ W2,
+                                                    float* __restrict__ gm, float* __restrict__ dW1,
+                                                    float* __restrict__ db1, float* __restrict__ dW2,
+                                                    float* __restrict__ db2, int N, int C) {
+    __shared__ float d2[256], d1[128], sz[128], sm[256];
+    const int Ch = C / 2;
+    for (int n = 0; n < N; ++n) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const float sv = s[n * C + c];
+            d2[c] = gs[n * C + c] * sv * (1.f - sv);
+            sm[c] = m[n * C + c];
+        }
+        for (int j = threadIdx.x; j < Ch; j += 256) sz[j] = z1[n * Ch + j];
+        __syncthreads();
+        for (int j = threadIdx.x; j < Ch; j += 256) {
+            float a = 0.f;
+            for (int c = 0; c < C; ++c) a += W2[c * Ch + j] * d2[c];
+            d1[j] = sz[j] > 0.f ? a : 0.f;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f;
+            for (int j = 0; j < Ch; ++j) a += W1[j * C + c] * d1[j];
+            gm[n * C + c] = a;
+            db2[c] += d2[c];
+        }
+        for (int j = threadIdx.x; j < Ch; j += 256) db1[j] += d1[j];
+        for (int e = threadIdx.x; e < C * Ch; e += 256) {
+            dW2[e] += d2[e / Ch] * sz[e % Ch];          // W2: (C, Ch)
+            dW1[e] += d1[e / C] * sm[e % C];            // W1: (Ch, C)
+        }
+        __syncthreads();
+    }
+}
+
+// out[n,p,0:C] = xi*s[n] ; out[n,p,C:2C] = xe*s[n]      (fm:312-315 without the cat temp)
+template <int LPP>
+__global__ __launch_bounds__(256) void scale_cat_kernel(const float* __restrict__ xi, const float* __restrict__ xe,
+                                                       const float* __restrict__ s, float* __restrict__ out,
+                                                       int HW, long long npix) {
+    constexpr int C = LPP * 4, L2 = LPP * 2, PPB = 256 / L2;
+    const int q = threadIdx.x % L2;
+    for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / L2; p < npix; p += (long long)gridDim.x * PPB) {
+        const int n = (int)(p / HW);
+        const int c = (q % LPP) * 4;
+        const float* src = (q < LPP ? xi : xe) + p * C + c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s + n * C + c);
+        *reinterpret_cast<f32x4*>(out + p * 2 * C + q * 4) = v * sv;
+    }
+}
+
+// gs[n][c] += sum_p gxs[n,p,c]*xi[n,p,c] + gxs[n,p,C+c]*xe[n,p,c]   ; grid = (chunks, N)
+template <int LPP>
+__global__ __launch_bounds__(256) void gs_reduce_kernel(const float* __restrict__ gxs, const float* __restrict__ xi,
+                                                       const float* __restrict__ xe, float* __restrict__ gs, int HW) {
+    constexpr int C = LPP * 4, PPB = 256 / LPP;
+    __shared__ float sg[C];
+    const int q = threadIdx.x % LPP, n = blockIdx.y;
+    if (threadIdx.x < C) sg[threadIdx.x] = 0.f;
+    __syncthreads();
+    f32x4 ps = {0.f, 0.f, 0.f, 0.f};
+    for (int p = blockIdx.x * PPB + threadIdx.x / LPP; p < HW; p += gridDim.x * PPB) {
+        const long long pix = (long long)n * HW + p;
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(gxs + pix * 2 * C + q * 4);
+        const f32x4 ge = *reinterpret_cast<const f32x4*>(gxs + pix * 2 * C + C + q * 4);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(xi + pix * C + q * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(xe + pix * C + q * 4);
+        ps += gi * a + ge * b;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&sg[q * 4 + k], ps[k]);
+    __syncthreads();
+    if (threadIdx.x < C) atomicAdd(gs + n * C + threadIdx.x, sg[threadIdx.x]);
+}
+
+// gdwe = (gxs_e*s + gm/HW) * gelu'(dwe) ;  gxi_acc (+)= gxs_i*s
+template <int LPP>
+__global__ __launch_bounds__(256) void egaca_bwd_elem_kernel(const float* __restrict__ gxs, const float* __restrict__ s,
+                                                            const float* __restrict__ gm, float invHW,
+                                                            const float* __restrict__ dwe, float* __restrict__ gdwe,
+                                                            float* __restrict__ gxi, int accXi, int HW, long long npix) {
+    constexpr int C = LPP * 4, PPB = 256 / LPP;
+    const int q = threadIdx.x % LPP;
+    for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / LPP; p < npix; p += (long long)gridDim.x * PPB) {
+        const int n = (int)(p / HW);
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(s + n * C + q * 4);
+        const f32x4 gmv = *reinterpret_cast<const f32x4*>(gm + n * C + q * 4);
+        const f32x4 gi = *reinterpret_cast<const f32x4*>(gxs + p * 2 * C + q * 4);
+        const f32x4 ge = *reinterpret_cast<const f32x4*>(gxs + p * 2 * C + C + q * 4);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(dwe + p * C + q * 4);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (ge[k] * sv[k] + gmv[k] * invHW) * gelu_d(dv[k]);
+        *reinterpret_cast<f32x4*>(gdwe + p * C + q * 4) = o;
+        f32x4 xi = gi * sv;
+        float* xo = gxi + p * C + q * 4;
+        if (accXi) xi += *reinterpret_cast<const f32x4*>(xo);
+        *reinterpret_cast<f32x4*>(xo) = xi;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = in[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = gelu_f(v[k]);
+        out[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ in,
+                                                      f32x4* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = in[i], gv = g[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = gv[k] * gelu_d(v[k]);
+        out[i] = o;
+    }
+}
+
+// db[c] += sum_p g[p][c]  (bias gradient of ConvTranspose2d); C/4 must divide 256
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int ldg, float* __restrict__ db,
+                                                    int C, long long npix) {
+    __shared__ float sb[1024];
+    const int Q = C / 4, PPB = 256 / Q;
+    const int q = threadIdx.x % Q;
+    for (int i = threadIdx.x; i < C; i += 256) sb[i] = 0.f;
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / Q; p < npix; p += (long long)gridDim.x * PPB)
+        acc += *reinterpret_cast<const f32x4*>(g + p * ldg + q * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) atomicAdd(&sb[q * 4 + k], acc[k]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(db + i, sb[i]);
+}
+
+// beta/gamma fold-back (see refid_hip.h): per row r:
+//   dscale[r] += sum_k W[r][k]*G[r][k] + b[r]*gb[r] ;  G[r][:] *= scale[r] ; gb[r] *= scale[r]
+__global__ __launch_bounds__(64) void fold_back_kernel(const float* __restrict__ W, const float* __restrict__ b,
+                                                      const float* __restrict__ scale, float* __restrict__ G,
+                                                      float* __restrict__ gb, float* __restrict__ dscale, int K) {
+    const int r = blockIdx.x;
+    float a = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) a += W[(long long)r * K + k] * G[(long long)r * K + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    const float sc = scale[r];
+    for (int k = threadIdx.x; k < K; k += 64) G[(long long)r * K + k] *= sc;
+    if (threadIdx.x == 0) {
+        dscale[r] += a + b[r] * gb[r];
+        gb[r] *= sc;
+    }
+}
+
+__global__ __launch_bounds__(256) void mul_vec_kernel(const float* a, const float* b, float* out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
+int blocks_for(long long items, int per_block, int cap = 2048) {
+    long long b = (items + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define LPP_DISPATCH(C, CALL)                                                     \
+    switch (C) {                                                                  \
+        case 16: { constexpr int LPP = 4; CALL; break; }                          \
+        case 32: { constexpr int LPP = 8; CALL; break; }                          \
+        case 64: { constexpr int LPP = 16; CALL; break; }                         \
+        case 128: { constexpr int LPP = 32; CALL; break; }                        \
+        default: refid_set_error("egaca: unsupported channel count %d (16/32/64/128)", C); return 1; \
+    }
+
+extern "C" int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float* b, float* out,
+                                     int ld_out, long long npix, int c, float eps, void* stream) {
+    REFID_CHECK(x && w && b && out && npix > 0, "layernorm2d_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    LPP_DISPATCH(c, hipLaunchKernelGGL(ln_fwd_kernel<LPP>, dim3(blocks_for(npix, 256 / LPP)), dim3(256), 0, st, x,
+                                       ld_x, w, b, out, ld_out, npix, eps));
+    REFID_LAUNCH_CHECK("layernorm2d_fwd");
+    return 0;
+}
+
+extern "C" int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
+                                     int ld_gx, int accumulate, float* dw, float* db, long long npix, int c,
+                                     float eps, void* stream) {
+    REFID_CHECK(g && x && w && gx && dw && db && npix > 0, "layernorm2d_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    LPP_DISPATCH(c, hipLaunchKernelGGL(ln_bwd_kernel<LPP>, dim3(blocks_for(npix, 256 / LPP, 512)), dim3(256), 0, st,
+                                       g, ld_g, x, ld_x, w, gx, ld_gx, accumulate, dw, db, npix, eps));
+    REFID_LAUNCH_CHECK("layernorm2d_bwd");
+    return 0;
+}
+
+extern "C" int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
+                                        float* act, float* pool, int n, int h, int wd, int c, void* stream) {
+    REFID_CHECK(in && w && b && pre && act && n > 0 && h > 0 && wd > 0, "dwconv3x3_gelu_fwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (pool) {
+        hipError_t e = hipMemsetAsync(pool, 0, sizeof(float) * n * c, st);
+        REFID_CHECK(e == hipSuccess, "dwconv3x3_gelu_fwd: memset failed: %s", hipGetErrorString(e));
+    }
+    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_fwd_kernel<LPP>, dim3(blocks_for((long long)h * wd, 256 / LPP, 256), n),
+                                       dim3(256), 0, st, in, ld_in, w, b, pre, act, pool, h, wd));
+    REFID_LAUNCH_CHECK("dwconv3x3_gelu_fwd");
+    return 0;
+}
+
+extern "C" int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
+                                   float* dw, float* db, int n, int h, int wd, int c, void* stream) {
+    REFID_CHECK(gd && in && w && gin && dw && db && n > 0, "dwconv3x3_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_bwd_kernel<LPP>, dim3(blocks_for((long long)h * wd, 256 / LPP, 64), n),
+                                       dim3(256), 0, st, gd, in, ld_in, w, gin, dw, db, h, wd));
+    REFID_LAUNCH_CHECK("dwconv3x3_bwd");
+    return 0;
+}
+
+extern "C" int refid_se_fwd(const float* pool, float inv_hw, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* m, float* z1, float* s, int n, int c, void* stream) {
+    REFID_CHECK(pool && w1 && b1 && w2 && b2 && m && z1 && s && n > 0 && c > 0 && c <= 256 && c % 2 == 0,
+                "se_fwd: bad arguments (c=%d)", c);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pool, inv_hw, w1, b1, w2, b2, m, z1,
+                       s, c);
+    REFID_LAUNCH_CHECK("se_fwd");
+    return 0;
+}
+
+extern "C" int refid_se_bwd(const float* gs, const float* s, const float* z1, const float* m, const float* w1,
+                            const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, int n, int c,
+                            void* stream) {
+    REFID_CHECK(gs && s && z1 && m && w1 && w2 && gm && dw1 && db1 && dw2 && db2 && n > 0 && c <= 256,
+                "se_bwd: bad arguments");
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gs, s, z1, m, w1, w2, gm, dw1, db1,
+                       dw2, db2, n, c);
+    REFID_LAUNCH_CHECK("se_bwd");
+    return 0;
+}
+
+extern "C" int refid_scale_cat(const float* xi, const float* xe, const float* s, float* out, int n, int hw, int c,
+                               void* stream) {
+    REFID_CHECK(xi && xe && s && out && n > 0 && hw > 0, "scale_cat: bad arguments");
+    const long long npix = (long long)n * hw;
+    hipStream_t st = (hipStream_t)stream;
+    LPP_DISPATCH(c, hipLaunchKernelGGL(scale_cat_kernel<LPP>, dim3(blocks_for(npix, 256 / (2 * LPP))), dim3(256), 0,
+                                       st, xi, xe, s, out, hw, npix));
+    REFID_LAUNCH_CHECK("scale_cat");
+    return 0;
+}
+
+extern "C" int refid_egaca_gs_reduce(const float* gxs, const float* xi, const float* xe, float* gs, int n, int hw,
+                                     int c, void* stream) {
+    REFID_CHECK(gxs && xi && xe && gs && n > 0 && hw > 0, "egaca_gs_reduce: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(gs, 0, sizeof(float) * n * c, st);
+    REFID_CHECK(e == hipSuccess, "egaca_gs_reduce: memset failed: %s", hipGetErrorString(e));
+    LPP_DISPATCH(c, hipLaunchKernelGGL(gs_reduce_kernel<LPP>, dim3(blocks_for(hw, 256 / LPP, 128), n), dim3(256), 0,
+                                       st, gxs, xi, xe, gs, hw));
+    REFID_LAUNCH_CHECK("egaca_gs_reduce");
+    return 0;
+}
+
+extern "C" int refid_egaca_bwd_elem(const float* gxs, const float* s, const float* gm, float inv_hw, const float* dwe,
+                                    float* gdwe, float* gxi, int accumulate_xi, int n, int hw, int c, void* stream) {
+    REFID_CHECK(gxs && s && gm && dwe && gdwe && gxi && n > 0 && hw > 0, "egaca_bwd_elem: bad arguments");
+    const long long npix = (long long)n * hw;
+    hipStream_t st = (hipStream_t)stream;
+    LPP_DISPATCH(c, hipLaunchKernelGGL(egaca_bwd_elem_kernel<LPP>, dim3(blocks_for(npix, 256 / LPP)), dim3(256), 0, st,
+                                       gxs, s, gm, inv_hw, dwe, gdwe, gxi, accumulate_xi, hw, npix));
+    REFID_LAUNCH_CHECK("egaca_bwd_elem");
+    return 0;
+}
+
+extern "C" int refid_gelu_fwd(const float* in, float* out, long long count, void* stream) {
+    REFID_CHECK(in && out && count > 0 && count % 4 == 0, "gelu_fwd: bad arguments");
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(blocks_for(count / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)in, (f32x4*)out, count / 4);
+    REFID_LAUNCH_CHECK("gelu_fwd");
+    return 0;
+}
+
+extern "C" int refid_gelu_bwd(const float* g, const float* in, float* out, long long count, void* stream) {
+    REFID_CHECK(g && in && out && count > 0 && count % 4 == 0, "gelu_bwd: bad arguments");
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(blocks_for(count / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4*)g, (const f32x4*)in, (f32x4*)out, count / 4);
+    REFID_LAUNCH_CHECK("gelu_bwd");
+    return 0;
+}
+
+extern "C" int refid_colsum(const float* g, int ld_g, float* db, long long npix, int c, void* stream) {
+    REFID_CHECK(g && db && npix > 0 && c >= 4 && c <= 1024 && c % 4 == 0 && 256 % (c / 4) == 0,
+                "colsum: bad arguments (c=%d; c/4 must divide 256)", c);
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(npix, 256 / (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, g,
+                       ld_g, db, c, npix);
+    REFID_LAUNCH_CHECK("colsum");
+    return 0;
+}
+
+extern "C" int refid_fold_back(const float* w, const float* b, const float* scale, float* gw, float* gb,
+                               float* dscale, int rows, int k, void* stream) {
+    REFID_CHECK(w && b && scale && gw && gb && dscale && rows > 0 && k > 0, "fold_back: bad arguments");
+    hipLaunchKernelGGL(fold_back_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, w, b, scale, gw, gb, dscale, k);
+    REFID_LAUNCH_CHECK("fold_back");
+    return 0;
+}
+
+extern "C" int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream) {
+    REFID_CHECK(a && b && out && n > 0, "mul_vec: bad arguments");
+    hipLaunchKernelGGL(mul_vec_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+    REFID_LAUNCH_CHECK("mul_vec");
+    return 0;
+}

@@ -26,6 +26,7 @@ namespace {
 
 // ---- NCHW -> NHWC (padded) : one block transposes a 32-pixel x C strip through LDS ----------
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
+                                                          long long srcBatchStride,
                                                           float* __restrict__ dst, int C, int HW,
                                                           int Cpad) {
     // grid.x = pixel blocks of 64, grid.y = n
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         // read: coalesced along pixels
         for (int cc = ty; cc < 64; cc += 4) {
             const int c = c0 + cc, p = p0 + tx;
-            tile[cc][tx] = (c < C && p < HW) ? src[((long long)n * C + c) * HW + p] : 0.f;
+            tile[cc][tx] = (c < C && p < HW) ? src[(long long)n * srcBatchStride + (long long)c * HW + p] : 0.f;
         }
         __syncthreads();
         // write: coalesced along channels
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const f32x4* __restrict__ 
 // ---- weight packing --------------------------------------------------------------------------
 // packed[cls][chunk][tap][row][k] = W[src index] or 0.
 struct PackArgs {
-    const float* w; float* dst;
+    const float* w; float* dst; const float* oscale;   // oscale: optional per-output-channel factor
     int role, O, I, KH, KW, KC, rows, rowsPad, K, nchunks, ntaps, ncls;
 };
 
@@ -100,9 +101,9 @@ __device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap,
     const int KK = p.KH * p.KW;
     switch (p.role) {
         case REFID_ROLE_FWD:            // rows = O, k = I ; W[o][i][tap]
-            return p.w[((long long)row * p.I + k) * KK + tap];
+            return p.w[((long long)row * p.I + k) * KK + tap] * (p.oscale ? p.oscale[row] : 1.f);
         case REFID_ROLE_DGRAD:          // rows = I, k = O ; flipped taps
-            return p.w[((long long)k * p.I + row) * KK + (KK - 1 - tap)];
+            return p.w[((long long)k * p.I + row) * KK + (KK - 1 - tap)] * (p.oscale ? p.oscale[k] : 1.f);
         case REFID_ROLE_CONVT: {        // W is (I=Ci, O=Co, 2, 2); rows = (q, co), k = ci
             const int Co = p.O;
             const int qd = row / Co, co = row - qd * Co;
@@ -165,9 +166,24 @@ extern "C" size_t refid_packed_weight_floats(int role, int o, int i, int kh, int
     return (size_t)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
 }
 
+static int pack_impl(const float* w, const float* oscale, float* packed, int role, int o, int i, int kh,
+                     int kw, int kc, int bn, void* stream);
+
 extern "C" int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int i, int kh,
                                        int kw, int kc, int bn, void* stream) {
+    return pack_impl(w, nullptr, packed, role, o, i, kh, kw, kc, bn, stream);
+}
+
+extern "C" int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* packed, int role, int o,
+                                              int i, int kh, int kw, int kc, int bn, void* stream) {
+    REFID_CHECK(role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD, "pack_scaled: only FWD/DGRAD roles take a scale");
+    return pack_impl(w, oscale, packed, role, o, i, kh, kw, kc, bn, stream);
+}
+
+static int pack_impl(const float* w, const float* oscale, float* packed, int role, int o, int i, int kh,
+                     int kw, int kc, int bn, void* stream) {
     PackArgs p;
+    p.oscale = oscale;
     REFID_CHECK(w && packed, "pack: null pointer");
     REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack: unknown role %d", role);
     REFID_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),
@@ -180,11 +196,12 @@ extern "C" int refid_pack_conv_weights(const float* w, float* packed, int role, 
     return 0;
 }
 
-extern "C" int refid_nchw_to_nhwc(const float* src, float* dst, int n, int c, int h, int w, int c_pad,
-                                  void* stream) {
+extern "C" int refid_nchw_to_nhwc(const float* src, long long src_batch_stride, float* dst, int n, int c, int h,
+                                  int w, int c_pad, void* stream) {
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc: bad arguments");
     dim3 grid(cdiv(h * w, 64), n);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, dst, c, h * w, c_pad);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
+                       h * w, c_pad);
     REFID_LAUNCH_CHECK("nchw_to_nhwc");
     return 0;
 }

@@ -1,0 +1,122 @@
+// Train-step tail of the REFID hot path: Charbonnier loss
+// forward+backward in one pass, global gradient norm, and clip + AdamW fused over the
+// FLAT parameter / gradient arenas (one launch for all 183 tensors instead of 183 x k
+// torch launches).  All HBM-bound streaming kernels, 16 bytes per lane per access.
+//
+// Reference: losses/losses.py:28-30,143-173 (CharbonnierLoss, eps=1e-12, mean);
+// twoImage_event_recurrent_model.py:303-306 (backward, clip_grad_norm_(0.01), AdamW step).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum_double(double v, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    return r;       // valid on thread 0
+}
+
+// loss_sum += sum sqrt(d^2 + eps) ; grad = d / sqrt(d^2 + eps) * gscale     (d = pred - gt)
+__global__ __launch_bounds__(256) void charbonnier_kernel(const f32x4* __restrict__ pred, const f32x4* __restrict__ gt,
+                                                         f32x4* __restrict__ grad, double* __restrict__ loss_sum,
+                                                         float eps, float gscale, long long n4) {
+    __shared__ double sh[4];
+    float acc = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 d = pred[i] - gt[i];
+        f32x4 g;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float r = sqrtf(d[k] * d[k] + eps);
+            acc += r;
+            g[k] = d[k] / r * gscale;
+        }
+        if (grad) grad[i] = g;
+    }
+    const double t = block_sum_double((double)acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, t);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const f32x4* __restrict__ g, double* __restrict__ out, long long n4) {
+    __shared__ double sh[4];
+    float acc = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = g[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    const double t = block_sum_double((double)acc, sh);
+    if (threadIdx.x == 0) atomicAdd(out, t);
+}
+
+// torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.AdamW single step.
+__global__ __launch_bounds__(256) void clip_adamw_kernel(f32x4* __restrict__ p, const f32x4* __restrict__ g,
+                                                        f32x4* __restrict__ m, f32x4* __restrict__ v,
+                                                        const double* __restrict__ sqnorm, float max_norm,
+                                                        float gscale, float lr, float b1, float b2, float eps,
+                                                        float wd, float bc1, float bc2_sqrt, long long n4) {
+    float coef = 1.f;
+    if (max_norm > 0.f) {
+        const float norm = (float)sqrt(*sqnorm) * gscale;
+        const float c = max_norm / (norm + 1e-6f);
+        coef = c < 1.f ? c : 1.f;
+    }
+    coef *= gscale;
+    const float step = lr / bc1;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 pv = p[i], mv = m[i], vv = v[i];
+        const f32x4 gv = g[i] * coef;
+        pv *= (1.f - lr * wd);
+        mv = mv * b1 + gv * (1.f - b1);
+        vv = vv * b2 + gv * gv * (1.f - b2);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] -= step * mv[k] / (sqrtf(vv[k]) / bc2_sqrt + eps);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+
+int nblocks(long long n4) {
+    long long b = (n4 + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, long long count,
+                                 float eps, float grad_scale, void* stream) {
+    REFID_CHECK(pred && gt && loss_sum && count > 0 && count % 4 == 0, "charbonnier: bad arguments (count=%lld)", count);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), st);
+    REFID_CHECK(e == hipSuccess, "charbonnier: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(charbonnier_kernel, dim3(nblocks(count / 4)), dim3(256), 0, st, (const f32x4*)pred,
+                       (const f32x4*)gt, (f32x4*)grad, loss_sum, eps, grad_scale, count / 4);
+    REFID_LAUNCH_CHECK("charbonnier");
+    return 0;
+}
+
+extern "C" int refid_grad_sqnorm(const float* g, double* out, long long count, void* stream) {
+    REFID_CHECK(g && out && count > 0 && count % 4 == 0, "grad_sqnorm: bad arguments (count=%lld)", count);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
+    REFID_CHECK(e == hipSuccess, "grad_sqnorm: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nblocks(count / 4)), dim3(256), 0, st, (const f32x4*)g, out, count / 4);
+    REFID_LAUNCH_CHECK("grad_sqnorm");
+    return 0;
+}
+
+extern "C" int refid_clip_adamw(float* p, const float* g, float* m, float* v, const double* sqnorm, float max_norm,
+                                float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                int step, long long count, void* stream) {
+    REFID_CHECK(p && g && m && v && count > 0 && count % 4 == 0 && step >= 1, "clip_adamw: bad arguments");
+    REFID_CHECK(max_norm <= 0.f || sqnorm != nullptr, "clip_adamw: clipping needs the squared norm");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblocks(count / 4)), dim3(256), 0, (hipStream_t)stream, (f32x4*)p,
+                       (const f32x4*)g, (f32x4*)m, (f32x4*)v, sqnorm, max_norm, grad_scale, lr, beta1, beta2, eps,
+                       weight_decay, (float)bc1, (float)sqrt(bc2), count / 4);
+    REFID_LAUNCH_CHECK("clip_adamw");
+    return 0;
+}

@@ -1,0 +1,724 @@
+"""Timestep scheduler of the MI355X-native REFID hot path.
+
+Drives the HIP kernels (through ``refid_amd.ops`` -> librefid_hip.so) for the forward pass
+of ``FinalBidirectionAttenfusion`` and for a hand-written BPTT backward pass; torch is used
+for device memory, streams and the autograd hand-off only -- there is no torch arithmetic
+and no CPU/eager fallback in this file.
+
+Reference behaviour followed (paths relative to /root/reference/basicsr/models/archs):
+  XXNet_final_attenfusion_arch.py:130-218  forward orchestration, incl. the list-aliasing
+      of backward states (:167,180-181): every forward step fuses the FINAL backward state;
+  recurrent_sub_modules.py:41-49, 74-84, 270-296, 386-408, 488-503, 659-678, 719-726, 755-758;
+  fusion_modules.py:97-134, 290-333 (EGACA).  Backward: SURVEY.md Appendix A.2.
+
+Design notes (MI355X-first):
+  * activations live in HBM as NHWC fp32; ``torch.cat`` is never materialised (two-source
+    conv tiles), activations/residual adds ride in the conv epilogues;
+  * parameters and gradients live in two flat arenas (``ParamArena``); the nn.Module's
+    parameters are views into them, so clip+AdamW and the DDP all-reduce are single
+    launches over one buffer;
+  * EGACA's image branch (LN -> 1x1 -> dw3x3 -> GELU) does not depend on t: it is computed
+    once per sweep direction instead of 2T times, its gradient is accumulated over the sweep;
+  * EGACA's beta/gamma are folded into conv3/conv5's packed weights (scaled branch + residual
+    in the conv epilogue) and un-folded once after BPTT (``refid_fold_back``);
+  * dead work is skipped: ``encoders_backward[2].down`` (its output is discarded by the
+    reference, arch :179) and the T copies of backward states.
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import ops
+from ._lib import RefidHipError
+
+
+def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2):
+    """State-dict inventory (names, shapes, registration order) of the reference network:
+    XXNet_final_attenfusion_arch.py:90-128 + the sub-module ctors it calls."""
+    b = base
+    sh = OrderedDict()
+
+    def conv(name, co, ci, k, bias=True):
+        sh[name + ".weight"] = (co, ci, k, k)
+        if bias:
+            sh[name + ".bias"] = (co,)
+
+    conv("head.conv2d", b, ev_chn, 5)
+    enc_in = [b, 2 * b, 4 * b]
+    enc_out = [2 * b, 4 * b, 8 * b]
+
+    def evr(prefix, ci, co, fuse, atten):
+        conv(prefix + ".conv.conv2d", co, ci, 3)
+        if atten:
+            a = prefix + ".atten_fuse"
+            sh[a + ".beta"] = (1, ci, 1, 1)
+            sh[a + ".gamma"] = (1, co, 1, 1)
+            conv(a + ".conv1", ci, ci, 1)
+            sh[a + ".conv2.weight"] = (ci, 1, 3, 3); sh[a + ".conv2.bias"] = (ci,)
+            conv(a + ".conv1_e", ci, ci, 1)
+            sh[a + ".conv2_e.weight"] = (ci, 1, 3, 3); sh[a + ".conv2_e.bias"] = (ci,)
+            conv(a + ".conv3", ci, 2 * ci, 1)
+            conv(a + ".se_1.1", ci // 2, ci, 1); conv(a + ".se_1.3", ci, ci // 2, 1)
+            conv(a + ".se_2.1", ci // 2, ci, 1); conv(a + ".se_2.3", ci, ci // 2, 1)
+            conv(a + ".conv4", 2 * ci, ci, 1)
+            conv(a + ".conv5", co, 2 * ci, 1)
+            conv(a + ".conv_y_side", co, ci, 1)
+            for n in ("norm1", "norm1_e", "norm2"):
+                sh[f"{a}.{n}.weight"] = (ci,); sh[f"{a}.{n}.bias"] = (ci,)
+        t = prefix + ".recurrent_block.forward_trunk.main"
+        conv(t + ".0", co, 2 * co, 3)
+        conv(t + ".2.0.conv1", co, co, 3)
+        conv(t + ".2.0.conv2", co, co, 3)
+        if fuse:
+            conv(prefix + ".fuse_two_dir.conv2d", co, 2 * co, 1)
+        sh[prefix + ".down.weight"] = (co, co, 4, 4)
+
+    for i in range(3):
+        evr(f"encoders_backward.{i}", enc_in[i], enc_out[i], False, i == 1)
+    for i in range(3):
+        evr(f"encoders_forward.{i}", enc_in[i], enc_out[i], True, i == 1)
+    conv("head_img.conv2d", b, img_chn, 5)
+    for i in range(3):
+        p = f"img_encoders.{i}"
+        conv(p + ".identity", enc_out[i], enc_in[i], 1)
+        conv(p + ".conv_1", enc_out[i], enc_in[i], 3)
+        conv(p + ".conv_2", enc_out[i], enc_out[i], 3)
+        sh[p + ".down.weight"] = (enc_out[i], enc_out[i], 4, 4)
+    cmax = 8 * b
+    for i in range(num_residual_blocks):
+        conv(f"resblocks.{i}.conv1", cmax, cmax, 3)
+        conv(f"resblocks.{i}.conv2", cmax, cmax, 3)
+    for j, ci in enumerate(reversed(enc_out)):
+        p = f"decoders.{j}"
+        sh[p + ".transposed_conv2d.weight"] = (ci, ci // 2, 2, 2)
+        sh[p + ".transposed_conv2d.bias"] = (ci // 2,)
+        t = p + ".forward_trunk.main"
+        conv(t + ".0", ci // 2, ci, 3)
+        conv(t + ".2.0.conv1", ci // 2, ci // 2, 3)
+        conv(t + ".2.0.conv2", ci // 2, ci // 2, 3)
+    conv("pred.conv2d", out_chn, b, 3)
+    return sh
+
+
+class ParamArena:
+    """Flat fp32 parameter / gradient arenas; every tensor starts on a 16-byte boundary."""
+
+    def __init__(self, shapes, device):
+        self.shapes = shapes
+        self.offsets = OrderedDict()
+        off = 0
+        for k, s in shapes.items():
+            n = 1
+            for d in s:
+                n *= d
+            self.offsets[k] = (off, n)
+            off += (n + 3) // 4 * 4
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+
+    def p(self, k):
+        o, n = self.offsets[k]
+        return self.flat_p[o:o + n].view(self.shapes[k])
+
+    def g(self, k):
+        o, n = self.offsets[k]
+        return self.flat_g[o:o + n].view(self.shapes[k])
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class ConvOp:
+    """One convolution of the network: geometry + packed weights + the three kernels."""
+
+    def __init__(self, arena, name, kind="conv", need_dgrad=True, scale_name=None):
+        self.arena, self.name, self.kind = arena, name, kind
+        self.w = arena.p(name + ".weight")
+        self.gw = arena.g(name + ".weight")
+        self.has_bias = (name + ".bias") in arena.shapes
+        self.b = arena.p(name + ".bias") if self.has_bias else None
+        self.gb = arena.g(name + ".bias") if self.has_bias else None
+        self.scale = arena.p(scale_name).view(-1) if scale_name else None
+        self.scale_name = scale_name
+        s = self.w.shape
+        if kind == "convT":
+            self.ci, self.co, self.k = s[0], s[1], 2
+        else:
+            self.co, self.ci, self.k = s[0], s[1], s[2]
+        self.need_dgrad = need_dgrad
+        k = self.k
+        if kind == "conv":
+            self.stride, self.pad, self.mode = 1, k // 2, 0
+            self.f_geo = (k, k, 1, 0)
+            self.f_role, self.f_rows = ops.ROLE_FWD, self.co
+            self.d_geo = (k, k, 1, 0)
+            self.d_role, self.d_rows = ops.ROLE_DGRAD, self.ci
+        elif kind == "down":
+            self.stride, self.pad, self.mode = 2, 1, 0
+            self.f_geo = (4, 4, 2, 0)
+            self.f_role, self.f_rows = ops.ROLE_FWD, self.co
+            self.d_geo = (4, 4, 2, 2)
+            self.d_role, self.d_rows = ops.ROLE_DOWN_DGRAD, self.ci
+        elif kind == "convT":
+            self.stride, self.pad, self.mode = 1, 0, 1
+            self.f_geo = (1, 1, 1, 1)
+            self.f_role, self.f_rows = ops.ROLE_CONVT, 4 * self.co
+            self.d_geo = (2, 2, 2, 0)
+            self.d_role, self.d_rows = ops.ROLE_CONVT_DGRAD, self.ci
+        else:
+            raise ValueError(kind)
+        kh, kw, st, md = self.f_geo
+        self.f_kc = ops.conv_kc(kh, kw, st, md)
+        self.f_bn = ops.conv_bn(kh, kw, st, md, self.f_rows)
+        self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
+        dev = self.w.device
+        self.wp = torch.empty(ops.packed_weight_floats(self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci),
+                              dtype=torch.float32, device=dev)
+        self.wd = None
+        self.d_bn_cache = {}
+        if need_dgrad:
+            kh, kw, st, md = self.d_geo
+            self.d_kc = ops.conv_kc(kh, kw, st, md)
+            # a dgrad may be issued for a row range (two-source convs): tile width follows the range
+            self.d_bn = ops.conv_bn(kh, kw, st, md, self.d_rows if self.d_rows <= 128 else 128)
+            if kind == "conv" and self.ci == 2 * self.co and self.k in (1, 3):
+                self.d_bn = ops.conv_bn(kh, kw, st, md, self.co)     # issued as two halves of co rows
+            self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
+            self.wd = torch.empty(ops.packed_weight_floats(self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci),
+                                  dtype=torch.float32, device=dev)
+        self.b_eff = self.b
+        if self.scale is not None and self.has_bias:
+            self.b_eff = torch.empty_like(self.b)
+
+    def repack(self):
+        k = self.k
+        ops.pack_conv_weights(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp,
+                              oscale=self.scale)
+        if self.wd is not None:
+            ops.pack_conv_weights(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd,
+                                  oscale=self.scale)
+        if self.scale is not None and self.has_bias:
+            ops.mul_vec(self.b, self.scale, out=self.b_eff)
+
+    # ---- forward ---------------------------------------------------------------------------
+    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None):
+        n, h, w, _ = a.shape
+        if self.kind == "conv":
+            ho, wo, oc = h, w, self.co
+        elif self.kind == "down":
+            ho, wo, oc = h // 2, w // 2, self.co
+        else:
+            ho, wo, oc = 2 * h, 2 * w, self.co
+        if out is None:
+            out = torch.empty((n, ho, wo, _pad4(oc)), dtype=torch.float32, device=a.device)
+            if _pad4(oc) != oc:
+                out.zero_()
+                out = out[..., :oc]
+        kh, kw, st, md = self.f_geo
+        ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
+                   cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post)
+        return out
+
+    # ---- input gradient ----------------------------------------------------------------------
+    def dgrad(self, g, rows=None, res=None, mask=None, slope_mask=1.0, out=None):
+        if self.wd is None:
+            raise RefidHipError(f"{self.name}: dgrad weights were not requested")
+        base, cnt = rows if rows is not None else (0, self.d_rows)
+        n, h, w, _ = g.shape
+        if self.kind == "conv":
+            ho, wo = h, w
+        elif self.kind == "down":
+            ho, wo = 2 * h, 2 * w
+        else:
+            ho, wo = h // 2, w // 2
+        if out is None:
+            out = torch.empty((n, ho, wo, cnt), dtype=torch.float32, device=g.device)
+        kh, kw, st, md = self.d_geo
+        pad = self.pad if self.kind == "conv" else (1 if self.kind == "down" else 0)
+        if self.kind == "conv":
+            pad = self.k - 1 - self.pad
+        ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
+                   co_base=base, res=res, mask=mask, slope_mask=slope_mask)
+        return out
+
+    # ---- weight / bias gradient ----------------------------------------------------------------
+    def wgrad(self, g, a, b=None):
+        """g: gradient w.r.t. this conv's (pre-epilogue) output; (a|b): its input sources."""
+        if self.kind == "convT":
+            # roles swapped (refid_hip.h): "g" := layer input (low res), "src" := output gradient
+            ops.conv2d_wgrad(a, g, self.gw, kh=2, kw=2, stride=2, pad=0)
+            if self.has_bias:
+                ops.colsum(g, self.gb)
+            return
+        ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
+                         db=self.gb, i_total=self.ci)
+
+
+class _Trunk:
+    def __init__(self, arena, prefix):
+        self.c0 = ConvOp(arena, prefix + ".0")
+        self.c1 = ConvOp(arena, prefix + ".2.0.conv1")
+        self.c2 = ConvOp(arena, prefix + ".2.0.conv2")
+        self.C = self.c0.co
+
+    def ops(self):
+        return [self.c0, self.c1, self.c2]
+
+
+class _Egaca:
+    def __init__(self, arena, a):
+        self.a = a
+        P, G = arena.p, arena.g
+        self.conv1 = ConvOp(arena, a + ".conv1")
+        self.conv1_e = ConvOp(arena, a + ".conv1_e")
+        self.conv3 = ConvOp(arena, a + ".conv3", scale_name=a + ".beta")
+        self.conv4 = ConvOp(arena, a + ".conv4")
+        self.conv5 = ConvOp(arena, a + ".conv5", scale_name=a + ".gamma")
+        self.side = ConvOp(arena, a + ".conv_y_side")
+        self.c = self.conv1.ci
+        self.names = {n: (P(f"{a}.{n}"), G(f"{a}.{n}")) for n in (
+            "norm1.weight", "norm1.bias", "norm1_e.weight", "norm1_e.bias", "norm2.weight", "norm2.bias",
+            "conv2.weight", "conv2.bias", "conv2_e.weight", "conv2_e.bias",
+            "se_1.1.weight", "se_1.1.bias", "se_1.3.weight", "se_1.3.bias", "beta", "gamma")}
+
+    def ops(self):
+        return [self.conv1, self.conv1_e, self.conv3, self.conv4, self.conv5, self.side]
+
+    def p(self, n):
+        return self.names[n][0]
+
+    def g(self, n):
+        return self.names[n][1]
+
+
+class _EvrLevel:
+    def __init__(self, arena, prefix, level, fuse, dead_down=False):
+        self.level = level
+        self.conv = ConvOp(arena, prefix + ".conv.conv2d") if level != 1 else None
+        self.att = _Egaca(arena, prefix + ".atten_fuse") if level == 1 else None
+        self.trunk = _Trunk(arena, prefix + ".recurrent_block.forward_trunk.main")
+        self.fuse = ConvOp(arena, prefix + ".fuse_two_dir.conv2d") if fuse else None
+        self.down = None if dead_down else ConvOp(arena, prefix + ".down", kind="down")
+        self.C = self.trunk.C
+
+    def ops(self):
+        r = self.trunk.ops()
+        for o in (self.conv, self.fuse, self.down):
+            if o is not None:
+                r.append(o)
+        if self.att is not None:
+            r += self.att.ops()
+        return r
+
+
+class Engine:
+    """Forward + BPTT backward of FinalBidirectionAttenfusion on one GPU."""
+
+    def __init__(self, img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, device="cuda"):
+        if base % 8 != 0:
+            raise ValueError("base_num_channels must be a multiple of 8")
+        self.img_chn, self.ev_chn, self.out_chn, self.base = img_chn, ev_chn, out_chn, base
+        self.nres = num_residual_blocks
+        self.device = torch.device(device)
+        self.shapes = param_shapes(img_chn, ev_chn, out_chn, base, num_residual_blocks)
+        self.arena = A = ParamArena(self.shapes, self.device)
+        self.head_ev = ConvOp(A, "head.conv2d", need_dgrad=False)
+        self.head_img = ConvOp(A, "head_img.conv2d", need_dgrad=False)
+        self.enc_b = [_EvrLevel(A, f"encoders_backward.{i}", i, False, dead_down=(i == 2)) for i in range(3)]
+        self.enc_f = [_EvrLevel(A, f"encoders_forward.{i}", i, True) for i in range(3)]
+        self.img = []
+        for i in range(3):
+            p = f"img_encoders.{i}"
+            self.img.append(dict(identity=ConvOp(A, p + ".identity"), conv_1=ConvOp(A, p + ".conv_1"),
+                                 conv_2=ConvOp(A, p + ".conv_2"), down=ConvOp(A, p + ".down", kind="down")))
+        self.res = [(ConvOp(A, f"resblocks.{i}.conv1"), ConvOp(A, f"resblocks.{i}.conv2")) for i in range(self.nres)]
+        self.dec = []
+        for j in range(3):
+            p = f"decoders.{j}"
+            self.dec.append(dict(t2=ConvOp(A, p + ".transposed_conv2d", kind="convT"),
+                                 trunk=_Trunk(A, p + ".forward_trunk.main")))
+        self.pred = ConvOp(A, "pred.conv2d")
+        self.all_ops = [self.head_ev, self.head_img, self.pred]
+        for lv in self.enc_b + self.enc_f:
+            self.all_ops += lv.ops()
+        for e in self.img:
+            self.all_ops += list(e.values())
+        for c1, c2 in self.res:
+            self.all_ops += [c1, c2]
+        for d in self.dec:
+            self.all_ops += [d["t2"]] + d["trunk"].ops()
+        self.packed_version = -1
+        self.param_version = 0
+        self.ctx = None
+
+    # -------------------------------------------------------------------------------------------
+    def mark_params_changed(self):
+        self.param_version += 1
+
+    def repack(self):
+        if self.packed_version == self.param_version:
+            return
+        for o in self.all_ops:
+            o.repack()
+        self.packed_version = self.param_version
+
+    # -------------------------------------------------------------------------------------------
+    # EGACA
+    # -------------------------------------------------------------------------------------------
+    def _egaca_img_path(self, A, img):
+        """xi = GELU(dw3x3(conv1(LN1(img)))): t-independent, once per sweep (fm:300,303-305)."""
+        ln_i = ops.layernorm2d_fwd(img, A.p("norm1.weight"), A.p("norm1.bias"))
+        c1i = A.conv1.fwd(ln_i)
+        dwi, xi = ops.dwconv3x3_gelu_fwd(c1i, A.p("conv2.weight"), A.p("conv2.bias"))
+        return dict(ln_i=ln_i, c1i=c1i, dwi=dwi, xi=xi, gxi=None)
+
+    def _egaca_fwd(self, A, ev, img, ip, st):
+        n, h, w, c = ev.shape
+        ln_e = ops.layernorm2d_fwd(ev, A.p("norm1_e.weight"), A.p("norm1_e.bias"))
+        c1e = A.conv1_e.fwd(ln_e)
+        pool = torch.empty((n, c), dtype=torch.float32, device=ev.device)
+        dwe, xe = ops.dwconv3x3_gelu_fwd(c1e, A.p("conv2_e.weight"), A.p("conv2_e.bias"), pool=pool)
+        m, z1, s = ops.se_fwd(pool, 1.0 / (h * w), A.p("se_1.1.weight"), A.p("se_1.1.bias"),
+                              A.p("se_1.3.weight"), A.p("se_1.3.bias"))
+        xs = ops.scale_cat(ip["xi"], xe, s)
+        evimg = ops.add(ev, img)
+        y = A.conv3.fwd(xs, res=evimg)                    # ev + img + beta * conv3(.)   (fm:319)
+        ln2 = ops.layernorm2d_fwd(y, A.p("norm2.weight"), A.p("norm2.bias"))
+        c4 = A.conv4.fwd(ln2)
+        f4 = ops.gelu_fwd(c4)
+        side = A.side.fwd(y)
+        out = A.conv5.fwd(f4, res=side)                   # conv_y_side(y) + gamma * conv5(.) (fm:331)
+        if st is not None:
+            st["eg"] = dict(ev=ev, ln_e=ln_e, c1e=c1e, dwe=dwe, xe=xe, m=m, z1=z1, s=s, xs=xs, y=y, ln2=ln2,
+                            c4=c4, f4=f4)
+        return out
+
+    def _egaca_bwd(self, A, g_u, img_grad, ip, st):
+        """Returns gradient w.r.t. the event input; adds the image-input gradient into img_grad."""
+        e = st["eg"]
+        A.conv5.wgrad(g_u, e["f4"])
+        g_f4 = A.conv5.dgrad(g_u)
+        g_c4 = ops.gelu_bwd(g_f4, e["c4"], out=g_f4)
+        A.conv4.wgrad(g_c4, e["ln2"])
+        g_ln2 = A.conv4.dgrad(g_c4)
+        A.side.wgrad(g_u, e["y"])
+        g_y = A.side.dgrad(g_u)
+        ops.layernorm2d_bwd(g_ln2, e["y"], A.p("norm2.weight"), g_y, A.g("norm2.weight"), A.g("norm2.bias"),
+                            accumulate=True)
+        A.conv3.wgrad(g_y, e["xs"])
+        g_xs = A.conv3.dgrad(g_y)
+        gs = ops.egaca_gs_reduce(g_xs, ip["xi"], e["xe"])
+        gm = ops.se_bwd(gs, e["s"], e["z1"], e["m"], A.p("se_1.1.weight"), A.p("se_1.3.weight"),
+                        A.g("se_1.1.weight"), A.g("se_1.1.bias"), A.g("se_1.3.weight"), A.g("se_1.3.bias"))
+        first = ip["gxi"] is None
+        if first:
+            ip["gxi"] = torch.empty_like(ip["xi"])
+        g_dwe = ops.egaca_bwd_elem(g_xs, e["s"], gm, e["dwe"], ip["gxi"], accumulate_xi=not first)
+        g_c1e = ops.dwconv3x3_bwd(g_dwe, e["c1e"], A.p("conv2_e.weight"), A.g("conv2_e.weight"), A.g("conv2_e.bias"))
+        A.conv1_e.wgrad(g_c1e, e["ln_e"])
+        g_lne = A.conv1_e.dgrad(g_c1e)
+        ops.add(img_grad, g_y, out=img_grad)              # y = ev + img + ...: image gets g_y
+        ops.layernorm2d_bwd(g_lne, e["ev"], A.p("norm1_e.weight"), g_y, A.g("norm1_e.weight"),
+                            A.g("norm1_e.bias"), accumulate=True)
+        return g_y                                        # = g_y + LN1e-backward: gradient w.r.t. ev
+
+    def _egaca_img_bwd(self, A, img, img_grad, ip):
+        if ip["gxi"] is None:
+            return
+        g_dwi = ops.gelu_bwd(ip["gxi"], ip["dwi"])
+        g_c1i = ops.dwconv3x3_bwd(g_dwi, ip["c1i"], A.p("conv2.weight"), A.g("conv2.weight"), A.g("conv2.bias"))
+        A.conv1.wgrad(g_c1i, ip["ln_i"])
+        g_lni = A.conv1.dgrad(g_c1i)
+        ops.layernorm2d_bwd(g_lni, img, A.p("norm1.weight"), img_grad, A.g("norm1.weight"), A.g("norm1.bias"),
+                            accumulate=True)
+
+    def _egaca_fold_back(self, A):
+        for conv, nm in ((A.conv3, "beta"), (A.conv5, "gamma")):
+            ops.fold_back(conv.w, conv.b, conv.scale, conv.gw, conv.gb, A.g(nm).view(-1))
+
+    # -------------------------------------------------------------------------------------------
+    # trunk = EvR hidden-state update (rsm:659-678, 719-726, 755-758)
+    # -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _trunk_fwd(T, u, h, st):
+        v = T.c0.fwd(u, h, slope_pre=0.1)
+        r = T.c1.fwd(v, slope_pre=0.0)
+        s = T.c2.fwd(r, res=v)
+        if st is not None:
+            st.update(u=u, h=h, v=v, r=r, s=s)
+        return s
+
+    @staticmethod
+    def _trunk_bwd(T, g_s, st, mask_u=None, slope_u=1.0):
+        u, h, v, r = st["u"], st["h"], st["v"], st["r"]
+        C = T.C
+        T.c2.wgrad(g_s, r)
+        g_r = T.c2.dgrad(g_s, mask=r, slope_mask=0.0)
+        T.c1.wgrad(g_r, v)
+        g_v = T.c1.dgrad(g_r, res=g_s, mask=v, slope_mask=0.1)
+        T.c0.wgrad(g_v, u, h)
+        g_u = T.c0.dgrad(g_v, rows=(0, C), mask=mask_u, slope_mask=slope_u)
+        g_h = T.c0.dgrad(g_v, rows=(C, C)) if h is not None else None
+        return g_u, g_h
+
+    # -------------------------------------------------------------------------------------------
+    # EvR level (rsm:270-296)
+    # -------------------------------------------------------------------------------------------
+    def _evr_fwd(self, L, a, xb, h_prev, Sb, ip, st):
+        i = L.level
+        if i == 0:
+            src = a
+            u = L.conv.fwd(a, slope_pre=0.04)                 # LeakyReLU(.2) twice (rsm:81-82,284-285)
+        elif i == 2:
+            src = ops.add(a, xb[1])
+            u = L.conv.fwd(src, slope_pre=0.04)
+        else:
+            src = a
+            u = self._egaca_fwd(L.att, a, xb[0], ip, st)
+        s = self._trunk_fwd(L.trunk, u, h_prev, st)
+        f = s
+        if L.fuse is not None:
+            f = L.fuse.fwd(s, Sb, slope_pre=0.2)
+        o = L.down.fwd(f) if L.down is not None else None
+        if st is not None:
+            st.update(src=src, f=f, Sb=Sb)
+        return o, s
+
+    # -------------------------------------------------------------------------------------------
+    def forward(self, x, event, save=True):
+        """x: (B,img_chn,H,W) or (B,2,3,H,W); event: (B,T,ev_chn,H,W); returns (B,T,out_chn,H,W)."""
+        if x.dim() == 5:
+            x = x.reshape(x.shape[0], x.shape[1] * x.shape[2], x.shape[3], x.shape[4])   # arch:140-141
+        if x.dtype != torch.float32 or event.dtype != torch.float32 or not x.is_cuda or not event.is_cuda:
+            raise RefidHipError("forward: float32 CUDA tensors required")
+        B, T, nb, H, W = event.shape
+        if H % 8 or W % 8:
+            raise RuntimeError(f"H and W must be multiples of 8, got {H}x{W}")   # reference: shape error
+        if x.shape != (B, self.img_chn, H, W) or nb != self.ev_chn:
+            raise RuntimeError(f"unexpected input shapes x={tuple(x.shape)} event={tuple(event.shape)}")
+        self.repack()
+        dev = x.device
+        x = x.contiguous()
+        event = event.contiguous()
+        x_in = ops.nchw_to_nhwc(x, _pad4(self.img_chn))
+        ev_in = torch.empty((T * B, H, W, _pad4(self.ev_chn)), dtype=torch.float32, device=dev)
+        for t in range(T):
+            ops.nchw_to_nhwc(event[:, t], _pad4(self.ev_chn), out=ev_in[t * B:(t + 1) * B])
+        head = self.head_img.fwd(x_in, slope_pre=0.2)                      # arch:147-148
+        e_all = self.head_ev.fwd(ev_in, slope_pre=0.2)                     # arch:149
+        xb, img_saved = [], []
+        g = head
+        for i in range(3):                                                 # rsm:41-49
+            E = self.img[i]
+            c1 = E["conv_1"].fwd(g, slope_pre=0.2)
+            c2 = E["conv_2"].fwd(c1, slope_pre=0.2)
+            sm = E["identity"].fwd(g, res=c2)
+            o = E["down"].fwd(sm)
+            img_saved.append((g, c1, c2, sm))
+            xb.append(o)
+            g = o
+        ip_b = self._egaca_img_path(self.enc_b[1].att, xb[0])
+        ip_f = self._egaca_img_path(self.enc_f[1].att, xb[0])
+
+        hb = [None, None, None]
+        steps_b = []
+        for t in range(T - 1, -1, -1):                                     # arch:172-181
+            cur = e_all[t * B:(t + 1) * B]
+            sts = []
+            for i in range(3):
+                st = {} if save else None
+                cur, hb[i] = self._evr_fwd(self.enc_b[i], cur, xb, hb[i], None, ip_b, st)
+                sts.append(st)
+            steps_b.append((t, sts))
+        Sb = hb                                                            # aliasing: final states only
+
+        out = torch.empty((B, T, self.out_chn, H, W), dtype=torch.float32, device=dev)
+        out4 = torch.zeros((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
+        hf = [None, None, None]
+        hd = [None, None, None]
+        steps_f = []
+        for t in range(T):                                                 # arch:185-216
+            cur = e_all[t * B:(t + 1) * B]
+            sts, eb = [], []
+            for i in range(3):
+                st = {} if save else None
+                cur, hf[i] = self._evr_fwd(self.enc_f[i], cur, xb, hf[i], Sb[i], ip_f, st)
+                sts.append(st)
+                eb.append(cur)
+            bs = []
+            z = cur
+            for i, (c1, c2) in enumerate(self.res):                        # arch:199-203, rsm:488-503
+                b0 = ops.add(z, xb[2]) if i == 0 else z
+                b1 = c1.fwd(b0, slope_pre=0.0)
+                z = c2.fwd(b1, res=b0, slope_post=0.0)
+                bs.append((b0, b1, z))
+            ds = []
+            for j in range(3):                                             # arch:210-212, rsm:386-408
+                D = self.dec[j]
+                di = ops.add(z, eb[2 - j])
+                q = D["t2"].fwd(di)
+                dst = {} if save else None
+                z = self._trunk_fwd(D["trunk"], q, hd[j], dst)
+                hd[j] = z
+                if save:
+                    dst["di"] = di
+                ds.append(dst)
+            pi = ops.add(z, head)
+            self.pred.fwd(pi, out=out4[..., :self.out_chn])                # arch:215 (no activation)
+            ops.nhwc_to_nchw(out4[..., :self.out_chn], self.out_chn, out[:, t],
+                             dst_batch_stride=T * self.out_chn * H * W)
+            if save:
+                steps_f.append(dict(lv=sts, bs=bs, ds=ds, pi=pi))
+        if save:
+            self.ctx = dict(B=B, T=T, H=H, W=W, x_in=x_in, ev_in=ev_in, head=head, e_all=e_all, xb=xb,
+                            img_saved=img_saved, ip_b=ip_b, ip_f=ip_f, steps_b=steps_b, steps_f=steps_f, Sb=Sb)
+        else:
+            self.ctx = None
+        return out
+
+    # -------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.arena.flat_g.zero_()
+
+    def backward(self, gout, grad_sync=None):
+        """BPTT.  gout: (B,T,out_chn,H,W) gradient of the loss w.r.t. forward()'s result.
+        Parameter gradients are ACCUMULATED into the arena (call zero_grad() first).
+        grad_sync(phase): optional hook, called with "early" once the forward-sweep / decoder /
+        bottleneck / pred gradients are final (overlaps the rest of BPTT) and with "late" at the end."""
+        c = self.ctx
+        if c is None:
+            raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
+        self.ctx = None
+        B, T, H, W = c["B"], c["T"], c["H"], c["W"]
+        dev = gout.device
+        gout = gout.contiguous()
+        xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]
+        zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)  # noqa: E731
+        g_head = zeros(head)
+        g_xb = [zeros(t) for t in xb]
+        g_Sb = [None, None, None]
+        g_e = torch.empty_like(e_all)
+        g4 = torch.empty((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
+
+        # ---------------- forward sweep, t = T-1 .. 0 -------------------------------------------
+        g_hf = [None, None, None]
+        g_hd = [None, None, None]
+        for t in range(T - 1, -1, -1):
+            S = c["steps_f"][t]
+            ops.nchw_to_nhwc(gout[:, t], _pad4(self.out_chn), out=g4)
+            self.pred.wgrad(g4, S["pi"])
+            g_pi = self.pred.dgrad(g4)
+            ops.add(g_head, g_pi, out=g_head)
+            g_sd = g_pi if g_hd[2] is None else ops.add(g_pi, g_hd[2])
+            g_skip = [None, None, None]
+            for j in (2, 1, 0):
+                D, dst = self.dec[j], S["ds"][j]
+                g_q, g_hd[j] = self._trunk_bwd(D["trunk"], g_sd, dst)
+                D["t2"].wgrad(g_q, dst["di"])
+                g_di = D["t2"].dgrad(g_q)
+                g_skip[2 - j] = g_di
+                if j > 0:
+                    g_sd = g_di if g_hd[j - 1] is None else ops.add(g_di, g_hd[j - 1])
+            # bottleneck
+            g_z = g_skip[2]                                   # decoder 0's di = z + e_blocks[2]
+            for i in range(self.nres - 1, -1, -1):
+                c1, c2 = self.res[i]
+                b0, b1, z = S["bs"][i]
+                gz = ops.act_bwd(g_z, z, 0.0)
+                c2.wgrad(gz, b1)
+                g_b1 = c2.dgrad(gz, mask=b1, slope_mask=0.0)
+                c1.wgrad(g_b1, b0)
+                if i > 0:
+                    g_z = c1.dgrad(g_b1, res=gz)              # b0 is the previous block's output
+                else:
+                    g_b0 = c1.dgrad(g_b1, res=gz)
+            ops.add(g_xb[2], g_b0, out=g_xb[2])
+            g_o = ops.add(g_b0, g_skip[2])
+            for i in (2, 1, 0):
+                L, st = self.enc_f[i], S["lv"][i]
+                C = L.C
+                L.down.wgrad(g_o, st["f"])
+                g_f = L.down.dgrad(g_o, mask=st["f"], slope_mask=0.2)
+                L.fuse.wgrad(g_f, st["s"], st["Sb"])
+                g_s = L.fuse.dgrad(g_f, rows=(0, C), res=g_hf[i])
+                if g_Sb[i] is None:
+                    g_Sb[i] = L.fuse.dgrad(g_f, rows=(C, C))
+                else:
+                    L.fuse.dgrad(g_f, rows=(C, C), res=g_Sb[i], out=g_Sb[i])
+                g_o = self._evr_first_bwd(L, g_s, st, g_hf, g_xb, g_e, t, B, c["ip_f"], g_skip, first_writer=True)
+
+        # forward-sweep, bottleneck, decoder and pred weights are final from here on -- except the
+        # folded EGACA convs, un-folded now so the early bucket is complete
+        self._egaca_img_bwd(self.enc_f[1].att, xb[0], g_xb[0], c["ip_f"])
+        self._egaca_fold_back(self.enc_f[1].att)
+        if grad_sync is not None:
+            grad_sync("early")
+
+        # ---------------- backward sweep (executed t = T-1..0), BPTT in reverse: t = 0 .. T-1 ----
+        g_hb = [None, None, None]
+        for t, sts in reversed(c["steps_b"]):
+            g_o = None
+            for i in (2, 1, 0):
+                L, st = self.enc_b[i], sts[i]
+                carry = g_hb[i] if g_hb[i] is not None else g_Sb[i]     # t == 0: dL/dS_b,i
+                if i == 2:
+                    g_s = carry
+                else:
+                    L.down.wgrad(g_o, st["s"])
+                    g_s = L.down.dgrad(g_o, res=carry)
+                g_o = self._evr_first_bwd(L, g_s, st, g_hb, g_xb, g_e, t, B, c["ip_b"], None, first_writer=False)
+
+        # ---------------- t-independent tails ----------------------------------------------------
+        self._egaca_img_bwd(self.enc_b[1].att, xb[0], g_xb[0], c["ip_b"])
+        self._egaca_fold_back(self.enc_b[1].att)
+        gz_e = ops.act_bwd(g_e, e_all, 0.2, out=g_e)
+        self.head_ev.wgrad(gz_e, c["ev_in"])
+        g = g_xb[2]
+        for i in (2, 1, 0):
+            E = self.img[i]
+            gin, c1, c2, sm = c["img_saved"][i]
+            E["down"].wgrad(g, sm)
+            g_sm = E["down"].dgrad(g)
+            E["identity"].wgrad(g_sm, gin)
+            gz2 = ops.act_bwd(g_sm, c2, 0.2)
+            E["conv_2"].wgrad(gz2, c1)
+            g_c1 = E["conv_2"].dgrad(gz2, mask=c1, slope_mask=0.2)
+            E["conv_1"].wgrad(g_c1, gin)
+            acc = g_xb[i - 1] if i > 0 else g_head
+            t1 = E["identity"].dgrad(g_sm, res=acc)
+            if i > 0:
+                g = E["conv_1"].dgrad(g_c1, res=t1)
+            else:
+                g = E["conv_1"].dgrad(g_c1, res=t1, mask=head, slope_mask=0.2)
+        self.head_img.wgrad(g, c["x_in"])
+        if grad_sync is not None:
+            grad_sync("late")
+
+    def _evr_first_bwd(self, L, g_s, st, g_h, g_xb, g_e, t, B, ip, g_skip, first_writer):
+        """Trunk + first op of an EvR level; returns the gradient w.r.t. the level's input
+        (already including the decoder skip gradient when g_skip is given)."""
+        i = L.level
+        if i == 1:
+            g_u, g_h[i] = self._trunk_bwd(L.trunk, g_s, st)
+            g_in = self._egaca_bwd(L.att, g_u, g_xb[0], ip, st)
+            if g_skip is not None:
+                g_in = ops.add(g_in, g_skip[0], out=g_in)
+            return g_in
+        g_u, g_h[i] = self._trunk_bwd(L.trunk, g_s, st, mask_u=st["u"], slope_u=0.04)
+        L.conv.wgrad(g_u, st["src"])
+        if i == 2:
+            g_a2 = L.conv.dgrad(g_u)
+            ops.add(g_xb[1], g_a2, out=g_xb[1])
+            if g_skip is not None:
+                g_a2 = ops.add(g_a2, g_skip[1], out=g_a2)
+            return g_a2
+        # level 0: the input is e_t = head(event_t); collect its gradient (both sweeps) for the
+        # event head's weight gradient.  The forward-sweep BPTT runs first and writes every slice.
+        sl = g_e[t * B:(t + 1) * B]
+        if first_writer:
+            L.conv.dgrad(g_u, out=sl)
+        else:
+            L.conv.dgrad(g_u, res=sl, out=sl)
+        return None

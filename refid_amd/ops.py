@@ -44,16 +44,30 @@ def conv_bn(kh, kw, stride, mode, cout):
     return lib().refid_conv_bn(kh, kw, stride, mode, cout)
 
 
-def pack_conv_weights(w, role, bn, kc, kh, kw, o, i):
-    """Pack a reference-layout weight (OIHW, or IOHW for ConvTranspose2d) for the conv tile."""
+def packed_weight_floats(role, bn, kc, kh, kw, o, i):
+    return lib().refid_packed_weight_floats(role, o, i, kh, kw, kc, bn)
+
+
+def pack_conv_weights(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None):
+    """Pack a reference-layout weight (OIHW, or IOHW for ConvTranspose2d) for the conv tile.
+
+    oscale: optional per-output-channel factor folded into the packed copy (FWD/DGRAD)."""
     L = lib()
     nfl = L.refid_packed_weight_floats(role, o, i, kh, kw, kc, bn)
     if nfl == 0:
         raise _lib.RefidHipError("pack_conv_weights: bad geometry")
-    w = w.contiguous()
-    out = torch.empty(nfl, dtype=torch.float32, device=w.device)
-    check(L.refid_pack_conv_weights(w.data_ptr(), out.data_ptr(), role, o, i, kh, kw, kc, bn, _stream()),
-          "refid_pack_conv_weights")
+    if not w.is_contiguous():
+        raise _lib.RefidHipError("pack_conv_weights: weight must be contiguous")
+    if out is None:
+        out = torch.empty(nfl, dtype=torch.float32, device=w.device)
+    elif out.numel() != nfl:
+        raise _lib.RefidHipError("pack_conv_weights: out has the wrong size")
+    if oscale is None:
+        check(L.refid_pack_conv_weights(w.data_ptr(), out.data_ptr(), role, o, i, kh, kw, kc, bn, _stream()),
+              "refid_pack_conv_weights")
+    else:
+        check(L.refid_pack_conv_weights_scaled(w.data_ptr(), oscale.data_ptr(), out.data_ptr(), role, o, i, kh, kw,
+                                               kc, bn, _stream()), "refid_pack_conv_weights_scaled")
     return out
 
 
@@ -121,9 +135,12 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     d.ho, d.wo = g.shape[1], g.shape[2]
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
     d.i_base = i_base
-    d.i_total = i_total if i_total is not None else d.c_a + d.c_b
-    if not dw.is_contiguous() or dw.numel() != d.c_o * d.i_total * kh * kw:
-        raise _lib.RefidHipError(f"wgrad: dw shape {tuple(dw.shape)} does not match ({d.c_o},{d.i_total},{kh},{kw})")
+    d.i_total = i_total if i_total is not None else dw.shape[1]
+    d.o_real = dw.shape[0]
+    if not dw.is_contiguous() or dw.dim() != 4 or dw.shape[1] != d.i_total or dw.shape[2:] != (kh, kw) \
+            or d.o_real > d.c_o:
+        raise _lib.RefidHipError(f"wgrad: dw shape {tuple(dw.shape)} does not match g/in channels "
+                                 f"({d.c_o},{d.i_total},{kh},{kw})")
     d.dw = dw.data_ptr()
     d.db = db.data_ptr() if db is not None else None
     nbytes = lib().refid_wgrad_workspace_bytes(C.byref(d))
@@ -134,13 +151,15 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
 
 
-def nchw_to_nhwc(src, c_pad=None):
-    """(N,C,H,W) contiguous -> (N,H,W,c_pad) with zero channel padding."""
-    src = src.contiguous()
+def nchw_to_nhwc(src, c_pad=None, out=None):
+    """(N,C,H,W) with dense (C,H,W) planes (any batch stride) -> (N,H,W,c_pad), zero channel padding."""
     n, c, h, w = src.shape
+    if src.stride(3) != 1 or src.stride(2) != w or src.stride(1) != h * w:
+        raise _lib.RefidHipError("nchw_to_nhwc: per-sample (C,H,W) block must be dense")
     c_pad = c_pad or ((c + 3) // 4) * 4
-    dst = torch.empty((n, h, w, c_pad), dtype=torch.float32, device=src.device)
-    check(lib().refid_nchw_to_nhwc(src.data_ptr(), dst.data_ptr(), n, c, h, w, c_pad, _stream()), "refid_nchw_to_nhwc")
+    dst = out if out is not None else torch.empty((n, h, w, c_pad), dtype=torch.float32, device=src.device)
+    check(lib().refid_nchw_to_nhwc(src.data_ptr(), src.stride(0) if n > 1 else c * h * w, dst.data_ptr(), n, c, h, w,
+                                   c_pad, _stream()), "refid_nchw_to_nhwc")
     return dst
 
 
@@ -174,3 +193,155 @@ def act_bwd(g, y, slope, out=None, accumulate=False):
     check(lib().refid_act_bwd(g.data_ptr(), y.data_ptr(), out.data_ptr(), slope, int(accumulate), g.numel(), _stream()),
           "refid_act_bwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# EGACA pieces / train-step tail.  Plain contiguous NHWC tensors unless a pitch is mentioned.
+# ---------------------------------------------------------------------------------------------
+def _c(t, name):
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise _lib.RefidHipError(f"{name}: contiguous CUDA float32 tensor required")
+    return t.data_ptr()
+
+
+def layernorm2d_fwd(x, w, b, out=None, eps=1e-6):
+    px, ld = _nhwc(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    po, ldo = _nhwc(out, "out")
+    npix = x.shape[0] * x.shape[1] * x.shape[2]
+    check(lib().refid_layernorm2d_fwd(px, ld, _c(w, "w"), _c(b, "b"), po, ldo, npix, x.shape[3], eps, _stream()),
+          "refid_layernorm2d_fwd")
+    return out
+
+
+def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, eps=1e-6):
+    pg, ldg = _nhwc(g, "g")
+    px, ldx = _nhwc(x, "x")
+    pgx, ldgx = _nhwc(gx, "gx")
+    npix = x.shape[0] * x.shape[1] * x.shape[2]
+    check(lib().refid_layernorm2d_bwd(pg, ldg, px, ldx, _c(w, "w"), pgx, ldgx, int(accumulate), _c(dw, "dw"),
+                                      _c(db, "db"), npix, x.shape[3], eps, _stream()), "refid_layernorm2d_bwd")
+    return gx
+
+
+def dwconv3x3_gelu_fwd(x, w, b, pool=None):
+    px, ld = _nhwc(x, "x")
+    n, h, wd, c = x.shape
+    pre = torch.empty((n, h, wd, c), dtype=torch.float32, device=x.device)
+    act = torch.empty_like(pre)
+    check(lib().refid_dwconv3x3_gelu_fwd(px, ld, _c(w, "w"), _c(b, "b"), pre.data_ptr(), act.data_ptr(),
+                                         pool.data_ptr() if pool is not None else None, n, h, wd, c, _stream()),
+          "refid_dwconv3x3_gelu_fwd")
+    return pre, act
+
+
+def dwconv3x3_bwd(gd, x, w, dw, db):
+    px, ld = _nhwc(x, "x")
+    n, h, wd, c = x.shape
+    gin = torch.empty((n, h, wd, c), dtype=torch.float32, device=x.device)
+    check(lib().refid_dwconv3x3_bwd(_c(gd, "gd"), px, ld, _c(w, "w"), gin.data_ptr(), _c(dw, "dw"), _c(db, "db"),
+                                    n, h, wd, c, _stream()), "refid_dwconv3x3_bwd")
+    return gin
+
+
+def se_fwd(pool, inv_hw, w1, b1, w2, b2):
+    n, c = pool.shape
+    m = torch.empty_like(pool)
+    z1 = torch.empty((n, c // 2), dtype=torch.float32, device=pool.device)
+    s = torch.empty_like(pool)
+    check(lib().refid_se_fwd(_c(pool, "pool"), inv_hw, _c(w1, "w1"), _c(b1, "b1"), _c(w2, "w2"), _c(b2, "b2"),
+                             m.data_ptr(), z1.data_ptr(), s.data_ptr(), n, c, _stream()), "refid_se_fwd")
+    return m, z1, s
+
+
+def se_bwd(gs, s, z1, m, w1, w2, dw1, db1, dw2, db2):
+    n, c = gs.shape
+    gm = torch.empty_like(gs)
+    check(lib().refid_se_bwd(_c(gs, "gs"), _c(s, "s"), _c(z1, "z1"), _c(m, "m"), _c(w1, "w1"), _c(w2, "w2"),
+                             gm.data_ptr(), _c(dw1, "dw1"), _c(db1, "db1"), _c(dw2, "dw2"), _c(db2, "db2"), n, c,
+                             _stream()), "refid_se_bwd")
+    return gm
+
+
+def scale_cat(xi, xe, s):
+    n, h, w, c = xi.shape
+    out = torch.empty((n, h, w, 2 * c), dtype=torch.float32, device=xi.device)
+    check(lib().refid_scale_cat(_c(xi, "xi"), _c(xe, "xe"), _c(s, "s"), out.data_ptr(), n, h * w, c, _stream()),
+          "refid_scale_cat")
+    return out
+
+
+def egaca_gs_reduce(gxs, xi, xe):
+    n, h, w, c = xi.shape
+    gs = torch.empty((n, c), dtype=torch.float32, device=xi.device)
+    check(lib().refid_egaca_gs_reduce(_c(gxs, "gxs"), _c(xi, "xi"), _c(xe, "xe"), gs.data_ptr(), n, h * w, c,
+                                      _stream()), "refid_egaca_gs_reduce")
+    return gs
+
+
+def egaca_bwd_elem(gxs, s, gm, dwe, gxi, accumulate_xi):
+    n, h, w, c = dwe.shape
+    gdwe = torch.empty_like(dwe)
+    check(lib().refid_egaca_bwd_elem(_c(gxs, "gxs"), _c(s, "s"), _c(gm, "gm"), 1.0 / (h * w), _c(dwe, "dwe"),
+                                     gdwe.data_ptr(), _c(gxi, "gxi"), int(accumulate_xi), n, h * w, c, _stream()),
+          "refid_egaca_bwd_elem")
+    return gdwe
+
+
+def gelu_fwd(x):
+    out = torch.empty_like(x)
+    check(lib().refid_gelu_fwd(_c(x, "x"), out.data_ptr(), x.numel(), _stream()), "refid_gelu_fwd")
+    return out
+
+
+def gelu_bwd(g, x, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().refid_gelu_bwd(_c(g, "g"), _c(x, "x"), out.data_ptr(), x.numel(), _stream()), "refid_gelu_bwd")
+    return out
+
+
+def colsum(g, db):
+    pg, ld = _nhwc(g, "g")
+    npix = g.shape[0] * g.shape[1] * g.shape[2]
+    check(lib().refid_colsum(pg, ld, _c(db, "db"), npix, g.shape[3], _stream()), "refid_colsum")
+
+
+def mul_vec(a, b, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib().refid_mul_vec(_c(a, "a"), _c(b, "b"), out.data_ptr(), a.numel(), _stream()), "refid_mul_vec")
+    return out
+
+
+def fold_back(w, b, scale, gw, gb, dscale):
+    rows = scale.numel()
+    k = w.numel() // rows
+    check(lib().refid_fold_back(_c(w, "w"), _c(b, "b"), _c(scale, "scale"), _c(gw, "gw"), _c(gb, "gb"),
+                                _c(dscale, "dscale"), rows, k, _stream()), "refid_fold_back")
+
+
+def charbonnier(pred, gt, grad=None, eps=1e-12, grad_scale=None):
+    """Returns the device double holding sum sqrt((pred-gt)^2+eps); grad (optional) gets d/dpred of the MEAN."""
+    n = pred.numel()
+    loss_sum = torch.empty(1, dtype=torch.float64, device=pred.device)
+    if grad_scale is None:
+        grad_scale = 1.0 / n
+    check(lib().refid_charbonnier(_c(pred, "pred"), _c(gt, "gt"), grad.data_ptr() if grad is not None else None,
+                                  loss_sum.data_ptr(), n, eps, grad_scale, _stream()), "refid_charbonnier")
+    return loss_sum
+
+
+def grad_sqnorm(flat_g, out=None):
+    if out is None:
+        out = torch.empty(1, dtype=torch.float64, device=flat_g.device)
+    check(lib().refid_grad_sqnorm(_c(flat_g, "g"), out.data_ptr(), flat_g.numel(), _stream()), "refid_grad_sqnorm")
+    return out
+
+
+def clip_adamw(p, g, m, v, sqnorm, *, max_norm, lr, betas, eps, weight_decay, step, grad_scale=1.0):
+    check(lib().refid_clip_adamw(_c(p, "p"), _c(g, "g"), _c(m, "m"), _c(v, "v"),
+                                 sqnorm.data_ptr() if sqnorm is not None else None, max_norm, grad_scale, lr,
+                                 betas[0], betas[1], eps, weight_decay, step, p.numel(), _stream()),
+          "refid_clip_adamw")

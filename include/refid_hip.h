@@ -87,6 +87,9 @@ int refid_conv2d(const refid_conv_desc* d, void* stream);
 /* Channel-chunk width (KC) and row padding (BN) the conv tile for this geometry wants
  * its packed weights in. */
 int refid_conv_kc(int kh, int kw, int stride, int mode);
+/* "Cfg<...>" template signature of the tile refid_conv2d launches for this geometry (matches the
+ * kernel name rocprofv3 reports); used by bench.py to attribute time to the dominant kernel. */
+const char* refid_conv_tile_name(int kh, int kw, int stride, int mode, int cout);
 int refid_conv_bn(int kh, int kw, int stride, int mode, int cout);
 
 /* ------------------------------------------------------------------------------------

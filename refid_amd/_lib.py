@@ -64,6 +64,8 @@ def lib():
     L.refid_conv2d.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
     L.refid_conv_kc.argtypes = [C.c_int] * 4
     L.refid_conv_bn.argtypes = [C.c_int] * 5
+    L.refid_conv_tile_name.argtypes = [C.c_int] * 5
+    L.refid_conv_tile_name.restype = C.c_char_p
     L.refid_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
     L.refid_wgrad_workspace_bytes.restype = C.c_size_t
     L.refid_conv2d_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]

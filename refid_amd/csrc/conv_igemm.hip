@@ -311,6 +311,23 @@ extern "C" int refid_conv_bn(int kh, int kw, int stride, int mode, int cout) {
     }
 }
 
+extern "C" const char* refid_conv_tile_name(int kh, int kw, int stride, int mode, int cout) {
+    // template signature of the instantiation refid_conv2d launches (= the rocprof kernel name's Cfg<...>)
+    const int bn = refid_conv_bn(kh, kw, stride, mode, cout);
+    switch (family_of(kh, kw, stride, mode)) {
+        case F_3x3: return bn == 32 ? "Cfg<3, 3, 1, 4, 1, 2, 1, 1, 0>" : bn == 64 ? "Cfg<3, 3, 1, 4, 1, 2, 2, 1, 0>"
+                                                                                  : "Cfg<3, 3, 1, 2, 2, 2, 2, 1, 0>";
+        case F_5x5: return "Cfg<5, 5, 1, 4, 1, 2, 1, 1, 0>";
+        case F_1x1: return bn == 32 ? "Cfg<1, 1, 1, 4, 1, 2, 1, 4, 0>" : bn == 64 ? "Cfg<1, 1, 1, 4, 1, 2, 2, 4, 0>"
+                                                                                  : "Cfg<1, 1, 1, 2, 2, 2, 2, 4, 0>";
+        case F_4x4s2: return "Cfg<4, 4, 2, 4, 1, 2, 2, 1, 0>";
+        case F_2x2s2: return bn == 64 ? "Cfg<2, 2, 2, 4, 1, 2, 2, 1, 0>" : "Cfg<2, 2, 2, 2, 2, 2, 2, 1, 0>";
+        case F_convT: return bn == 64 ? "Cfg<1, 1, 1, 4, 1, 2, 2, 4, 1>" : "Cfg<1, 1, 1, 2, 2, 2, 2, 4, 1>";
+        case F_downDgrad: return bn == 64 ? "Cfg<3, 3, 1, 4, 1, 2, 2, 2, 2>" : "Cfg<3, 3, 1, 2, 2, 2, 2, 2, 2>";
+        default: return "none";
+    }
+}
+
 extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     REFID_CHECK(d != nullptr, "conv2d: null descriptor");

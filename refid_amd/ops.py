@@ -14,6 +14,11 @@ from ._lib import ConvDesc, WgradDesc, check, lib
 ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD = range(5)
 
 
+# bench.py's roofline leg: when PROFILE is a list, conv2d()/conv2d_wgrad() bracket each launch with
+# events on the launch stream and append (kernel, algorithmic_flops, start_event, end_event).
+PROFILE = None
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -104,7 +109,17 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.cout, d.cout_pad, d.co_base = cout, cout_pad, co_base
     d.kh, d.kw, d.stride, d.pad, d.mode = kh, kw, stride, pad, mode
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
+    if PROFILE is None:
+        check(lib().refid_conv2d(C.byref(d), _stream()), "refid_conv2d")
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().refid_conv2d(C.byref(d), _stream()), "refid_conv2d")
+    e1.record()
+    taps = {0: kh * kw, 1: 1, 2: 16}[mode]
+    flops = 2.0 * d.n * d.ho * d.wo * cout * (d.c_a + d.c_b) * taps
+    name = lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode()
+    PROFILE.append(("conv_igemm_kernel<" + name + ">", flops, e0, e1))
     return out
 
 
@@ -148,7 +163,15 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
         raise _lib.RefidHipError("wgrad: unsupported geometry")
     ws = _workspace(nbytes, g.device)
     d.slabs = ws.data_ptr()
+    if PROFILE is None:
+        check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
+    e1.record()
+    flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
+    PROFILE.append((f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce", flops, e0, e1))
 
 
 def nchw_to_nhwc(src, c_pad=None, out=None):

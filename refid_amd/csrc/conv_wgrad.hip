@@ -210,49 +210,84 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
 
 struct RedArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
-    int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal;
+    int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
 };
 
+// Slab reduction.  grid = (float4 elements / 256, split groups): every thread sums ONE float4
+// (4 consecutive input channels) over its group's slabs with 8 independent 16-byte loads in
+// flight, then adds into the parameter-layout gradient with fp32 atomics (groups <= 8, so a
+// gradient element sees at most 8 atomics per call).  Bandwidth-bound instead of latency-bound.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
-    // threads <-> (tap, co, ci), ci fastest (coalesced slab reads)
-    const long long total = (long long)a.ntaps * a.Co * a.Ci;
-    const long long slabStride = (long long)a.ntaps * a.CoP * a.CiP;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int Ci4 = a.CiP / 4;
+    const long long total4 = (long long)a.ntaps * a.CoP * Ci4;
+    const long long slabStride4 = total4;
+    const int s0 = blockIdx.y * a.perGroup;
+    const int s1 = min(a.nsplit, s0 + a.perGroup);
+    const long long e = blockIdx.x * 256ll + threadIdx.x;
+    if (e < total4) {
         long long r = e;
-        const int ci = r % a.Ci; r /= a.Ci;
-        const int co = r % a.Co;
-        const int tap = r / a.Co;
-        const float* p = a.slabs + ((long long)tap * a.CoP + co) * a.CiP + ci;
-        float s = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) s += p[k * slabStride];
-        float* d = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * a.ntaps + tap;
-        *d += s;
+        const int ci = (int)(r % Ci4) * 4; r /= Ci4;
+        const int co = (int)(r % a.CoP);
+        const int tap = (int)(r / a.CoP);
+        if (co < a.Co && ci < a.Ci) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.slabs) + e;
+            f32x4 acc[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            int k = s0;
+            for (; k + 8 <= s1; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u] += p[(long long)(k + u) * slabStride4];
+            }
+            for (; k < s1; ++k) acc[0] += p[(long long)k * slabStride4];
+            const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            float* d = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * a.ntaps + tap;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ci + j >= a.Ci) break;
+                if (gridDim.y > 1) atomicAdd(d + (long long)j * a.ntaps, sum[j]);
+                else d[(long long)j * a.ntaps] += sum[j];       // single group: this thread owns the element
+            }
+        }
     }
     if (a.db != nullptr && blockIdx.x == 0) {
         for (int co = threadIdx.x; co < a.Co; co += 256) {
             float s = 0.f;
-            for (int k = 0; k < a.nsplit; ++k) s += a.bslabs[(long long)k * a.CoP + co];
-            a.db[co] += s;
+            for (int k = s0; k < s1; ++k) s += a.bslabs[(long long)k * a.CoP + co];
+            if (gridDim.y > 1) atomicAdd(a.db + co, s);
+            else a.db[co] += s;
         }
     }
 }
 
 // <KH,KW,S, TPW, SM,SN, WR,WC,WT, TH,TW>
-using W3 = WCfg<3, 3, 1, 9, 1, 1, 2, 2, 1, 2, 32>;
+using W3 = WCfg<3, 3, 1, 9, 1, 1, 2, 2, 1, 2, 32>;          // 64 x 64 channels, 9 taps per wave
+using W3_64x32 = WCfg<3, 3, 1, 5, 1, 1, 2, 1, 2, 2, 32>;    // narrow input  (Ci <= 32): taps split over 2 waves
+using W3_32x64 = WCfg<3, 3, 1, 5, 1, 1, 1, 2, 2, 2, 32>;    // narrow output (Co <= 32)
+using W3_32x32 = WCfg<3, 3, 1, 3, 1, 1, 1, 1, 4, 2, 32>;    // both narrow: taps split over 4 waves
 using W1 = WCfg<1, 1, 1, 1, 2, 2, 2, 2, 1, 2, 32>;
 using W4S2 = WCfg<4, 4, 2, 8, 1, 1, 2, 1, 2, 2, 16>;
 using W5 = WCfg<5, 5, 1, 7, 1, 1, 1, 1, 4, 2, 32>;
 using W2S2 = WCfg<2, 2, 2, 4, 1, 1, 2, 2, 1, 2, 16>;
 
-struct Plan { int cot, cit, th, tw, ntaps; bool ok; };
+enum PlanId { P_W3, P_W3_64x32, P_W3_32x64, P_W3_32x32, P_W1, P_W4S2, P_W5, P_W2S2, P_NONE };
+struct Plan { PlanId id; int cot, cit, th, tw, ntaps; bool ok; };
 
-Plan plan_of(int kh, int kw, int s) {
-    if (kh == 3 && kw == 3 && s == 1) return {W3::COT, W3::CIT, W3::TH, W3::TW, 9, true};
-    if (kh == 1 && kw == 1 && s == 1) return {W1::COT, W1::CIT, W1::TH, W1::TW, 1, true};
-    if (kh == 4 && kw == 4 && s == 2) return {W4S2::COT, W4S2::CIT, W4S2::TH, W4S2::TW, 16, true};
-    if (kh == 5 && kw == 5 && s == 1) return {W5::COT, W5::CIT, W5::TH, W5::TW, 25, true};
-    if (kh == 2 && kw == 2 && s == 2) return {W2S2::COT, W2S2::CIT, W2S2::TH, W2S2::TW, 4, true};
-    return {0, 0, 0, 0, 0, false};
+template <class C>
+Plan mk(PlanId id) { return {id, C::COT, C::CIT, C::TH, C::TW, C::NTAPS, true}; }
+
+Plan plan_of(int kh, int kw, int s, int co, int ci) {
+    if (kh == 3 && kw == 3 && s == 1) {
+        if (co <= 32 && ci <= 32) return mk<W3_32x32>(P_W3_32x32);
+        if (ci <= 32) return mk<W3_64x32>(P_W3_64x32);
+        if (co <= 32) return mk<W3_32x64>(P_W3_32x64);
+        return mk<W3>(P_W3);
+    }
+    if (kh == 1 && kw == 1 && s == 1) return mk<W1>(P_W1);
+    if (kh == 4 && kw == 4 && s == 2) return mk<W4S2>(P_W4S2);
+    if (kh == 5 && kw == 5 && s == 1) return mk<W5>(P_W5);
+    if (kh == 2 && kw == 2 && s == 2) return mk<W2S2>(P_W2S2);
+    return {P_NONE, 0, 0, 0, 0, 0, false};
 }
 
 struct Geo { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
@@ -264,7 +299,7 @@ Geo geo_of(const refid_wgrad_desc* d, const Plan& p) {
     g.tilesX = cdiv(d->wo, p.tw);
     g.tilesY = cdiv(d->ho, p.th);
     g.ntiles = g.tilesX * g.tilesY * d->n;
-    int want = cdiv(768, g.ncoT * g.nciT);           // ~3 workgroups per CU on 256 CUs
+    int want = cdiv(512, g.ncoT * g.nciT);           // 2 resident workgroups per CU on 256 CUs, one round
     if (want < 1) want = 1;
     if (want > g.ntiles) want = g.ntiles;
     g.nsplit = want;
@@ -292,7 +327,7 @@ int launch_w(const WgKArgs& a, const Geo& g, hipStream_t st) {
 
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
-    const Plan p = plan_of(d->kh, d->kw, d->stride);
+    const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->c_a + d->c_b);
     if (!p.ok) return 0;
     const Geo g = geo_of(d, p);
     return ((size_t)g.nsplit * p.ntaps * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP) * sizeof(float);
@@ -301,7 +336,7 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
 extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     REFID_CHECK(d != nullptr, "wgrad: null descriptor");
-    const Plan p = plan_of(d->kh, d->kw, d->stride);
+    const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->c_a + d->c_b);
     REFID_CHECK(p.ok, "wgrad: unsupported geometry k=%dx%d stride=%d", d->kh, d->kw, d->stride);
     REFID_CHECK(d->g && d->in_a && d->dw && d->slabs, "wgrad: null tensor pointer");
     REFID_CHECK(d->c_o > 0 && d->c_o % 4 == 0 && d->c_a > 0 && d->c_a % 4 == 0 && d->c_b >= 0 && d->c_b % 4 == 0,
@@ -324,12 +359,18 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pad = d->pad;
     a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
     a.CoP = g.CoP; a.CiP = g.CiP;
-    int rc;
-    if (d->kh == 3) rc = launch_w<W3>(a, g, st);
-    else if (d->kh == 1) rc = launch_w<W1>(a, g, st);
-    else if (d->kh == 4) rc = launch_w<W4S2>(a, g, st);
-    else if (d->kh == 5) rc = launch_w<W5>(a, g, st);
-    else rc = launch_w<W2S2>(a, g, st);
+    int rc = 1;
+    switch (p.id) {
+        case P_W3: rc = launch_w<W3>(a, g, st); break;
+        case P_W3_64x32: rc = launch_w<W3_64x32>(a, g, st); break;
+        case P_W3_32x64: rc = launch_w<W3_32x64>(a, g, st); break;
+        case P_W3_32x32: rc = launch_w<W3_32x32>(a, g, st); break;
+        case P_W1: rc = launch_w<W1>(a, g, st); break;
+        case P_W4S2: rc = launch_w<W4S2>(a, g, st); break;
+        case P_W5: rc = launch_w<W5>(a, g, st); break;
+        case P_W2S2: rc = launch_w<W2S2>(a, g, st); break;
+        default: break;
+    }
     if (rc) return rc;
     RedArgs r;
     r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
@@ -339,10 +380,16 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     r.Ci = a.Ctot < d->i_total - d->i_base ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP;
     r.iBase = d->i_base; r.iTotal = d->i_total;
-    const long long total = (long long)p.ntaps * r.Co * r.Ci;
-    long long nb = (total + 255) / 256;
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)nb), dim3(256), 0, st, r);
+    const long long total4 = (long long)p.ntaps * g.CoP * (g.CiP / 4);
+    const int nb = (int)((total4 + 255) / 256);
+    // split groups only where one thread per float4 would leave the chip idle (small weight tensors)
+    int groups = (int)(65536 / total4);
+    if (groups > 8) groups = 8;
+    if (groups > g.nsplit) groups = g.nsplit;
+    if (groups < 1) groups = 1;
+    r.perGroup = cdiv(g.nsplit, groups);
+    groups = cdiv(g.nsplit, r.perGroup);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb, groups), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }

@@ -185,7 +185,10 @@ def test_conv_transpose_fwd_and_dgrad(cfg):
     (2, 16, 32, 64, 0, 64, 3, 1, 1),
     (1, 24, 40, 64, 64, 64, 3, 1, 1),
     (1, 8, 8, 256, 256, 256, 3, 1, 1),
-    (1, 16, 32, 32, 32, 32, 3, 1, 1),
+    (1, 16, 32, 32, 32, 32, 3, 1, 1),         # narrow-output tile
+    (1, 16, 32, 32, 0, 64, 3, 1, 1),          # narrow-input tile
+    (2, 8, 32, 32, 0, 32, 3, 1, 1),           # both narrow
+    (1, 8, 32, 32, 0, 3, 3, 1, 1),            # pred: 3 real output rows (g padded to 4)
     (1, 16, 24, 28, 0, 32, 5, 1, 2),
     (2, 8, 16, 128, 128, 128, 1, 1, 0),
     (1, 16, 16, 32, 0, 64, 1, 1, 0),
@@ -206,8 +209,13 @@ def test_conv_wgrad(cfg):
     db = torch.zeros(Co, device="cuda")
     xa = nhwc(x[:, :Ca])
     xb = nhwc(x[:, Ca:]) if Cb else None
+    gd = nhwc(g)
+    if Co % 4:              # channel-padded gradient (pred): pad channel carries garbage-free zeros
+        buf = torch.zeros(*gd.shape[:3], -(-Co // 4) * 4, device="cuda")
+        buf[..., :Co] = gd
+        gd = buf
     for _ in range(2):      # accumulates: two calls -> 2x
-        ops.conv2d_wgrad(nhwc(g), xa, dw, kh=k, kw=k, stride=s, pad=p, in_b=xb, db=db)
+        ops.conv2d_wgrad(gd, xa, dw, kh=k, kw=k, stride=s, pad=p, in_b=xb, db=db)
     scale = max(1.0, float(w.grad.abs().max()))
     np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
     np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)

@@ -1,0 +1,164 @@
+"""CPU-only tests of the host side: discovery, option parsing, parameter inventory, arena
+layout, schedules, bucket planning, and that the product path refuses to run without a GPU."""
+import os
+import textwrap
+
+import pytest
+import torch
+
+from oracle import refid_oracle as O
+
+
+def test_define_network_contract():
+    from refid_amd.archs import define_network
+    opt = dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2, num_encoders=3, base_num_channels=32,
+               num_block=1, num_residual_blocks=2)
+    net = define_network(opt)
+    assert "type" not in opt                                  # popped destructively like the reference
+    assert type(net).__name__ == "FinalBidirectionAttenfusion"
+    with pytest.raises(ValueError, match="NoSuchNet is not found."):
+        define_network(dict(type="NoSuchNet"))
+
+
+@pytest.mark.parametrize("img_chn,count", [(26, 15928355), (6, 15912355), (3, 15909955)])
+def test_state_dict_keys_shapes_and_counts(img_chn, count):
+    from refid_amd.archs import define_network
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=3,
+                              base_num_channels=32, num_block=1, num_residual_blocks=2))
+    sd = net.state_dict()
+    ref = O.param_shapes(img_chn)                   # pinned to the reference by tests/test_oracle_golden.py
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 183
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    assert sum(p.numel() for p in net.parameters()) == count
+    # a reference-style checkpoint loads strictly, also with DDP's "module." prefix stripped by the wrapper
+    P = O.make_params(img_chn)
+    net.load_state_dict(P, strict=True)
+    assert torch.equal(net.state_dict()["pred.conv2d.weight"], P["pred.conv2d.weight"])
+    # zero-initialised beta/gamma, LayerNorm 1/0 after reset (fm:287-288)
+    net.reset_parameters()
+    sd = net.state_dict()
+    assert float(sd["encoders_forward.1.atten_fuse.beta"].abs().max()) == 0.0
+    assert float(sd["encoders_forward.1.atten_fuse.norm1.weight"].min()) == 1.0
+
+
+def test_unsupported_options_fail_loudly():
+    from refid_amd.archs import define_network
+    base = dict(type="FinalBidirectionAttenfusion", img_chn=6, ev_chn=2, num_encoders=3, num_block=1)
+    for bad in (dict(num_encoders=4), dict(num_block=3), dict(skip_type="concat"), dict(norm="BN"),
+                dict(use_recurrent_upsample_conv=False)):
+        with pytest.raises(NotImplementedError):
+            define_network({**base, **bad})
+    with pytest.raises(AssertionError):
+        define_network({**base, "img_chn": 0})
+    # ignored-by-the-reference keywords are accepted
+    define_network({**base, "recurrent_block_type": "convgru", "activation": "tanh", "use_first_dcn": True})
+
+
+def test_no_cpu_fallback():
+    from refid_amd._lib import RefidHipError
+    from refid_amd.archs import define_network
+    from refid_amd import ops
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=6, ev_chn=2, num_encoders=3,
+                              base_num_channels=8, num_block=1))
+    x, ev, _ = O.make_inputs(1, 2, 16, 16, 6)
+    with pytest.raises(RefidHipError, match="no CPU path"):
+        net(x=x, event=ev)
+    with pytest.raises(RefidHipError):
+        ops.conv2d(torch.zeros(1, 8, 8, 64), torch.zeros(10), torch.zeros(1, 8, 8, 64), kh=3, kw=3, pad=1,
+                   cout=64, cout_pad=64)
+
+
+def test_param_arena_layout():
+    from refid_amd.engine import ParamArena, param_shapes
+    sh = param_shapes(26)
+    A = ParamArena(sh, torch.device("cpu"))
+    prev_end = 0
+    for k, (off, n) in A.offsets.items():
+        assert off % 4 == 0 and off >= prev_end
+        prev_end = off + n
+    assert A.total % 4 == 0 and A.total >= 15928355
+    A.p("pred.conv2d.bias").fill_(3.0)
+    off, n = A.offsets["pred.conv2d.bias"]
+    assert float(A.flat_p[off:off + n].sum()) == 9.0 and A.g("pred.conv2d.bias").shape == (3,)
+
+
+def test_bucket_plan_covers_arena_once():
+    from refid_amd.dist import bucket_slices, EARLY_PREFIXES, shard_batch
+    from refid_amd.engine import ParamArena, param_shapes
+    A = ParamArena(param_shapes(26), torch.device("cpu"))
+    runs = bucket_slices(A.offsets, A.total)
+    spans = sorted(runs["early"] + runs["late"])
+    assert spans[0][0] == 0 and spans[-1][1] == A.total
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    for k, (off, n) in A.offsets.items():
+        phase = "early" if k.startswith(EARLY_PREFIXES) else "late"
+        assert any(s <= off and off + n <= e for s, e in runs[phase]), k
+    assert len(runs["early"]) == 2 and len(runs["late"]) == 2
+    assert sorted(shard_batch(8, 0, 4) + shard_batch(8, 1, 4) + shard_batch(8, 2, 4) + shard_batch(8, 3, 4)) == list(range(8))
+
+
+def test_options_parse_and_shapes(tmp_path):
+    from refid_amd import options
+    yml = tmp_path / "train_debug.yml"
+    yml.write_text(textwrap.dedent("""
+        name: Final_debug_run
+        model_type: TwoImageEventRecurrentRestorationModel
+        scale: 1
+        num_gpu: 8
+        manual_seed: 10
+        datasets:
+          train:
+            name: gopro-twoblur-train
+            type: GoProEventRecurrentDataset
+            dataroot: ~/data
+            num_end_interpolation: 11
+            num_inter_interpolation: 1
+            return_deblur_voxel: true
+            gt_size: 256
+            batch_size_per_gpu: 1
+        network_g:
+          type: FinalBidirectionAttenfusion
+          img_chn: 26
+          ev_chn: 2
+          num_encoders: 3
+          base_num_channels: 32
+          num_block: 1
+          num_residual_blocks: 2
+        path:
+          pretrain_network_g: ~
+          strict_load_g: true
+          resume_state: ~
+        train:
+          optim_g: {type: AdamW, lr: !!float 2e-4, weight_decay: !!float 1e-4, betas: [0.9, 0.99]}
+          scheduler: {type: TrueCosineAnnealingLR, T_max: 200000, eta_min: !!float 1e-7}
+          total_iter: 200000
+          pixel_opt: {type: CharbonnierLoss, loss_weight: 1, reduction: mean}
+        val: {val_freq: !!float 5e4, max_minibatch: 2, grids: ~}
+        logger: {print_freq: 200, save_checkpoint_freq: !!float 25000}
+        dist_params: {backend: nccl, port: 29500}
+    """))
+    opt = options.parse(str(yml), is_train=True)
+    assert opt["is_train"] and opt["datasets"]["train"]["phase"] == "train" and opt["datasets"]["train"]["scale"] == 1
+    assert opt["val"]["val_freq"] == 8 and opt["logger"]["print_freq"] == 1          # debug-mode overrides
+    assert opt["path"]["models"].endswith(os.path.join("experiments", "Final_debug_run", "models"))
+    assert opt["train"]["optim_g"]["lr"] == 2e-4 and opt["dist_params"]["backend"] == "nccl"
+    assert options.shapes_from_dataset_opt(opt["datasets"]["train"]) == (23, 26)
+    assert options.shapes_from_dataset_opt(dict(num_end_interpolation=11, num_inter_interpolation=3,
+                                                return_deblur_voxel=True)) == (25, 26)
+    assert options.shapes_from_dataset_opt(dict(num_end_interpolation=1, num_inter_interpolation=7)) == (7, 6)
+    t = options.parse(str(yml), is_train=False)
+    assert "results_root" in t["path"]
+
+
+def test_cosine_schedule_matches_reference_stepping():
+    """base_model.py:158-180: scheduler.step() from iteration 2 on; torch CosineAnnealingLR."""
+    import math
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=2e-4)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=100, eta_min=1e-7)
+    epoch = 0
+    for it in range(1, 30):
+        if it > 1:
+            opt.step(); sch.step(); epoch += 1
+        mine = 1e-7 + (2e-4 - 1e-7) * (1 + math.cos(math.pi * epoch / 100)) / 2
+        assert abs(opt.param_groups[0]["lr"] - mine) < 1e-12

@@ -156,7 +156,7 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
-        for name, fl, e0, e1 in prof:
+        for name, fl, e0, e1, _shape in prof:
             a = agg.setdefault(name, [0.0, 0.0, 0])
             a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
         name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])

@@ -27,7 +27,9 @@
 //     workgroups per CU cover each other's barrier bubbles.
 //   * NHWC activations: a halo pixel's KC channels are one contiguous 32..128-byte piece.
 //   * Epilogue is fused: bias, LeakyReLU, residual add, second LeakyReLU, activation-
-//     derivative mask; stores are 128-byte contiguous runs per pixel (32 channels).
+//     derivative mask.  The accumulator is D[cout][pixel] (weights are the MFMA "A" operand), so
+//     a lane owns 4 consecutive channels of one pixel per register quad: every epilogue tensor is
+//     touched with 16-byte accesses.
 #include "common.h"
 
 namespace {
@@ -44,6 +46,7 @@ struct ConvKArgs {
     int pad, nchunks, tilesX, tilesY;
     float slopePre, slopePost, slopeMask;
     long long wClsStride;
+    int vecOK;                 // out/res/mask/bias allow 16-byte channel-quad accesses
 };
 
 template <int KH_, int KW_, int S_, int WM_, int WN_, int MT_, int NT_, int NSUB_, int MODE_>
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                     for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                         for (int nn = 0; nn < C::NT; ++nn)
-                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m][kk], bf[nn][kk],
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nn][kk], af[m][kk],
                                                                              acc[m][nn], 0, 0, 0);
             }
         }
@@ -209,34 +212,62 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
 
     // ---- fused epilogue -------------------------------------------------------------------
+    // D[cout][pixel]: lane (li = pixel column, kh) holds, per register quad g, the four
+    // consecutive output channels 8g + 4kh + {0..3} of pixel li -> one 16-byte access per
+    // tensor (bias / residual / mask / out) instead of four 4-byte ones.
     const int Co1 = (C::MODE == 1) ? (a.Cout >> 2) : a.Cout;   // real channels (mode 1)
     const int OW = (C::MODE == 0) ? a.Wo : 2 * a.Wo;
     const int OH = (C::MODE == 0) ? a.Ho : 2 * a.Ho;
+    const int ox = ox0 + li;
 #pragma unroll
     for (int nn = 0; nn < C::NT; ++nn) {
-        const int j = n0 + wn * C::NT * 32 + nn * 32 + li;        // GEMM column
-        if (j >= a.Cout) continue;
-        int ch = j, sy = 0, sx = 0;
-        if (C::MODE == 1) { const int qd = j / Co1; ch = j - qd * Co1; sy = qd >> 1; sx = qd & 1; }
-        if (C::MODE == 2) { sy = py; sx = px; }
-        const float bv = a.bias ? a.bias[(C::MODE == 1) ? ch : a.coBase + j] : 0.f;
 #pragma unroll
-        for (int m = 0; m < C::MT; ++m) {
-            const int oy = oy0 + wm * C::MT + m;
-            if (oy >= a.Ho) continue;
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = n0 + wn * C::NT * 32 + nn * 32 + 8 * g + 4 * kh;   // first GEMM column of the quad
+            if (j0 >= a.Cout) continue;
+            int ch = j0, sy = 0, sx = 0;
+            if (C::MODE == 1) { const int qd = j0 / Co1; ch = j0 - qd * Co1; sy = qd >> 1; sx = qd & 1; }
+            if (C::MODE == 2) { sy = py; sx = px; }
+            const bool vec = a.vecOK && (j0 + 3 < a.Cout);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                const float* bp = a.bias + ((C::MODE == 1) ? ch : a.coBase + j0);
+                if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
+                else
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (ox >= a.Wo) continue;
+                    for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
+            }
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) {
+                const int oy = oy0 + wm * C::MT + m;
+                if (oy >= a.Ho || ox >= a.Wo) continue;
                 long long op;
                 if (C::MODE == 0) op = (long long)(n * OH + oy) * OW + ox;
                 else op = (long long)(n * OH + 2 * oy + sy) * OW + 2 * ox + sx;
-                float v = acc[m][nn][r] + bv;
-                v = lrelu(v, a.slopePre);
-                if (a.res) v += a.res[op * a.ldR + ch];
-                v = lrelu(v, a.slopePost);
-                if (a.mask) v *= (a.mask[op * a.ldM + ch] > 0.f) ? 1.f : a.slopeMask;
-                a.out[op * a.ldO + ch] = v;
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(acc[m][nn][4 * g + k] + bv[k], a.slopePre);
+                if (vec) {
+                    if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + ch);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                    if (a.mask) {
+                        const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + ch);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+                    }
+                    *reinterpret_cast<f32x4*>(a.out + op * a.ldO + ch) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (j0 + k >= a.Cout) break;
+                        float t = v[k];
+                        if (a.res) t += a.res[op * a.ldR + ch + k];
+                        t = lrelu(t, a.slopePost);
+                        if (a.mask) t *= (a.mask[op * a.ldM + ch + k] > 0.f) ? 1.f : a.slopeMask;
+                        a.out[op * a.ldO + ch + k] = t;
+                    }
+                }
             }
         }
     }
@@ -367,6 +398,10 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
     a.pad = d->pad; a.nchunks = 0; a.tilesX = a.tilesY = 0;
     a.slopePre = d->slope_pre; a.slopePost = d->slope_post; a.slopeMask = d->slope_mask;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    a.vecOK = al16(d->out) && d->ld_out % 4 == 0 && (!d->res || (al16(d->res) && d->ld_res % 4 == 0)) &&
+              (!d->mask || (al16(d->mask) && d->ld_mask % 4 == 0)) && (!d->bias || al16(d->bias)) &&
+              d->co_base % 4 == 0 && (d->mode != 1 || (d->cout / 4) % 4 == 0);
     const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
     switch (f) {

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
                     for (int sm = 0; sm < C::SM; ++sm)
 #pragma unroll
                         for (int sn = 0; sn < C::SN; ++sn)
-                            acc[tt][sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sm], bv[sn],
+                            acc[tt][sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[sn], av[sm],
                                                                                   acc[tt][sm][sn], 0, 0, 0);
                 }
             }
@@ -189,11 +189,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
         for (int sm = 0; sm < C::SM; ++sm)
 #pragma unroll
             for (int sn = 0; sn < C::SN; ++sn) {
-                const int ci = ci0 + wc * C::SN * 32 + sn * 32 + li;
+                // D[ci][co]: lane li = output channel, register quad q = 4 consecutive input channels
+                const int co = co0 + wr * C::SM * 32 + sm * 32 + li;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wr * C::SM * 32 + sm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    sl[(long long)co * a.CiP + ci] = acc[tt][sm][sn][r];
+                for (int q = 0; q < 4; ++q) {
+                    const int ci = ci0 + wc * C::SN * 32 + sn * 32 + 8 * q + 4 * kh;
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[tt][sm][sn][4 * q + k];
+                    *reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci) = v;
                 }
             }
     }

@@ -119,7 +119,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     taps = {0: kh * kw, 1: 1, 2: 16}[mode]
     flops = 2.0 * d.n * d.ho * d.wo * cout * (d.c_a + d.c_b) * taps
     name = lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode()
-    PROFILE.append(("conv_igemm_kernel<" + name + ">", flops, e0, e1))
+    PROFILE.append(("conv_igemm_kernel<" + name + ">", flops, e0, e1,
+                    (d.n, d.h, d.w, d.c_a, d.c_b, cout, int(res is not None), int(mask is not None), int(bias is not None))))
     return out
 
 
@@ -171,7 +172,8 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
     e1.record()
     flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
-    PROFILE.append((f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce", flops, e0, e1))
+    PROFILE.append((f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce", flops, e0, e1,
+                    (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None))))
 
 
 def nchw_to_nhwc(src, c_pad=None, out=None):

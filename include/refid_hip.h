@@ -80,6 +80,9 @@ typedef struct refid_conv_desc {
     int kh, kw, stride, pad;
     int mode;
     float slope_pre, slope_post, slope_mask;
+    int algo;                                   /* 0 = direct implicit GEMM; 1 = Winograd F(2x2,3x3)
+                                                   (3x3, stride 1, mode 0 only; w_packed must come
+                                                   from the REFID_ROLE_WINO_* packings)          */
 } refid_conv_desc;
 
 int refid_conv2d(const refid_conv_desc* d, void* stream);
@@ -130,7 +133,9 @@ int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream);
  *   role CONVT : ConvTranspose2d forward (mode 1): rows = (dy,dx,Co), k = Ci
  * ---------------------------------------------------------------------------------- */
 enum { REFID_ROLE_FWD = 0, REFID_ROLE_DGRAD = 1, REFID_ROLE_CONVT = 2, REFID_ROLE_CONVT_DGRAD = 3,
-       REFID_ROLE_DOWN_DGRAD = 4 };
+       REFID_ROLE_DOWN_DGRAD = 4,
+       /* Winograd-domain weights U = G g G^T, 16 "taps" (algo 1; kc = 8): */
+       REFID_ROLE_WINO_FWD = 5, REFID_ROLE_WINO_DGRAD = 6 };
 size_t refid_packed_weight_floats(int role, int o, int i, int kh, int kw, int kc, int bn);
 int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int i, int kh, int kw,
                             int kc, int bn, void* stream);

@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("mode", C.c_int),
         ("slope_pre", C.c_float), ("slope_post", C.c_float), ("slope_mask", C.c_float),
+        ("algo", C.c_int),
     ]
 
 

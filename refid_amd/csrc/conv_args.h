@@ -1,0 +1,21 @@
+// Kernel-side argument block shared by the conv tiles (direct implicit GEMM and Winograd).
+#pragma once
+
+struct ConvKArgs {
+    const float* inA; const float* inB;
+    int ldA, ldB, Ca, Ctot;
+    const float* w; const float* bias;
+    float* out; int ldO;
+    const float* res; int ldR;
+    const float* mask; int ldM;
+    int N, H, W, Ho, Wo;
+    int Cout, CoutPad, coBase;
+    int pad, nchunks, tilesX, tilesY;
+    float slopePre, slopePost, slopeMask;
+    long long wClsStride;
+    int vecOK;                 // out/res/mask/bias allow 16-byte channel-quad accesses
+};
+
+
+// conv_wino.hip
+int refid_launch_wino3x3(const ConvKArgs& a, hipStream_t st);

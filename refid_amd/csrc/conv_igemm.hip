@@ -31,23 +31,9 @@
 //     a lane owns 4 consecutive channels of one pixel per register quad: every epilogue tensor is
 //     touched with 16-byte accesses.
 #include "common.h"
+#include "conv_args.h"
 
 namespace {
-
-struct ConvKArgs {
-    const float* inA; const float* inB;
-    int ldA, ldB, Ca, Ctot;
-    const float* w; const float* bias;
-    float* out; int ldO;
-    const float* res; int ldR;
-    const float* mask; int ldM;
-    int N, H, W, Ho, Wo;
-    int Cout, CoutPad, coBase;
-    int pad, nchunks, tilesX, tilesY;
-    float slopePre, slopePost, slopeMask;
-    long long wClsStride;
-    int vecOK;                 // out/res/mask/bias allow 16-byte channel-quad accesses
-};
 
 template <int KH_, int KW_, int S_, int WM_, int WN_, int MT_, int NT_, int NSUB_, int MODE_>
 struct Cfg {
@@ -374,6 +360,8 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     REFID_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
+    REFID_CHECK(d->algo == 0 || (d->algo == 1 && f == F_3x3), "conv2d: algo %d needs a 3x3 stride-1 mode-0 conv",
+                d->algo);
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
     REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
                 "conv2d: rows [%d, %d) exceed the packed weight's %d rows", d->co_base, d->co_base + d->cout,
@@ -404,6 +392,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
               d->co_base % 4 == 0 && (d->mode != 1 || (d->cout / 4) % 4 == 0);
     const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
+    if (d->algo == 1) return refid_launch_wino3x3(a, st);
     switch (f) {
         case F_3x3:
             if (bn == 32) return launch<C3_32>(a, 1, st);

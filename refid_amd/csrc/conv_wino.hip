@@ -1,0 +1,274 @@
+// Fused Winograd F(2x2, 3x3) convolution tile on the gfx950 fp32 matrix cores.
+//
+// 88 % of the REFID hot path's FLOPs are 3x3 / stride-1 convolutions (SURVEY.md section 8a,
+// Appendix B).  gfx950 has no reduced-precision shortcut for fp32 (no xf32/TF32; the fp32 MFMA
+// runs at the vector rate), so the lever that remains is arithmetic: Winograd's minimal
+// filtering computes a 2x2 output tile from a 4x4 input tile with 16 multiplies per
+// (cin, cout) pair instead of 36 -- 2.25x fewer MFMAs at identical fp32 arithmetic class
+//   Y = A^T [ sum_c (G g G^T) (.) (B^T d B) ] A            (Lavin & Gray, 2016)
+// with the transforms' +-1 / 0.5 constants exact in fp32.
+//
+//   out = mask( post( pre(conv3x3(src) + bias) + res ) ),  src = in_a or [in_a | in_b]
+// (same contract, epilogue and two-source input as conv_igemm.hip; also serves the input
+// gradient on flipped/transposed weights.)
+//
+// Mapping (one workgroup = 256 threads = 4 waves, 2 workgroups per CU):
+//   * workgroup tile = 4x32 output pixels = 32 Winograd tiles (2 tile rows x 16 tile cols)
+//     x 64 output channels; K walks input channels in chunks of 8.
+//   * the 16 transform-domain GEMMs  M_xi[cout][tile] += U_xi[cout][c] * V_xi[c][tile]  run on
+//     v_mfma_f32_32x32x2_f32.  A wave owns 8 of the 16 xi (transform rows i = 2h, 2h+1) for 32
+//     output channels: 8 accumulators = 128 AGPRs, so two waves fit per SIMD.  4 waves =
+//     {xi half h} x {channel half nt}.
+//   * the raw 6x34-pixel input halo of the NEXT chunk is prefetched global->VGPR->LDS (double
+//     buffered, 6.5 KB each) while the current chunk's MFMAs run; between the two barriers of a
+//     chunk wave w computes transform row i = w of B^T d B for all 32 tiles x 2 channel quads
+//     from LDS (8 x ds_read_b128, 12 float4 adds) and writes the V planes [xi][quad][tile].
+//   * transformed weights U = G g G^T are produced once per step by the pack kernel in the
+//     [chunk][xi][cout][8] layout and staged per chunk as [xi][quad][cout].
+//   * output transform: each lane reduces its 8 accumulators along j in registers, the two xi
+//     halves swap one half of the row-partials through LDS (32 KB, after the K loop), and every
+//     wave finishes one output row parity with the fused 16-byte epilogue.
+#include "common.h"
+#include "conv_args.h"
+
+namespace {
+
+constexpr int TW = 32, TH = 4;          // output pixels per workgroup
+constexpr int NT = 32;                  // Winograd tiles per workgroup (2 x 16)
+constexpr int BN = 64;                  // output channels per workgroup
+constexpr int KC = 8;                   // input channels per chunk
+constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;   // raw input halo: 6 x 34 pixels
+constexpr int V_F4 = 16 * 2 * NT;       // float4 slots: [xi][quad][tile]
+constexpr int U_F4 = 16 * 2 * BN;       // [xi][quad][cout]
+constexpr int R_F4 = 2 * HP;            // one raw halo buffer: [quad][pixel]
+constexpr int U_ITEMS = U_F4 / 256;     // 8 float4 per thread per chunk
+constexpr int R_ITEMS = (R_F4 + 255) / 256;
+constexpr int LDS_BYTES = (V_F4 + U_F4 + 2 * R_F4) * 16;      // 61 KB (the exchange re-uses 32 KB)
+
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* sV = reinterpret_cast<f32x4*>(smem);
+    f32x4* sU = sV + V_F4;
+    f32x4* sR = sU + U_F4;               // two raw halo buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int h = wave & 1, nt = wave >> 1;
+
+    int bt = blockIdx.x;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int n = bt / a.tilesY;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int n0 = blockIdx.y * BN;
+
+    // ---- raw halo loader: (quad q, halo pixel) items, quad fastest -------------------------------
+    const int q = tid & 1;
+    int rpix[R_ITEMS];
+#pragma unroll
+    for (int it = 0; it < R_ITEMS; ++it) {
+        const int hp = (tid >> 1) + it * 128;
+        const int iy = oy0 - a.pad + hp / HWD, ix = ox0 - a.pad + hp % HWD;
+        const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        rpix[it] = ok ? ((n * a.H + iy) * a.W + ix) : -1;
+    }
+    // ---- input-transform item of this thread: (quad q, tile tt, transform row ti = wave) ----------
+    const int tt = (tid >> 1) & 31;
+    const int ti = wave;
+    // rows of the 4x4 patch with non-zero B^T[ti][.]:  i=0: d0-d2  i=1: d1+d2  i=2: d2-d1  i=3: d1-d3
+    const int ra = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
+    const int rb = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
+    const float sgn = (ti == 1) ? 1.f : -1.f;
+    const int hpa = (2 * (tt >> 4) + ra) * HWD + 2 * (tt & 15);     // halo index of patch (ra, col 0)
+    const int hpb = (2 * (tt >> 4) + rb) * HWD + 2 * (tt & 15);
+
+    f32x4 rr[R_ITEMS], ru[U_ITEMS];
+
+    auto load_raw = [&](int ch) {
+        const int c = ch * KC + q * 4;
+        const bool fromA = c < a.Ca;
+        const float* src = fromA ? a.inA : a.inB;
+        const int ld = fromA ? a.ldA : a.ldB;
+        const int cc = fromA ? c : c - a.Ca;
+        const bool cok = c < a.Ctot;
+#pragma unroll
+        for (int it = 0; it < R_ITEMS; ++it) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (cok && rpix[it] >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)rpix[it] * ld + cc);
+            rr[it] = v;
+        }
+    };
+    auto store_raw = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < R_ITEMS; ++it) {
+            const int hp = (tid >> 1) + it * 128;
+            if (hp < HP) sR[buf * R_F4 + q * HP + hp] = rr[it];
+        }
+    };
+    auto load_u = [&](int ch) {
+        const float* wc = a.w + (long long)ch * (16 * a.CoutPad * KC);
+#pragma unroll
+        for (int it = 0; it < U_ITEMS; ++it) {
+            const int e = tid + it * 256;           // (xi, co, quad), quad fastest
+            const int uq = e & 1, co = (e >> 1) & 63, xi = e >> 7;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a.coBase + n0 + co < a.CoutPad)
+                v = *reinterpret_cast<const f32x4*>(wc + ((long long)(xi * a.CoutPad + a.coBase + n0 + co)) * KC + uq * 4);
+            ru[it] = v;
+        }
+    };
+    auto store_u = [&]() {
+#pragma unroll
+        for (int it = 0; it < U_ITEMS; ++it) {
+            const int e = tid + it * 256;
+            const int uq = e & 1, co = (e >> 1) & 63, xi = e >> 7;
+            sU[(xi * 2 + uq) * BN + co] = ru[it];
+        }
+    };
+    auto transform = [&](int buf) {
+        // V[ti][j] of B^T d B:  T_b = d[ra][b] + sgn*d[rb][b];  V_j = {T0-T2, T1+T2, T2-T1, T1-T3}
+        const f32x4* r = sR + buf * R_F4 + q * HP;
+        f32x4 t[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) t[b] = r[hpa + b] + r[hpb + b] * sgn;
+        f32x4* v = sV + (ti * 4 * 2 + q) * NT + tt;               // xi = ti*4 + j  ->  + j*2*NT
+        v[0 * 2 * NT] = t[0] - t[2];
+        v[1 * 2 * NT] = t[1] + t[2];
+        v[2 * 2 * NT] = t[2] - t[1];
+        v[3 * 2 * NT] = t[1] - t[3];
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    // prologue: raw(0) -> LDS, U(0) -> LDS, transform(0); raw(1) in flight
+    load_raw(0);
+    load_u(0);
+    store_raw(0);
+    store_u();
+    if (a.nchunks > 1) load_raw(1);
+    __syncthreads();
+    transform(0);
+    __syncthreads();
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const bool more = ch + 1 < a.nchunks;
+        if (more) {
+            store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
+            if (ch + 2 < a.nchunks) load_raw(ch + 2);
+            load_u(ch + 1);
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            const int xi = h * 8 + x;
+            const f32x4 uf = sU[(xi * 2 + kh) * BN + nt * 32 + li];
+            const f32x4 vf = sV[(xi * 2 + kh) * NT + li];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[kk], vf[kk], acc[x], 0, 0, 0);
+        }
+        __syncthreads();                             // V(ch), U(ch) consumed; raw(ch+1) visible
+        if (more) {
+            transform((ch + 1) & 1);
+            store_u();
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform --------------------------------------------------------------------------
+    // lane: tile li, channels (r&3)+8(r>>2)+4kh of the wave's 32;  acc[i'*4+j] = M[2h+i'][j]
+    // R[i'][b] = sum_j M[i'][j] A^T[b][j] :  b=0: M0+M1+M2   b=1: M1-M2-M3
+    f32x16 keep[2];
+    float* xch = reinterpret_cast<float*>(smem);            // [wave][b][reg][lane], 8 KB per wave
+    const float ks = h ? -1.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float r00 = acc[0][r] + acc[1][r] + acc[2][r], r01 = acc[1][r] - acc[2][r] - acc[3][r];
+        const float r10 = acc[4][r] + acc[5][r] + acc[6][r], r11 = acc[5][r] - acc[6][r] - acc[7][r];
+        // Y[a][b] = sum_i A^T[a][i] R[i][b]:  a=0: R0+R1+R2   a=1: R1-R2-R3
+        //   h=0 (rows 0,1): own parity a=0 gets R0+R1, partner's a=1 gets R1
+        //   h=1 (rows 2,3): own parity a=1 gets -R2-R3, partner's a=0 gets R2
+        keep[0][r] = ks * (r00 + r10);
+        keep[1][r] = ks * (r01 + r11);
+        xch[((wave * 2 + 0) * 16 + r) * 64 + lane] = h ? r00 : r10;
+        xch[((wave * 2 + 1) * 16 + r) * 64 + lane] = h ? r01 : r11;
+    }
+    __syncthreads();
+    const int partner = wave ^ 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[b][r] += xch[((partner * 2 + b) * 16 + r) * 64 + lane];
+
+    // ---- fused epilogue: this wave owns output row parity a = h, columns b = 0,1 ------------------
+    const int oy = oy0 + 2 * (li >> 4) + h;
+    if (oy >= a.Ho) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int j0 = n0 + nt * 32 + 8 * g + 4 * kh;
+        if (j0 >= a.Cout) continue;
+        const bool vec = a.vecOK && (j0 + 3 < a.Cout);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const float* bp = a.bias + a.coBase + j0;
+            if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
+            else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ox = ox0 + 2 * (li & 15) + b;
+            if (ox >= a.Wo) continue;
+            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(keep[b][4 * g + k] + bv[k], a.slopePre);
+            if (vec) {
+                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                if (a.mask) {
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+                }
+                *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 + k >= a.Cout) break;
+                    float t = v[k];
+                    if (a.res) t += a.res[op * a.ldR + j0 + k];
+                    t = lrelu(t, a.slopePost);
+                    if (a.mask) t *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                    a.out[op * a.ldO + j0 + k] = t;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { refid_set_error("conv_wino: LDS attribute: %s", hipGetErrorString(e)); return 2; }
+        attr_set = true;
+    }
+    ConvKArgs a = ka;
+    a.tilesX = cdiv(a.Wo, TW);
+    a.tilesY = cdiv(a.Ho, TH);
+    a.nchunks = cdiv(a.Ctot, KC);
+    dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, BN));
+    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), LDS_BYTES, st, a);
+    REFID_LAUNCH_CHECK("conv_wino");
+    return 0;
+}

@@ -111,6 +111,22 @@ __device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap,
         }
         case REFID_ROLE_CONVT_DGRAD:    // rows = ci, k = co, tap = dy*2+dx
             return p.w[((long long)row * p.O + k) * 4 + tap];
+        case REFID_ROLE_WINO_FWD:       // U[xi=(i,j)] = sum_ab G[i][a] G[j][b] g[a][b]
+        case REFID_ROLE_WINO_DGRAD: {
+            const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+            const int i = tap >> 2, j = tap & 3;
+            const bool fwd = p.role == REFID_ROLE_WINO_FWD;
+            const float* g = fwd ? p.w + ((long long)row * p.I + k) * 9 : p.w + ((long long)k * p.I + row) * 9;
+            float u = 0.f;
+#pragma unroll
+            for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 3; ++bb) {
+                    const float gv = fwd ? g[aa * 3 + bb] : g[(2 - aa) * 3 + (2 - bb)];   // dgrad: flipped taps
+                    u += G[i][aa] * G[j][bb] * gv;
+                }
+            return u * (p.oscale ? p.oscale[fwd ? row : k] : 1.f);
+        }
         case REFID_ROLE_DOWN_DGRAD: {   // W (O,I,4,4); rows = i, k = o; class (py,px), tap (ta,tb)
             const int py = cls >> 1, px = cls & 1, ta = tap >> 1, tb = tap & 1;
             const int ky = (ta == 0) ? (py ? 2 : 1) : (py ? 0 : 3);
@@ -146,6 +162,8 @@ int pack_geometry(int role, int o, int i, int kh, int kw, int kc, int bn, PackAr
         case REFID_ROLE_CONVT: p->rows = 4 * o; p->K = i; p->ntaps = 1; break;
         case REFID_ROLE_CONVT_DGRAD: p->rows = i; p->K = o; p->ntaps = 4; break;
         case REFID_ROLE_DOWN_DGRAD: p->rows = i; p->K = o; p->ntaps = 4; p->ncls = 4; break;
+        case REFID_ROLE_WINO_FWD: p->rows = o; p->K = i; p->ntaps = 16; break;
+        case REFID_ROLE_WINO_DGRAD: p->rows = i; p->K = o; p->ntaps = 16; break;
         default: return 1;
     }
     p->rowsPad = round_up(p->rows, bn);
@@ -176,7 +194,8 @@ extern "C" int refid_pack_conv_weights(const float* w, float* packed, int role, 
 
 extern "C" int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* packed, int role, int o,
                                               int i, int kh, int kw, int kc, int bn, void* stream) {
-    REFID_CHECK(role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD, "pack_scaled: only FWD/DGRAD roles take a scale");
+    REFID_CHECK(role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD || role == REFID_ROLE_WINO_FWD ||
+                    role == REFID_ROLE_WINO_DGRAD, "pack_scaled: only FWD/DGRAD roles take a scale");
     return pack_impl(w, oscale, packed, role, o, i, kh, kw, kc, bn, stream);
 }
 
@@ -189,6 +208,8 @@ static int pack_impl(const float* w, const float* oscale, float* packed, int rol
     REFID_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),
                 "pack: convT roles need a 2x2 kernel");
     REFID_CHECK(role != REFID_ROLE_DOWN_DGRAD || (kh == 4 && kw == 4), "pack: down-dgrad needs a 4x4 kernel");
+    REFID_CHECK((role != REFID_ROLE_WINO_FWD && role != REFID_ROLE_WINO_DGRAD) || (kh == 3 && kw == 3 && kc == 8),
+                "pack: Winograd roles need a 3x3 kernel and kc = 8");
     p.w = w; p.dst = packed;
     const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);

@@ -24,6 +24,7 @@ Design notes (MI355X-first):
   * dead work is skipped: ``encoders_backward[2].down`` (its output is discarded by the
     reference, arch :179) and the T copies of backward states.
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -130,6 +131,12 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+# 3x3 stride-1 convolutions (88 % of the FLOPs) run on the fused Winograd F(2x2,3x3) tile
+# (csrc/conv_wino.hip) when they are wide enough for its 64-channel tile; REFID_WINOGRAD=0
+# forces the direct implicit-GEMM tile everywhere.
+USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
+
+
 class ConvOp:
     """One convolution of the network: geometry + packed weights + the three kernels."""
 
@@ -172,6 +179,13 @@ class ConvOp:
         kh, kw, st, md = self.f_geo
         self.f_kc = ops.conv_kc(kh, kw, st, md)
         self.f_bn = ops.conv_bn(kh, kw, st, md, self.f_rows)
+        self.f_algo = self.d_algo = 0
+        if USE_WINOGRAD and kind == "conv" and k == 3:
+            if self.co > 32:
+                self.f_algo, self.f_role, self.f_kc, self.f_bn = 1, ops.ROLE_WINO_FWD, 8, 64
+            d_cnt = self.co if self.ci == 2 * self.co else self.ci     # rows per dgrad issue
+            if d_cnt > 32:
+                self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
         self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
         dev = self.w.device
         self.wp = torch.empty(ops.packed_weight_floats(self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci),
@@ -185,6 +199,8 @@ class ConvOp:
             self.d_bn = ops.conv_bn(kh, kw, st, md, self.d_rows if self.d_rows <= 128 else 128)
             if kind == "conv" and self.ci == 2 * self.co and self.k in (1, 3):
                 self.d_bn = ops.conv_bn(kh, kw, st, md, self.co)     # issued as two halves of co rows
+            if self.d_algo == 1:
+                self.d_kc, self.d_bn = 8, 64
             self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
             self.wd = torch.empty(ops.packed_weight_floats(self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci),
                                   dtype=torch.float32, device=dev)
@@ -218,7 +234,8 @@ class ConvOp:
                 out = out[..., :oc]
         kh, kw, st, md = self.f_geo
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
-                   cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post)
+                   cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post,
+                   algo=self.f_algo)
         return out
 
     # ---- input gradient ----------------------------------------------------------------------
@@ -240,7 +257,7 @@ class ConvOp:
         if self.kind == "conv":
             pad = self.k - 1 - self.pad
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
-                   co_base=base, res=res, mask=mask, slope_mask=slope_mask)
+                   co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo)
         return out
 
     # ---- weight / bias gradient ----------------------------------------------------------------

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, WgradDesc, check, lib
 
-ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD = range(5)
+ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_FWD, ROLE_WINO_DGRAD = range(7)
 
 
 # bench.py's roofline leg: when PROFILE is a list, conv2d()/conv2d_wgrad() bracket each launch with
@@ -77,7 +77,7 @@ def pack_conv_weights(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None):
 
 
 def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_pad, co_base=0,
-           in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0):
+           in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0):
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc."""
     d = ConvDesc()
     d.in_a, d.ld_a = _nhwc(in_a, "in_a")
@@ -109,6 +109,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.cout, d.cout_pad, d.co_base = cout, cout_pad, co_base
     d.kh, d.kw, d.stride, d.pad, d.mode = kh, kw, stride, pad, mode
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
+    d.algo = algo
     if PROFILE is None:
         check(lib().refid_conv2d(C.byref(d), _stream()), "refid_conv2d")
         return out
@@ -118,8 +119,10 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     e1.record()
     taps = {0: kh * kw, 1: 1, 2: 16}[mode]
     flops = 2.0 * d.n * d.ho * d.wo * cout * (d.c_a + d.c_b) * taps
-    name = lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode()
-    PROFILE.append(("conv_igemm_kernel<" + name + ">", flops, e0, e1,
+    name = "conv_igemm_kernel<" + lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode() + ">"
+    if algo == 1:
+        name = "conv_wino_kernel"
+    PROFILE.append((name, flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, cout, int(res is not None), int(mask is not None), int(bias is not None))))
     return out
 

@@ -263,3 +263,73 @@ def test_errors_are_loud():
         ops.conv2d(x, x, torch.zeros(1, 8, 8, 64, device="cuda"), kh=7, kw=7, cout=64, cout_pad=64)
     with pytest.raises(RefidHipError):
         ops.conv2d(x.cpu(), x, x, kh=3, kw=3, pad=1, cout=64, cout_pad=64)
+
+
+# ---------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) tile (algo=1): same contract as the direct tile
+# ---------------------------------------------------------------------------------------------
+def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_post=1.0, mask=False):
+    ops = _ops()
+    Ci = Ca + Cb
+    xa = rnd(N, Ca, H, W, seed=1)
+    xb = rnd(N, Cb, H, W, seed=2) if Cb else None
+    w = rnd(Co, Ci, 3, 3, seed=3, scale=1.0 / np.sqrt(Ci * 9))
+    b = rnd(Co, seed=4) if bias else None
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    ref = lrelu(F.conv2d(x, w, b, 1, 1), slope_pre)
+    r = rnd(N, Co, H, W, seed=5) if res else None
+    if res:
+        ref = ref + r
+    ref = lrelu(ref, slope_post)
+    m = rnd(N, Co, H, W, seed=6) if mask else None
+    if mask:
+        ref = ref * torch.where(m > 0, 1.0, 0.3)
+    wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+    copad = -(-Co // 64) * 64
+    Cop = -(-Co // 4) * 4
+    outbuf = torch.full((N, H, W, Cop), 7.0, device="cuda")
+    out = outbuf[..., :Co]
+    ops.conv2d(nhwc(xa), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=copad, algo=1,
+               in_b=nhwc(xb) if Cb else None, bias=b.float().cuda() if bias else None,
+               res=nhwc(r) if res else None, mask=nhwc(m) if mask else None,
+               slope_pre=slope_pre, slope_post=slope_post, slope_mask=0.3)
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+    if Cop != Co:
+        assert float(outbuf[..., Co:].min()) == 7.0
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 16, 32, 32, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 128, 128, 128), (1, 12, 20, 64, 0, 256),
+    (2, 16, 16, 32, 32, 32), (1, 5, 3, 64, 0, 64), (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 0, 3),
+])
+def test_winograd_forward_geometries(cfg):
+    run_wino(*cfg)
+
+
+def test_winograd_fused_epilogues():
+    run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04)
+    run_wino(1, 16, 32, 64, 0, 64, res=True)
+    run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0)
+    run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1)
+    run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True)
+
+
+@pytest.mark.parametrize("cfg", [(1, 16, 32, 32, 64), (1, 9, 24, 128, 64), (1, 8, 16, 256, 128)])
+def test_winograd_dgrad(cfg):
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
+    g = rnd(N, Co, H, W, seed=3)
+    F.conv2d(x, w, None, 1, 1).backward(g)
+    wd = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_DGRAD, 64, 8, 3, 3, Co, Ci)
+    rp = -(-Ci // 64) * 64
+    gd = nhwc(g)
+    out = torch.empty(N, H, W, Ci, device="cuda")
+    ops.conv2d(gd, wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=rp, algo=1)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+    if Ci >= 64:        # row-range issue (two-source convs): second half of the rows
+        half = Ci // 2
+        o2 = torch.empty(N, H, W, half, device="cuda")
+        ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=rp, co_base=half, algo=1)
+        np.testing.assert_allclose(nchw(o2).numpy(), x.grad[:, half:].numpy(), rtol=RTOL, atol=ATOL)

@@ -119,6 +119,7 @@ typedef struct refid_wgrad_desc {
     int i_base, i_total;                        /* dw second-dim offset / full size (slices) */
     int o_real;                                 /* rows of dw/db actually written (<= c_o); the
                                                    rest of g's channels is padding        */
+    int algo;                                   /* 0 = direct; 1 = Winograd F(2x2,3x3) (3x3 stride 1) */
 } refid_wgrad_desc;
 
 size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d);

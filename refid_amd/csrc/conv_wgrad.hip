@@ -329,8 +329,13 @@ int launch_w(const WgKArgs& a, const Geo& g, hipStream_t st) {
 
 }  // namespace
 
+// wgrad_wino.hip
+size_t refid_wgrad_wino_workspace_bytes(const refid_wgrad_desc* d);
+int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st);
+
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
+    if (d->algo == 1) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->c_a + d->c_b);
     if (!p.ok) return 0;
     const Geo g = geo_of(d, p);
@@ -353,6 +358,9 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
                 d->wo, eh, ew);
     REFID_CHECK(d->i_total > d->i_base && d->i_base >= 0 && d->o_real > 0 && d->o_real <= d->c_o,
                 "wgrad: i_base/i_total/o_real inconsistent");
+    REFID_CHECK(d->algo == 0 || (d->algo == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1),
+                "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
+    if (d->algo == 1) return refid_wgrad_wino_launch(d, st);
     const Geo g = geo_of(d, p);
     WgKArgs a;
     a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;

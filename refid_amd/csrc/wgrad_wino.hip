@@ -1,0 +1,305 @@
+// Winograd F(2x2,3x3) weight gradient of the 3x3 / stride-1 convolutions on the fp32 matrix cores.
+//
+//   dg[o][i] = G^T [ sum_{tiles} (A dY A^T)_xi[o] * (B^T d B)_xi[i] ] G          (xi = 0..15)
+//
+// i.e. 16 transform-domain GEMMs  dU_xi[o][i] += Z_xi[tile][o] * V_xi[tile][i]  over 2x2-pixel
+// tiles (K = tiles) instead of 9 tap GEMMs over pixels (K = pixels): 16 MFMAs per
+// (32o x 32i x 2 tiles) instead of 36.  The inverse transform G^T dU G (16 -> 9 values) is applied
+// once per call by the slab reduction.
+//
+// Mapping: workgroup = 256 threads = 4 waves; wave w owns transform row i = w (xi = 4w..4w+3) for
+// the whole 64(o) x 32(i) channel tile: 8 accumulators = 128 AGPRs.  Because a wave only needs ITS
+// row of Z and V, both transforms are done on the fly in registers straight from the raw NHWC LDS
+// tiles (gradient tile 4x32 pixels x 64 o, input halo 6x34 pixels x 32 i; conflict-free
+// ds_read_b32 of 32 consecutive channels) -- no transformed copy is ever stored.  Split-K over pixel
+// tiles into private slabs [split][xi][o][i]; bias gradient rides along as in conv_wgrad.hip.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 4, TW = 32;                 // output pixels per K tile (2 x 16 Winograd tiles)
+constexpr int COT = 64, CIT = 32;
+constexpr int PX = TH * TW;
+constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;
+constexpr int G4 = COT / 4, X4 = CIT / 4;
+constexpr int G_TOTAL = PX * G4, X_TOTAL = HP * X4;
+constexpr int G_ITEMS = G_TOTAL / 256, X_ITEMS = (X_TOTAL + 255) / 256;
+constexpr int LDS_BYTES = (G_TOTAL + X_TOTAL) * 16 + COT * 4;
+
+struct WwArgs {
+    const float* g; int ldG, Co;
+    const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
+    float* slabs; float* bslabs;
+    int N, H, W, Ho, Wo, pad;
+    int tilesX, tilesY, ntiles, nsplit;
+    int CoP, CiP;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* sG4 = reinterpret_cast<f32x4*>(smem);
+    f32x4* sX4 = sG4 + G_TOTAL;
+    float* sBias = reinterpret_cast<float*>(sX4 + X_TOTAL);
+    const float* sG = reinterpret_cast<const float*>(sG4);
+    const float* sX = reinterpret_cast<const float*>(sX4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int ti = wave;                                   // transform row owned by this wave
+    const int co0 = blockIdx.z * COT, ci0 = blockIdx.y * CIT;
+    const int split = blockIdx.x;
+
+    // B^T rows: i=0: d0-d2  i=1: d1+d2  i=2: d2-d1  i=3: d1-d3 ;  A rows: X_b = ca*dY0b + cb*dY1b
+    const int ra = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
+    const int rb = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
+    const float sgn = (ti == 1) ? 1.f : -1.f;
+    const float ca = (ti == 3) ? 0.f : 1.f;
+    const float cb = (ti == 0) ? 0.f : ((ti == 1) ? 1.f : -1.f);
+
+    const int gq = tid % G4, xq = tid % X4;
+    const int gco = co0 + gq * 4;
+    const bool gcok = gco < a.Co;
+    const int xc = ci0 + xq * 4;
+    const bool xFromA = xc < a.Ca;
+    const bool xcok = xc < a.Ctot;
+    const float* xsrc = xFromA ? a.inA : a.inB;
+    const int xld = xFromA ? a.ldA : a.ldB;
+    const int xcc = xFromA ? xc : xc - a.Ca;
+
+    f32x16 acc[4][2];                                      // [j][o sub-tile]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][sm][r] = 0.f;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 rg[G_ITEMS], rx[X_ITEMS];
+
+    auto load_tile = [&](int pt) {
+        int t = pt;
+        const int tx = t % a.tilesX; t /= a.tilesX;
+        const int ty = t % a.tilesY;
+        const int n = t / a.tilesY;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+#pragma unroll
+        for (int it = 0; it < G_ITEMS; ++it) {
+            const int p = tid / G4 + it * (256 / G4);
+            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gcok && oy < a.Ho && ox < a.Wo)
+                v = *reinterpret_cast<const f32x4*>(a.g + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
+            rg[it] = v;
+            bsum += v;
+        }
+#pragma unroll
+        for (int it = 0; it < X_ITEMS; ++it) {
+            const int hp = tid / X4 + it * (256 / X4);
+            const int iy = iy0 + hp / HWD, ix = ix0 + hp % HWD;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (xcok && hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const f32x4*>(xsrc + ((long long)(n * a.H + iy) * a.W + ix) * xld + xcc);
+            rx[it] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int it = 0; it < G_ITEMS; ++it) {
+            const int p = tid / G4 + it * (256 / G4);
+            sG4[p * G4 + gq] = rg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < X_ITEMS; ++it) {
+            const int hp = tid / X4 + it * (256 / X4);
+            if (hp < HP) sX4[hp * X4 + xq] = rx[it];
+        }
+    };
+
+    int pt = split;
+    if (pt < a.ntiles) {
+        load_tile(pt);
+        store_tile();
+    }
+    __syncthreads();
+
+    for (; pt < a.ntiles; pt += a.nsplit) {
+        const bool more = pt + a.nsplit < a.ntiles;
+        if (more) load_tile(pt + a.nsplit);
+
+#pragma unroll
+        for (int tr = 0; tr < TH / 2; ++tr) {
+#pragma unroll 2
+            for (int qk = 0; qk < TW / 4; ++qk) {
+                const int tc = 2 * qk + kh;                // this half-wave's tile column (K index)
+                // ---- V row ti for input channel li:  T_b = d[ra][b] + sgn d[rb][b] -------------------
+                const float* xa = sX + ((2 * tr + ra) * HWD + 2 * tc) * CIT + li;
+                const float* xb = sX + ((2 * tr + rb) * HWD + 2 * tc) * CIT + li;
+                const float t0 = xa[0] + sgn * xb[0], t1 = xa[CIT] + sgn * xb[CIT];
+                const float t2 = xa[2 * CIT] + sgn * xb[2 * CIT], t3 = xa[3 * CIT] + sgn * xb[3 * CIT];
+                float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+                // ---- Z row ti for output channels li, li+32:  X_b = ca dY[0][b] + cb dY[1][b] ----------
+                float z[2][4];
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm) {
+                    const float* g0 = sG + ((2 * tr) * TW + 2 * tc) * COT + sm * 32 + li;
+                    const float x0 = ca * g0[0] + cb * g0[TW * COT];
+                    const float x1 = ca * g0[COT] + cb * g0[TW * COT + COT];
+                    z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = -x1;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm)
+                        acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- slab: [split][xi][co][ci]; D[ci][co]: lane li = output channel, register quad = 4 ci ------
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float* sl = a.slabs + ((long long)(split * 16 + ti * 4 + j) * a.CoP) * a.CiP;
+#pragma unroll
+        for (int sm = 0; sm < 2; ++sm) {
+            const int co = co0 + sm * 32 + li;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int ci = ci0 + 8 * qd + 4 * kh;
+                f32x4 vv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) vv[k] = acc[j][sm][4 * qd + k];
+                *reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci) = vv;
+            }
+        }
+    }
+    if (a.bslabs != nullptr && blockIdx.y == 0) {
+        if (tid < COT) sBias[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
+        __syncthreads();
+        if (tid < COT) a.bslabs[(long long)split * a.CoP + co0 + tid] = sBias[tid];
+    }
+}
+
+struct WrArgs {
+    const float* slabs; const float* bslabs; float* dw; float* db;
+    int nsplit, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
+};
+
+// slab reduction + inverse weight transform: dg = G^T dU G, accumulated into OIHW (9 contiguous floats)
+__global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WrArgs a) {
+    const long long plane = (long long)a.CoP * a.CiP;
+    const long long slabStride = 16 * plane;
+    const int s0 = blockIdx.y * a.perGroup;
+    const int s1 = min(a.nsplit, s0 + a.perGroup);
+    const long long e = blockIdx.x * 256ll + threadIdx.x;          // (co, ci), ci fastest
+    if (e < (long long)a.Co * a.Ci) {
+        const int ci = (int)(e % a.Ci), co = (int)(e / a.Ci);
+        const float* p = a.slabs + (long long)co * a.CiP + ci;
+        float u[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) u[x] = 0.f;
+        for (int k = s0; k < s1; ++k) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) u[x] += p[k * slabStride + x * plane];
+        }
+        // t[a][j] = sum_i G[i][a] u[i][j] ;  dg[a][b] = sum_j t[a][j] G[j][b]
+        float dg[9];
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa) {
+            float t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float m = 0.5f * (u[4 + j] + u[8 + j]), d = 0.5f * (u[4 + j] - u[8 + j]);
+                t[j] = (aa == 0) ? u[j] + m : ((aa == 1) ? d : m + u[12 + j]);
+            }
+            const float m = 0.5f * (t[1] + t[2]), d = 0.5f * (t[1] - t[2]);
+            dg[aa * 3 + 0] = t[0] + m;
+            dg[aa * 3 + 1] = d;
+            dg[aa * 3 + 2] = m + t[3];
+        }
+        float* dst = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (gridDim.y > 1) atomicAdd(dst + k, dg[k]);
+            else dst[k] += dg[k];
+        }
+    }
+    if (a.db != nullptr && blockIdx.x == 0) {
+        for (int co = threadIdx.x; co < a.Co; co += 256) {
+            float s = 0.f;
+            for (int k = s0; k < s1; ++k) s += a.bslabs[(long long)k * a.CoP + co];
+            if (gridDim.y > 1) atomicAdd(a.db + co, s);
+            else a.db[co] += s;
+        }
+    }
+}
+
+struct Geo { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
+
+Geo geo_of(const refid_wgrad_desc* d) {
+    Geo g;
+    g.ncoT = cdiv(d->c_o, COT);
+    g.nciT = cdiv(d->c_a + d->c_b, CIT);
+    g.tilesX = cdiv(d->wo, TW);
+    g.tilesY = cdiv(d->ho, TH);
+    g.ntiles = g.tilesX * g.tilesY * d->n;
+    int want = cdiv(512, g.ncoT * g.nciT);
+    if (want < 1) want = 1;
+    if (want > g.ntiles) want = g.ntiles;
+    g.nsplit = want;
+    g.CoP = g.ncoT * COT;
+    g.CiP = g.nciT * CIT;
+    return g;
+}
+
+}  // namespace
+
+size_t refid_wgrad_wino_workspace_bytes(const refid_wgrad_desc* d) {
+    const Geo g = geo_of(d);
+    return ((size_t)g.nsplit * 16 * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP) * sizeof(float);
+}
+
+int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { refid_set_error("wgrad_wino: LDS attribute: %s", hipGetErrorString(e)); return 2; }
+        attr_set = true;
+    }
+    const Geo g = geo_of(d);
+    WwArgs a;
+    a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;
+    a.inA = d->in_a; a.inB = d->in_b; a.ldA = d->ld_a; a.ldB = d->ld_b;
+    a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
+    a.slabs = d->slabs;
+    a.bslabs = d->db ? d->slabs + (size_t)g.nsplit * 16 * g.CoP * g.CiP : nullptr;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pad = d->pad;
+    a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
+    a.CoP = g.CoP; a.CiP = g.CiP;
+    hipLaunchKernelGGL(wgrad_wino_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS_BYTES, st, a);
+    REFID_LAUNCH_CHECK("wgrad_wino");
+    WrArgs r;
+    r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
+    r.nsplit = g.nsplit; r.Co = d->o_real;
+    r.Ci = a.Ctot < d->i_total - d->i_base ? a.Ctot : d->i_total - d->i_base;
+    r.CoP = g.CoP; r.CiP = g.CiP; r.iBase = d->i_base; r.iTotal = d->i_total;
+    const long long total = (long long)r.Co * r.Ci;
+    int groups = (int)(65536 / (total > 0 ? total : 1));
+    if (groups > 16) groups = 16;
+    if (groups > g.nsplit) groups = g.nsplit;
+    if (groups < 1) groups = 1;
+    r.perGroup = cdiv(g.nsplit, groups);
+    groups = cdiv(g.nsplit, r.perGroup);
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((int)((total + 255) / 256), groups), dim3(256), 0, st, r);
+    REFID_LAUNCH_CHECK("wgrad_wino_reduce");
+    return 0;
+}

@@ -269,8 +269,9 @@ class ConvOp:
             if self.has_bias:
                 ops.colsum(g, self.gb)
             return
+        algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci >= 32) else 0
         ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                         db=self.gb, i_total=self.ci)
+                         db=self.gb, i_total=self.ci, algo=algo)
 
 
 class _Trunk:

@@ -140,7 +140,7 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_base=0, i_total=None):
+def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_base=0, i_total=None, algo=0):
     """dw (+)= wgrad, db (+)= sum g; dw in the reference layout (c_o, i_total, kh, kw)."""
     d = WgradDesc()
     d.g, d.ld_g = _nhwc(g, "g")
@@ -156,6 +156,7 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     d.i_base = i_base
     d.i_total = i_total if i_total is not None else dw.shape[1]
     d.o_real = dw.shape[0]
+    d.algo = algo
     if not dw.is_contiguous() or dw.dim() != 4 or dw.shape[1] != d.i_total or dw.shape[2:] != (kh, kw) \
             or d.o_real > d.c_o:
         raise _lib.RefidHipError(f"wgrad: dw shape {tuple(dw.shape)} does not match g/in channels "
@@ -175,7 +176,7 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
     e1.record()
     flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
-    PROFILE.append((f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce", flops, e0, e1,
+    PROFILE.append((("wgrad_wino_kernel+reduce" if algo == 1 else f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce"), flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None))))
 
 

@@ -333,3 +333,32 @@ def test_winograd_dgrad(cfg):
         o2 = torch.empty(N, H, W, half, device="cuda")
         ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=rp, co_base=half, algo=1)
         np.testing.assert_allclose(nchw(o2).numpy(), x.grad[:, half:].numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 256, 256, 256), (1, 5, 3, 64, 0, 128),
+    (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 32, 32), (1, 8, 32, 32, 0, 3),
+])
+def test_winograd_wgrad(cfg):
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    x = rnd(N, Ca + Cb, H, W, seed=1)
+    w = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, 1)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    dw = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    gd = nhwc(g)
+    if Co % 4:
+        buf = torch.zeros(*gd.shape[:3], -(-Co // 4) * 4, device="cuda")
+        buf[..., :Co] = gd
+        gd = buf
+    xa = nhwc(x[:, :Ca])
+    xb = nhwc(x[:, Ca:]) if Cb else None
+    for _ in range(2):
+        ops.conv2d_wgrad(gd, xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=1)
+    scale = max(1.0, float(w.grad.abs().max()))
+    np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
+    np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)

@@ -26,7 +26,27 @@ def one(name, H, Ca, Cb, Co):
     print(f"{name:28s} direct {t0*1e6:8.1f} us {fl/t0/1e12:6.1f} TF | winograd {t1*1e6:8.1f} us {fl/t1/1e12:6.1f} TF(eff) "
           f"x{t0/t1:4.2f}  maxdiff {err:.2e}")
 
+def wg(name, H, Ca, Cb, Co):
+    Ci = Ca + Cb
+    a = torch.randn(B, H, H, Ca, device="cuda")
+    b = torch.randn(B, H, H, Cb, device="cuda") if Cb else None
+    g = torch.randn(B, H, H, Co, device="cuda")
+    dw = torch.zeros(Co, Ci, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")
+    fl = 2.0 * B * H * H * Co * Ci * 9
+    t0 = timeit(lambda: ops.conv2d_wgrad(g, a, dw, kh=3, kw=3, pad=1, in_b=b, db=db))
+    t1 = timeit(lambda: ops.conv2d_wgrad(g, a, dw, kh=3, kw=3, pad=1, in_b=b, db=db, algo=1))
+    print(f"wgrad {name:24s} direct {t0*1e6:8.1f} us {fl/t0/1e12:6.1f} TF | winograd {t1*1e6:8.1f} us {fl/t1/1e12:6.1f} TF(eff) x{t0/t1:4.2f}")
+
+
 if __name__ == "__main__":
+    wg("L0 first 32->64 @256", 256, 32, 0, 64)
+    wg("L0 main.0 128->64 @256", 256, 64, 64, 64)
+    wg("L0 res 64->64 @256", 256, 64, 0, 64)
+    wg("L1 main.0 256->128 @128", 128, 128, 128, 128)
+    wg("L1 res 128->128 @128", 128, 128, 0, 128)
+    wg("L2 main.0 512->256 @64", 64, 256, 256, 256)
+    wg("L2 res 256->256 @64", 64, 256, 0, 256)
+    wg("bottleneck 256->256 @32", 32, 256, 0, 256)
     one("L0 first 32->64 @256", 256, 32, 0, 64)
     one("L0 main.0 128->64 @256", 256, 64, 64, 64)
     one("L0 res 64->64 @256", 256, 64, 0, 64)

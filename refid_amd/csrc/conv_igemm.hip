@@ -392,7 +392,14 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
               d->co_base % 4 == 0 && (d->mode != 1 || (d->cout / 4) % 4 == 0);
     const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
-    if (d->algo == 1) return refid_launch_wino3x3(a, st);
+    if (d->algo == 1) {
+        REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");
+        const long long lim = 0x7fffffffLL;      // buffer-load byte offsets are 32-bit
+        REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
+                        (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
+                    "conv2d: tensor too large for the Winograd tile's 32-bit offsets (use algo 0)");
+        return refid_launch_wino3x3(a, st);
+    }
     switch (f) {
         case F_3x3:
             if (bn == 32) return launch<C3_32>(a, 1, st);

@@ -38,10 +38,15 @@ constexpr int NT = 32;                  // Winograd tiles per workgroup (2 x 16)
 constexpr int BN = 64;                  // output channels per workgroup
 constexpr int KC = 8;                   // input channels per chunk
 constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;   // raw input halo: 6 x 34 pixels
-constexpr int V_F4 = 16 * 2 * NT;       // float4 slots: [xi][quad][tile]
-constexpr int U_F4 = 16 * 2 * BN;       // [xi][quad][cout]
+// plane strides padded by 4 float4 (64 B): the two channel-quad planes written by neighbouring
+// lanes must not alias modulo the 128-byte ds_write bank period
+constexpr int VS = NT + 4, US = BN + 4;
+constexpr int V_F4 = 16 * 2 * VS;       // float4 slots: [xi][quad][tile]
+constexpr int U_F4 = 16 * 2 * US;       // [xi][quad][cout]
 constexpr int R_F4 = 2 * HP;            // one raw halo buffer: [quad][pixel]
-constexpr int U_ITEMS = U_F4 / 256;     // 8 float4 per thread per chunk
+constexpr int U_ITEMS = 16 * 2 * BN / 256;   // 8 float4 per thread per chunk
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 constexpr int R_ITEMS = (R_F4 + 255) / 256;
 constexpr int LDS_BYTES = (V_F4 + U_F4 + 2 * R_F4) * 16;      // 61 KB (the exchange re-uses 32 KB)
 
@@ -63,16 +68,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int n0 = blockIdx.y * BN;
 
-    // ---- raw halo loader: (quad q, halo pixel) items, quad fastest -------------------------------
+    // ---- loaders: buffer loads (wave-uniform descriptor + per-chunk scalar offset + a per-thread
+    // byte offset that never changes across chunks); out-of-image pixels / out-of-range weight rows
+    // carry an out-of-range offset and come back as zeros -- no branches, no per-chunk address math.
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.inA), 0, (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.inB ? a.inB : a.inA), 0,
+        (int)min((long long)a.N * a.H * a.W * (a.inB ? a.ldB : a.ldA) * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * 16 * a.CoutPad * KC * 4, 0x7fffffffLL), 0x00020000);
     const int q = tid & 1;
-    int rpix[R_ITEMS];
+    int voA[R_ITEMS], voB[R_ITEMS];
 #pragma unroll
     for (int it = 0; it < R_ITEMS; ++it) {
         const int hp = (tid >> 1) + it * 128;
         const int iy = oy0 - a.pad + hp / HWD, ix = ox0 - a.pad + hp % HWD;
         const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        rpix[it] = ok ? ((n * a.H + iy) * a.W + ix) : -1;
+        const int pix = (n * a.H + iy) * a.W + ix;
+        voA[it] = ok ? pix * a.ldA * 4 + q * 16 : OOB;
+        voB[it] = ok ? pix * a.ldB * 4 + q * 16 : OOB;
     }
+    const int uco = (tid >> 1) & 63;
+    const int voU = (a.coBase + n0 + uco < a.CoutPad)
+                        ? (((tid >> 7) * a.CoutPad + a.coBase + n0 + uco) * KC + (tid & 1) * 4) * 4 : OOB;
+    const int uStep = 2 * a.CoutPad * KC * 4;              // bytes between xi and xi+2
+    const int uChunk = 16 * a.CoutPad * KC * 4;            // bytes per K chunk
     // ---- input-transform item of this thread: (quad q, tile tt, transform row ti = wave) ----------
     const int tt = (tid >> 1) & 31;
     const int ti = wave;
@@ -86,17 +107,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     f32x4 rr[R_ITEMS], ru[U_ITEMS];
 
     auto load_raw = [&](int ch) {
-        const int c = ch * KC + q * 4;
-        const bool fromA = c < a.Ca;
-        const float* src = fromA ? a.inA : a.inB;
-        const int ld = fromA ? a.ldA : a.ldB;
-        const int cc = fromA ? c : c - a.Ca;
-        const bool cok = c < a.Ctot;
+        const int c0 = ch * KC;                            // chunk-uniform: Ca % 8 == 0 for two sources
+        const bool fromA = c0 < a.Ca;
+        const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
+        const bool qok = c0 + q * 4 < a.Ctot;              // Ctot % 8 == 4: upper quad of the last chunk
 #pragma unroll
         for (int it = 0; it < R_ITEMS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && rpix[it] >= 0) v = *reinterpret_cast<const f32x4*>(src + (long long)rpix[it] * ld + cc);
-            rr[it] = v;
+            const int vo = qok ? (fromA ? voA[it] : voB[it]) : OOB;
+            const u32x4 v = fromA ? __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0)
+                                  : __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, soff, 0);
+            rr[it] = __builtin_bit_cast(f32x4, v);
         }
     };
     auto store_raw = [&](int buf) {
@@ -107,23 +127,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         }
     };
     auto load_u = [&](int ch) {
-        const float* wc = a.w + (long long)ch * (16 * a.CoutPad * KC);
 #pragma unroll
-        for (int it = 0; it < U_ITEMS; ++it) {
-            const int e = tid + it * 256;           // (xi, co, quad), quad fastest
-            const int uq = e & 1, co = (e >> 1) & 63, xi = e >> 7;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a.coBase + n0 + co < a.CoutPad)
-                v = *reinterpret_cast<const f32x4*>(wc + ((long long)(xi * a.CoutPad + a.coBase + n0 + co)) * KC + uq * 4);
-            ru[it] = v;
-        }
+        for (int it = 0; it < U_ITEMS; ++it)
+            ru[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voU, ch * uChunk + it * uStep, 0));
     };
     auto store_u = [&]() {
 #pragma unroll
         for (int it = 0; it < U_ITEMS; ++it) {
             const int e = tid + it * 256;
             const int uq = e & 1, co = (e >> 1) & 63, xi = e >> 7;
-            sU[(xi * 2 + uq) * BN + co] = ru[it];
+            sU[(xi * 2 + uq) * US + co] = ru[it];
         }
     };
     auto transform = [&](int buf) {
@@ -132,11 +145,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         f32x4 t[4];
 #pragma unroll
         for (int b = 0; b < 4; ++b) t[b] = r[hpa + b] + r[hpb + b] * sgn;
-        f32x4* v = sV + (ti * 4 * 2 + q) * NT + tt;               // xi = ti*4 + j  ->  + j*2*NT
-        v[0 * 2 * NT] = t[0] - t[2];
-        v[1 * 2 * NT] = t[1] + t[2];
-        v[2 * 2 * NT] = t[2] - t[1];
-        v[3 * 2 * NT] = t[1] - t[3];
+        f32x4* v = sV + (ti * 4 * 2 + q) * VS + tt;               // xi = ti*4 + j  ->  + j*2*VS
+        v[0 * 2 * VS] = t[0] - t[2];
+        v[1 * 2 * VS] = t[1] + t[2];
+        v[2 * 2 * VS] = t[2] - t[1];
+        v[3 * 2 * VS] = t[1] - t[3];
     };
 
     f32x16 acc[8];
@@ -159,18 +172,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         const bool more = ch + 1 < a.nchunks;
         if (more) {
             store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
-            if (ch + 2 < a.nchunks) load_raw(ch + 2);
-            load_u(ch + 1);
+            load_u(ch + 1);                          // weights first: their wait must not drain ...
+            if (ch + 2 < a.nchunks) load_raw(ch + 2);   // ... the younger activation prefetch
         }
+        // operand fragments double-buffered in registers: the LDS reads of group x+1 are in flight
+        // while the four dependent MFMAs of group x issue
+        const f32x4* pU = sU + (h * 16 + kh) * US + nt * 32 + li;     // xi = h*8 + x  ->  + x*2*US
+        const f32x4* pV = sV + (h * 16 + kh) * VS + li;
+        f32x4 ufA = pU[0], vfA = pV[0], ufB, vfB;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            const int xi = h * 8 + x;
-            const f32x4 uf = sU[(xi * 2 + kh) * BN + nt * 32 + li];
-            const f32x4 vf = sV[(xi * 2 + kh) * NT + li];
+        for (int x = 0; x < 8; x += 2) {
+            ufB = pU[(x + 1) * 2 * US]; vfB = pV[(x + 1) * 2 * VS];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(uf[kk], vf[kk], acc[x], 0, 0, 0);
+                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufA[kk], vfA[kk], acc[x], 0, 0, 0);
+            if (x + 2 < 8) { ufA = pU[(x + 2) * 2 * US]; vfA = pV[(x + 2) * 2 * VS]; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                acc[x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufB[kk], vfB[kk], acc[x + 1], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();                             // V(ch), U(ch) consumed; raw(ch+1) visible
         if (more) {
             transform((ch + 1) & 1);

@@ -19,12 +19,13 @@
 //     v_mfma_f32_32x32x2_f32.  A wave owns 8 of the 16 xi (transform rows i = 2h, 2h+1) for 32
 //     output channels: 8 accumulators = 128 AGPRs, so two waves fit per SIMD.  4 waves =
 //     {xi half h} x {channel half nt}.
-//   * the raw 6x34-pixel input halo of the NEXT chunk is prefetched global->VGPR->LDS (double
-//     buffered, 6.5 KB each) while the current chunk's MFMAs run; between the two barriers of a
-//     chunk wave w computes transform row i = w of B^T d B for all 32 tiles x 2 channel quads
-//     from LDS (8 x ds_read_b128, 12 float4 adds) and writes the V planes [xi][quad][tile].
+//   * both MFMA operands live in REGISTERS: the raw 6x34-pixel input halo of the next chunk is
+//     prefetched global->VGPR->LDS (double buffered, 6.5 KB each) while the current chunk's MFMAs
+//     run; each lane reads the 3x4 patch rows of ITS tile / channel quad (12 x ds_read_b128) and
+//     computes its own 8 fragments of B^T d B (16 float4 adds).  One barrier per chunk.
 //   * transformed weights U = G g G^T are produced once per step by the pack kernel in the
-//     [chunk][xi][cout][8] layout and staged per chunk as [xi][quad][cout].
+//     [chunk][xi][cout][8] layout; a lane's fragment is one 16-byte buffer load per xi (a wave reads
+//     1 KB contiguous), prefetched one chunk ahead -- weights never pass through LDS.
 //   * output transform: each lane reduces its 8 accumulators along j in registers, the two xi
 //     halves swap one half of the row-partials through LDS (32 KB, after the K loop), and every
 //     wave finishes one output row parity with the fused 16-byte epilogue.
@@ -38,23 +39,15 @@ constexpr int NT = 32;                  // Winograd tiles per workgroup (2 x 16)
 constexpr int BN = 64;                  // output channels per workgroup
 constexpr int KC = 8;                   // input channels per chunk
 constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;   // raw input halo: 6 x 34 pixels
-// plane strides padded by 4 float4 (64 B): the two channel-quad planes written by neighbouring
-// lanes must not alias modulo the 128-byte ds_write bank period
-constexpr int VS = NT + 4, US = BN + 4;
-constexpr int V_F4 = 16 * 2 * VS;       // float4 slots: [xi][quad][tile]
-constexpr int U_F4 = 16 * 2 * US;       // [xi][quad][cout]
-constexpr int R_F4 = 2 * HP;            // one raw halo buffer: [quad][pixel]
-constexpr int U_ITEMS = 16 * 2 * BN / 256;   // 8 float4 per thread per chunk
+constexpr int R_F4 = 2 * HP;            // one raw halo buffer: [quad][pixel] float4
+constexpr int R_ITEMS = (R_F4 + 255) / 256;
+constexpr int LDS_BYTES = 32768;        // 2 raw buffers (13 KB) in the K loop; 32 KB exchange afterwards
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
-constexpr int R_ITEMS = (R_F4 + 255) / 256;
-constexpr int LDS_BYTES = (V_F4 + U_F4 + 2 * R_F4) * 16;      // 61 KB (the exchange re-uses 32 KB)
 
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* sV = reinterpret_cast<f32x4*>(smem);
-    f32x4* sU = sV + V_F4;
-    f32x4* sR = sU + U_F4;               // two raw halo buffers
+    f32x4* sR = reinterpret_cast<f32x4*>(smem);            // two raw halo buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -89,22 +82,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         voA[it] = ok ? pix * a.ldA * 4 + q * 16 : OOB;
         voB[it] = ok ? pix * a.ldB * 4 + q * 16 : OOB;
     }
-    const int uco = (tid >> 1) & 63;
-    const int voU = (a.coBase + n0 + uco < a.CoutPad)
-                        ? (((tid >> 7) * a.CoutPad + a.coBase + n0 + uco) * KC + (tid & 1) * 4) * 4 : OOB;
-    const int uStep = 2 * a.CoutPad * KC * 4;              // bytes between xi and xi+2
+    // U fragment of this lane: row (cout) nt*32+li, K quad kh, for the wave's 8 xi -- read straight
+    // from the packed [chunk][xi][cout][8] weights (a wave reads 1 KB contiguous per xi): weights
+    // never pass through LDS.
+    const int urow = a.coBase + n0 + nt * 32 + li;
+    const int voU = (urow < a.CoutPad) ? ((h * 8 * a.CoutPad + urow) * KC + kh * 4) * 4 : OOB;
+    const int uStep = a.CoutPad * KC * 4;                  // bytes between xi and xi+1
     const int uChunk = 16 * a.CoutPad * KC * 4;            // bytes per K chunk
-    // ---- input-transform item of this thread: (quad q, tile tt, transform row ti = wave) ----------
-    const int tt = (tid >> 1) & 31;
-    const int ti = wave;
-    // rows of the 4x4 patch with non-zero B^T[ti][.]:  i=0: d0-d2  i=1: d1+d2  i=2: d2-d1  i=3: d1-d3
-    const int ra = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
-    const int rb = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
-    const float sgn = (ti == 1) ? 1.f : -1.f;
-    const int hpa = (2 * (tt >> 4) + ra) * HWD + 2 * (tt & 15);     // halo index of patch (ra, col 0)
-    const int hpb = (2 * (tt >> 4) + rb) * HWD + 2 * (tt & 15);
 
-    f32x4 rr[R_ITEMS], ru[U_ITEMS];
+    f32x4 rr[R_ITEMS], ufA[8], ufB[8];
 
     auto load_raw = [&](int ch) {
         const int c0 = ch * KC;                            // chunk-uniform: Ca % 8 == 0 for two sources
@@ -126,30 +112,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
             if (hp < HP) sR[buf * R_F4 + q * HP + hp] = rr[it];
         }
     };
-    auto load_u = [&](int ch) {
+    auto load_u = [&](int ch, f32x4 (&dst)[8]) {
 #pragma unroll
-        for (int it = 0; it < U_ITEMS; ++it)
-            ru[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voU, ch * uChunk + it * uStep, 0));
-    };
-    auto store_u = [&]() {
-#pragma unroll
-        for (int it = 0; it < U_ITEMS; ++it) {
-            const int e = tid + it * 256;
-            const int uq = e & 1, co = (e >> 1) & 63, xi = e >> 7;
-            sU[(xi * 2 + uq) * US + co] = ru[it];
-        }
-    };
-    auto transform = [&](int buf) {
-        // V[ti][j] of B^T d B:  T_b = d[ra][b] + sgn*d[rb][b];  V_j = {T0-T2, T1+T2, T2-T1, T1-T3}
-        const f32x4* r = sR + buf * R_F4 + q * HP;
-        f32x4 t[4];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) t[b] = r[hpa + b] + r[hpb + b] * sgn;
-        f32x4* v = sV + (ti * 4 * 2 + q) * VS + tt;               // xi = ti*4 + j  ->  + j*2*VS
-        v[0 * 2 * VS] = t[0] - t[2];
-        v[1 * 2 * VS] = t[1] + t[2];
-        v[2 * 2 * VS] = t[2] - t[1];
-        v[3 * 2 * VS] = t[1] - t[3];
+        for (int x = 0; x < 8; ++x)
+            dst[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voU, ch * uChunk + x * uStep, 0));
     };
 
     f32x16 acc[8];
@@ -158,47 +124,67 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
-    // prologue: raw(0) -> LDS, U(0) -> LDS, transform(0); raw(1) in flight
-    load_raw(0);
-    load_u(0);
-    store_raw(0);
-    store_u();
-    if (a.nchunks > 1) load_raw(1);
-    __syncthreads();
-    transform(0);
-    __syncthreads();
+    // input patch of this lane's tile: halo rows r0..r0+2 (h=0: patch rows 0,1,2; h=1: rows 1,2,3), 4 cols
+    const int hp0 = (2 * (li >> 4) + h) * HWD + 2 * (li & 15);
+    // transform row 2h   = p - m with (p,m) = halo rows (0,2) for h=0, (1,0) for h=1   [d0-d2 | d2-d1]
+    // transform row 2h+1 =            rows (1)+(2) for h=0, (0)-(2) for h=1            [d1+d2 | d1-d3]
+    const int rAp = h ? HWD : 0, rAm = h ? 0 : 2 * HWD;
+    const int rBp = h ? 0 : HWD, rBm = 2 * HWD;
+    const float sB = h ? -1.f : 1.f;
 
-    for (int ch = 0; ch < a.nchunks; ++ch) {
+    // one K chunk: cur = this chunk's U fragments, nxt = register set the next chunk's are prefetched into
+    auto phase = [&](int ch, f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
         const bool more = ch + 1 < a.nchunks;
         if (more) {
             store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
-            load_u(ch + 1);                          // weights first: their wait must not drain ...
-            if (ch + 2 < a.nchunks) load_raw(ch + 2);   // ... the younger activation prefetch
+            load_u(ch + 1, nxt);
+            if (ch + 2 < a.nchunks) load_raw(ch + 2);
         }
-        // operand fragments double-buffered in registers: the LDS reads of group x+1 are in flight
-        // while the four dependent MFMAs of group x issue
-        const f32x4* pU = sU + (h * 16 + kh) * US + nt * 32 + li;     // xi = h*8 + x  ->  + x*2*US
-        const f32x4* pV = sV + (h * 16 + kh) * VS + li;
-        f32x4 ufA = pU[0], vfA = pV[0], ufB, vfB;
+        // B^T d B for this lane's tile / channel quad, one transform row at a time, in registers
+        const f32x4* r = sR + (ch & 1) * R_F4 + kh * HP + hp0;
         __builtin_amdgcn_s_setprio(1);
+        {
+            f32x4 t[4];
 #pragma unroll
-        for (int x = 0; x < 8; x += 2) {
-            ufB = pU[(x + 1) * 2 * US]; vfB = pV[(x + 1) * 2 * VS];
+            for (int b = 0; b < 4; ++b) t[b] = r[rAp + b] - r[rAm + b];
+            const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufA[kk], vfA[kk], acc[x], 0, 0, 0);
-            if (x + 2 < 8) { ufA = pU[(x + 2) * 2 * US]; vfA = pV[(x + 2) * 2 * VS]; }
+            for (int kk = 0; kk < 4; ++kk) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][kk], v0[kk], acc[0], 0, 0, 0);
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                acc[x + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ufB[kk], vfB[kk], acc[x + 1], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][kk], v1[kk], acc[1], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[2][kk], v2[kk], acc[2], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[3][kk], v3[kk], acc[3], 0, 0, 0);
+        }
+        {
+            f32x4 t[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t[b] = r[rBp + b] + r[rBm + b] * sB;
+            const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[4][kk], v0[kk], acc[4], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[5][kk], v1[kk], acc[5], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[6][kk], v2[kk], acc[6], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[7][kk], v3[kk], acc[7], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        __syncthreads();                             // V(ch), U(ch) consumed; raw(ch+1) visible
-        if (more) {
-            transform((ch + 1) & 1);
-            store_u();
-        }
-        __syncthreads();
+        __syncthreads();                             // raw(ch) consumed by every wave; raw(ch+1) visible
+    };
+
+    // prologue: raw(0) -> LDS, U(0) -> regs; raw(1) in flight
+    load_raw(0);
+    load_u(0, ufA);
+    store_raw(0);
+    if (a.nchunks > 1) load_raw(1);
+    __syncthreads();
+
+    for (int ch = 0; ch < a.nchunks; ch += 2) {
+        phase(ch, ufA, ufB);
+        if (ch + 1 < a.nchunks) phase(ch + 1, ufB, ufA);
     }
 
     // ---- output transform --------------------------------------------------------------------------

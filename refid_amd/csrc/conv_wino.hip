@@ -34,25 +34,32 @@
 
 namespace {
 
-constexpr int TW = 32, TH = 4;          // output pixels per workgroup
-constexpr int NT = 32;                  // Winograd tiles per workgroup (2 x 16)
-constexpr int BN = 64;                  // output channels per workgroup
+constexpr int TW = 32;                  // output pixels per workgroup row
 constexpr int KC = 8;                   // input channels per chunk
-constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;   // raw input halo: 6 x 34 pixels
-constexpr int R_F4 = 2 * HP;            // one raw halo buffer: [quad][pixel] float4
-constexpr int R_ITEMS = (R_F4 + 255) / 256;
-constexpr int LDS_BYTES = 32768;        // 2 raw buffers (13 KB) in the K loop; 32 KB exchange afterwards
+constexpr int HWD = TW + 2;
+constexpr int LDS_BYTES = 32768;        // 2 raw buffers (13-22 KB) in the K loop; 32 KB exchange afterwards
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 
+// <NTN, MTN>: the two waves that are not xi-halves split either the 64 output channels (NTN = 2:
+// tile 4x32 pixels x 64 channels) or the pixels (MTN = 2: tile 8x32 pixels x 32 channels, for the
+// 32-channel layers).
+template <int NTN, int MTN>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
+    static_assert(NTN * MTN == 2, "4 waves = 2 xi halves x 2");
+    constexpr int TH = 4 * MTN;             // output rows per workgroup
+    constexpr int BN = 32 * NTN;            // output channels per workgroup
+    constexpr int HP = (TH + 2) * HWD;      // raw input halo pixels
+    constexpr int R_F4 = 2 * HP;            // one raw halo buffer: [quad][pixel] float4
+    constexpr int R_ITEMS = (R_F4 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sR = reinterpret_cast<f32x4*>(smem);            // two raw halo buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    const int h = wave & 1, nt = wave >> 1;
+    const int h = wave & 1;
+    const int nt = (NTN == 2) ? (wave >> 1) : 0, mt = (MTN == 2) ? (wave >> 1) : 0;
 
     int bt = blockIdx.x;
     const int tx = bt % a.tilesX; bt /= a.tilesX;
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
     // input patch of this lane's tile: halo rows r0..r0+2 (h=0: patch rows 0,1,2; h=1: rows 1,2,3), 4 cols
-    const int hp0 = (2 * (li >> 4) + h) * HWD + 2 * (li & 15);
+    const int hp0 = (4 * mt + 2 * (li >> 4) + h) * HWD + 2 * (li & 15);
     // transform row 2h   = p - m with (p,m) = halo rows (0,2) for h=0, (1,0) for h=1   [d0-d2 | d2-d1]
     // transform row 2h+1 =            rows (1)+(2) for h=0, (0)-(2) for h=1            [d1+d2 | d1-d3]
     const int rAp = h ? HWD : 0, rAm = h ? 0 : 2 * HWD;
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         for (int r = 0; r < 16; ++r) keep[b][r] += xch[((partner * 2 + b) * 16 + r) * 64 + lane];
 
     // ---- fused epilogue: this wave owns output row parity a = h, columns b = 0,1 ------------------
-    const int oy = oy0 + 2 * (li >> 4) + h;
+    const int oy = oy0 + 4 * mt + 2 * (li >> 4) + h;
     if (oy >= a.Ho) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -264,19 +271,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 }  // namespace
 
 int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { refid_set_error("conv_wino: LDS attribute: %s", hipGetErrorString(e)); return 2; }
-        attr_set = true;
-    }
     ConvKArgs a = ka;
+    const bool narrow = a.Cout <= 32;           // 32-channel layers: split pixels instead of channels
+    const int th = narrow ? 8 : 4, bn = narrow ? 32 : 64;
     a.tilesX = cdiv(a.Wo, TW);
-    a.tilesY = cdiv(a.Ho, TH);
+    a.tilesY = cdiv(a.Ho, th);
     a.nchunks = cdiv(a.Ctot, KC);
-    dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, BN));
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), LDS_BYTES, st, a);
+    dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, bn));
+    if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_wino");
     return 0;
 }

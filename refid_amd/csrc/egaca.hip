@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ p
     }
 }
 
-// SE backward, single block, loops over samples (deterministic accumulation):
+// SE backward, one block per sample; parameter gradients accumulate with atomics:
 // given gs = dL/ds: gm = dL/dm ; dW1,db1,dW2,db2 += ...
 __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
                                                     const float* __restrict__ z1, const float* __restrict__ m,
@@ -235,32 +235,30 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ g
                                                     float* __restrict__ db2, int N, int C) {
     __shared__ float d2[256], d1[128], sz[128], sm[256];
     const int Ch = C / 2;
-    for (int n = 0; n < N; ++n) {
-        for (int c = threadIdx.x; c < C; c += 256) {
-            const float sv = s[n * C + c];
-            d2[c] = gs[n * C + c] * sv * (1.f - sv);
-            sm[c] = m[n * C + c];
-        }
-        for (int j = threadIdx.x; j < Ch; j += 256) sz[j] = z1[n * Ch + j];
-        __syncthreads();
-        for (int j = threadIdx.x; j < Ch; j += 256) {
-            float a = 0.f;
-            for (int c = 0; c < C; ++c) a += W2[c * Ch + j] * d2[c];
-            d1[j] = sz[j] > 0.f ? a : 0.f;
-        }
-        __syncthreads();
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float a = 0.f;
-            for (int j = 0; j < Ch; ++j) a += W1[j * C + c] * d1[j];
-            gm[n * C + c] = a;
-            db2[c] += d2[c];
-        }
-        for (int j = threadIdx.x; j < Ch; j += 256) db1[j] += d1[j];
-        for (int e = threadIdx.x; e < C * Ch; e += 256) {
-            dW2[e] += d2[e / Ch] * sz[e % Ch];          // W2: (C, Ch)
-            dW1[e] += d1[e / C] * sm[e % C];            // W1: (Ch, C)
-        }
-        __syncthreads();
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sv = s[n * C + c];
+        d2[c] = gs[n * C + c] * sv * (1.f - sv);
+        sm[c] = m[n * C + c];
+    }
+    for (int j = threadIdx.x; j < Ch; j += 256) sz[j] = z1[n * Ch + j];
+    __syncthreads();
+    for (int j = threadIdx.x; j < Ch; j += 256) {
+        float a = 0.f;
+        for (int c = 0; c < C; ++c) a += W2[c * Ch + j] * d2[c];
+        d1[j] = sz[j] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < Ch; ++j) a += W1[j * C + c] * d1[j];
+        gm[n * C + c] = a;
+        atomicAdd(db2 + c, d2[c]);
+    }
+    for (int j = threadIdx.x; j < Ch; j += 256) atomicAdd(db1 + j, d1[j]);
+    for (int e = threadIdx.x; e < C * Ch; e += 256) {
+        atomicAdd(dW2 + e, d2[e / Ch] * sz[e % Ch]);          // W2: (C, Ch)
+        atomicAdd(dW1 + e, d1[e / C] * sm[e % C]);            // W1: (Ch, C)
     }
 }
 
@@ -468,7 +466,7 @@ extern "C" int refid_se_bwd(const float* gs, const float* s, const float* z1, co
                             void* stream) {
     REFID_CHECK(gs && s && z1 && m && w1 && w2 && gm && dw1 && db1 && dw2 && db2 && n > 0 && c <= 256,
                 "se_bwd: bad arguments");
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, gs, s, z1, m, w1, w2, gm, dw1, db1,
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, gs, s, z1, m, w1, w2, gm, dw1, db1,
                        dw2, db2, n, c);
     REFID_LAUNCH_CHECK("se_bwd");
     return 0;

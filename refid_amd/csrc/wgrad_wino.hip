@@ -127,31 +127,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         const bool more = pt + a.nsplit < a.ntiles;
         if (more) load_tile(pt + a.nsplit);
 
+        // 16 K steps (tile pairs) per K tile, fully unrolled: every LDS address is base + immediate.
+        // The raw operands of step s+1 are fetched before the 8 MFMAs of step s issue (explicit
+        // software pipelining -- the compiler does not do it across the on-the-fly transforms).
+        const float* xA = sX + (ra * HWD + 2 * kh) * CIT + li;       // + (2*tr*HWD + 4*qk) * CIT
+        const float* xB = sX + (rb * HWD + 2 * kh) * CIT + li;
+        const float* gP = sG + (2 * kh) * COT + li;                  // + (2*tr*TW + 4*qk) * COT
+        float cxa[4], cxb[4], cg[2][4], nxa[4], nxb[4], ng[2][4];
+        auto fetch = [&](int s, float (&pa)[4], float (&pb)[4], float (&pg)[2][4]) {
+            const int tr = s >> 3, qk = s & 7;
+            const int xo = (2 * tr * HWD + 4 * qk) * CIT, go = (2 * tr * TW + 4 * qk) * COT;
 #pragma unroll
-        for (int tr = 0; tr < TH / 2; ++tr) {
-#pragma unroll 2
-            for (int qk = 0; qk < TW / 4; ++qk) {
-                const int tc = 2 * qk + kh;                // this half-wave's tile column (K index)
-                // ---- V row ti for input channel li:  T_b = d[ra][b] + sgn d[rb][b] -------------------
-                const float* xa = sX + ((2 * tr + ra) * HWD + 2 * tc) * CIT + li;
-                const float* xb = sX + ((2 * tr + rb) * HWD + 2 * tc) * CIT + li;
-                const float t0 = xa[0] + sgn * xb[0], t1 = xa[CIT] + sgn * xb[CIT];
-                const float t2 = xa[2 * CIT] + sgn * xb[2 * CIT], t3 = xa[3 * CIT] + sgn * xb[3 * CIT];
-                float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
-                // ---- Z row ti for output channels li, li+32:  X_b = ca dY[0][b] + cb dY[1][b] ----------
-                float z[2][4];
+            for (int b = 0; b < 4; ++b) { pa[b] = xA[xo + b * CIT]; pb[b] = xB[xo + b * CIT]; }
 #pragma unroll
-                for (int sm = 0; sm < 2; ++sm) {
-                    const float* g0 = sG + ((2 * tr) * TW + 2 * tc) * COT + sm * 32 + li;
-                    const float x0 = ca * g0[0] + cb * g0[TW * COT];
-                    const float x1 = ca * g0[COT] + cb * g0[TW * COT + COT];
-                    z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = -x1;
-                }
+            for (int sm = 0; sm < 2; ++sm) {
+                pg[sm][0] = gP[go + sm * 32];            pg[sm][1] = gP[go + sm * 32 + COT];
+                pg[sm][2] = gP[go + sm * 32 + TW * COT]; pg[sm][3] = gP[go + sm * 32 + TW * COT + COT];
+            }
+        };
+        fetch(0, cxa, cxb, cg);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+        for (int s = 0; s < 16; ++s) {
+            if (s + 1 < 16) fetch(s + 1, nxa, nxb, ng);
+            // V row ti:  T_b = d[ra][b] + sgn d[rb][b]
+            const float t0 = cxa[0] + sgn * cxb[0], t1 = cxa[1] + sgn * cxb[1];
+            const float t2 = cxa[2] + sgn * cxb[2], t3 = cxa[3] + sgn * cxb[3];
+            const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+            // Z row ti:  X_b = ca dY[0][b] + cb dY[1][b]
+            float z[2][4];
 #pragma unroll
-                    for (int sm = 0; sm < 2; ++sm)
-                        acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
+            for (int sm = 0; sm < 2; ++sm) {
+                const float x0 = ca * cg[sm][0] + cb * cg[sm][2];
+                const float x1 = ca * cg[sm][1] + cb * cg[sm][3];
+                z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = -x1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm)
+                    acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
+            if (s + 1 < 16) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { cxa[b] = nxa[b]; cxb[b] = nxb[b]; cg[0][b] = ng[0][b]; cg[1][b] = ng[1][b]; }
             }
         }
         __syncthreads();

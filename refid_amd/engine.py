@@ -181,11 +181,9 @@ class ConvOp:
         self.f_bn = ops.conv_bn(kh, kw, st, md, self.f_rows)
         self.f_algo = self.d_algo = 0
         if USE_WINOGRAD and kind == "conv" and k == 3:
-            if self.co > 32:
+            if self.co >= 16:                  # pred (3 channels) stays on the direct tile
                 self.f_algo, self.f_role, self.f_kc, self.f_bn = 1, ops.ROLE_WINO_FWD, 8, 64
-            d_cnt = self.co if self.ci == 2 * self.co else self.ci     # rows per dgrad issue
-            if d_cnt > 32:
-                self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
+            self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
         self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
         dev = self.w.device
         self.wp = torch.empty(ops.packed_weight_floats(self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci),

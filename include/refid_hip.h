@@ -164,15 +164,17 @@ int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float*
 int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
                           int ld_gx, int accumulate, float* dw, float* db, long long npix, int c,
                           float eps, void* stream);
-/* pre = dwconv3x3(in)+b ; act = GELU(pre) ; pool[n][c] = sum_pixels act   (fm:304-309 + se_1's
- * AdaptiveAvgPool2d, fm:253-254; pool may be NULL).  w is the reference (c,1,3,3) tensor. */
+/* pre = dwconv3x3(in)+b ; act = GELU(pre) ; pool[n][part][c] = per-workgroup partial sums of act
+ * (fm:304-309 + se_1's AdaptiveAvgPool2d, fm:253-254; pool may be NULL; parts =
+ * refid_dwconv_pool_parts(h,w,c); deterministic, no atomics).  w is the reference (c,1,3,3) tensor. */
+int refid_dwconv_pool_parts(int h, int wd, int c);
 int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
                              float* act, float* pool, int n, int h, int wd, int c, void* stream);
 /* gd = gradient w.r.t. `pre`; gin = input gradient; dw/db accumulate. */
 int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
                         float* dw, float* db, int n, int h, int wd, int c, void* stream);
-/* se_1 (fm:253-260): m = pool*inv_hw ; z1 = relu(W1 m + b1) ; s = sigmoid(W2 z1 + b2) */
-int refid_se_fwd(const float* pool, float inv_hw, const float* w1, const float* b1, const float* w2,
+/* se_1 (fm:253-260): m = (sum_parts pool)*inv_hw ; z1 = relu(W1 m + b1) ; s = sigmoid(W2 z1 + b2) */
+int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const float* w1, const float* b1, const float* w2,
                  const float* b2, float* m, float* z1, float* s, int n, int c, void* stream);
 int refid_se_bwd(const float* gs, const float* s, const float* z1, const float* m, const float* w1,
                  const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, int n, int c,
@@ -221,6 +223,25 @@ int refid_add(const float* a, const float* b, float* out, long long count, void*
 /* out = (acc ? out : 0) + g * (y > 0 ? 1 : slope): activation derivative. */
 int refid_act_bwd(const float* g, const float* y, float* out, float slope, int accumulate,
                   long long count, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Callers either side of the path.
+ * ---------------------------------------------------------------------------------- */
+/* events_to_voxel_grid (basicsr/data/event_util.py:6-66): voxel (num_bins,height,width) is zeroed,
+ * then every event adds pol*(1-dt) to bin floor(t') and pol*dt to the next, t' = (bins-1)(t-first)/dT;
+ * polarity 0 counts as -1.  fp32 atomics: summation order differs from np.add.at (tolerance). */
+int refid_events_to_voxel(const double* ts, const int* xs, const int* ys, const float* ps, long long n_events,
+                          int num_bins, int width, int height, double first_stamp, double last_stamp,
+                          float* voxel, void* stream);
+/* tensor2img quantisation (utils/img_util.py:90-117: clamp [0,1], x255, round) fused with the squared
+ * error of calculate_psnr (metrics/psnr_ssim.py:48-63): sq[f] = sum (q(a)-q(b))^2 per frame, float64. */
+int refid_sqerr_u8(const float* a, const float* b, int n_frames, long long frame_elems, double* sq,
+                   void* stream);
+/* grids_inverse (twoImage_event_recurrent_model.py:252-268): acc[:, i0:i0+th, j0:j0+tw] += tile,
+ * cnt += 1; then acc /= cnt. */
+int refid_tile_add(const float* tile, float* acc, float* cnt, int c, int th, int tw, int h, int w, int i0, int j0,
+                   void* stream);
+int refid_tile_normalize(float* acc, const float* cnt, int c, int h, int w, void* stream);
 
 #ifdef __cplusplus
 }

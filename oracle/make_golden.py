@@ -208,6 +208,23 @@ def main():
         raised = True
         print("H=100 raises in the reference:", type(ex).__name__)
     np.savez(os.path.join(out_dir, "negative.npz"), h100_raises=np.array(raised))
+    # event voxelisation: the reference function as shipped uses the removed `np.int` alias
+    # (event_util.py:39,44); alias it back for the run -- no source edit.
+    if not hasattr(np, "int"):
+        np.int = int
+    sys.modules["basicsr.utils"].Timer = object
+    sys.modules["basicsr.utils"].CudaTimer = object
+    sys.modules.setdefault("basicsr.data", types.ModuleType("basicsr.data")).__path__ = [f"{REF}/basicsr/data"]
+    eu = importlib.import_module("basicsr.data.event_util")
+    rng = np.random.Generator(np.random.PCG64(11))
+    for name, (n_ev, bins, hh, ww) in {"voxel_a": (6000, 5, 24, 32), "voxel_b": (3000, 24, 16, 16)}.items():
+        t = np.sort(rng.random(n_ev) * 0.05 + 1.5)
+        ev = np.stack([t, rng.integers(0, ww, n_ev).astype(np.float64), rng.integers(0, hh, n_ev).astype(np.float64),
+                       rng.integers(0, 2, n_ev).astype(np.float64)], axis=1)
+        vox = eu.events_to_voxel_grid(ev.copy(), bins, ww, hh)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), events=ev, voxel=vox.astype(np.float32),
+                            meta=np.array([bins, hh, ww]))
+        print(name, "voxel sum", float(vox.sum()))
 
 
 if __name__ == "__main__":

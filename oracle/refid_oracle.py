@@ -468,3 +468,56 @@ def psnr_between(out_a: torch.Tensor, out_b: torch.Tensor) -> float:
     """PSNR (dB, peak 1) between two float outputs -- used for bf16/fp32 parity."""
     mse = ((out_a.double() - out_b.double()) ** 2).mean().item()
     return float("inf") if mse == 0 else 10.0 * math.log10(1.0 / mse)
+
+
+# --------------------------------------------------------------------------- #
+# callers either side of the path (SURVEY.md 8f)
+# --------------------------------------------------------------------------- #
+def events_to_voxel_grid(events, num_bins, width, height):
+    """numpy restatement of basicsr/data/event_util.py:6-66 (np.int -> int; otherwise line by line).
+    events: (N,4) float64 [t, x, y, p]; NOT modified in place (the reference overwrites column 0)."""
+    import numpy as np
+    events = np.array(events, dtype=np.float64, copy=True)
+    voxel_grid = np.zeros((num_bins, height, width), np.float32).ravel()
+    last_stamp, first_stamp = events[-1, 0], events[0, 0]
+    deltaT = last_stamp - first_stamp
+    if deltaT == 0:
+        deltaT = 1.0
+    ts = (num_bins - 1) * (events[:, 0] - first_stamp) / deltaT
+    xs = events[:, 1].astype(int)
+    ys = events[:, 2].astype(int)
+    pols = events[:, 3].copy()
+    pols[pols == 0] = -1
+    tis = ts.astype(int)
+    dts = ts - tis
+    vals_left = pols * (1.0 - dts)
+    vals_right = pols * dts
+    valid = tis < num_bins
+    np.add.at(voxel_grid, xs[valid] + ys[valid] * width + tis[valid] * width * height, vals_left[valid])
+    valid = (tis + 1) < num_bins
+    np.add.at(voxel_grid, xs[valid] + ys[valid] * width + (tis[valid] + 1) * width * height, vals_right[valid])
+    return np.reshape(voxel_grid, (num_bins, height, width))
+
+
+def tile_grid(h, w, crop):
+    """Tile origins of grids(): twoImage_event_recurrent_model.py:190-240 (trans_num=1, no random crops)."""
+    num_row = (h - 1) // crop + 1
+    num_col = (w - 1) // crop + 1
+    step_j = crop if num_col == 1 else math.ceil((w - crop) / (num_col - 1) - 1e-8)
+    step_i = crop if num_row == 1 else math.ceil((h - crop) / (num_row - 1) - 1e-8)
+    idxes = []
+    i, last_i = 0, False
+    while i < h and not last_i:
+        j = 0
+        if i + crop >= h:
+            i = h - crop
+            last_i = True
+        last_j = False
+        while j < w and not last_j:
+            if j + crop >= w:
+                j = w - crop
+                last_j = True
+            idxes.append({"i": i, "j": j})
+            j = j + step_j
+        i = i + step_i
+    return idxes

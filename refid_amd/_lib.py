@@ -94,7 +94,8 @@ def _bind_extra(L):
     L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, i, vp, vp, ll, i, f, vp]
     L.refid_dwconv3x3_gelu_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
     L.refid_dwconv3x3_bwd.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, i, vp]
-    L.refid_se_fwd.argtypes = [vp, f, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.refid_se_fwd.argtypes = [vp, i, f, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
+    L.refid_dwconv_pool_parts.argtypes = [i, i, i]
     L.refid_se_bwd.argtypes = [vp] * 11 + [i, i, vp]
     L.refid_scale_cat.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     L.refid_egaca_gs_reduce.argtypes = [vp, vp, vp, vp, i, i, i, vp]
@@ -105,6 +106,11 @@ def _bind_extra(L):
     L.refid_charbonnier.argtypes = [vp, vp, vp, vp, ll, f, f, vp]
     L.refid_grad_sqnorm.argtypes = [vp, vp, ll, vp]
     L.refid_clip_adamw.argtypes = [vp, vp, vp, vp, vp, f, f, f, f, f, f, f, i, ll, vp]
+    d = C.c_double
+    L.refid_events_to_voxel.argtypes = [vp, vp, vp, vp, ll, i, i, i, d, d, vp, vp]
+    L.refid_sqerr_u8.argtypes = [vp, vp, i, ll, vp, vp]
+    L.refid_tile_add.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
+    L.refid_tile_normalize.argtypes = [vp, vp, i, i, i, vp]
 
 
 def check(rc, what):

@@ -99,10 +99,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
                                                     float* __restrict__ pre, float* __restrict__ act,
                                                     float* __restrict__ pool, int H, int W) {
     constexpr int C = LPP * 4, PPB = 256 / LPP;
-    __shared__ float spool[C];
     const int q = threadIdx.x % LPP, n = blockIdx.y;
-    if (threadIdx.x < C) spool[threadIdx.x] = 0.f;
-    __syncthreads();
     float wr[4][9];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -136,10 +133,17 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
         psum += gl;
     }
     if (pool != nullptr) {
+        // deterministic: fixed-order sum over the block's pixel lanes, one partial row per block;
+        // se_fwd adds the rows in block order (no atomics on the forward path)
+        __shared__ float part[PPB][C];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&spool[q * 4 + k], psum[k]);
+        for (int k = 0; k < 4; ++k) part[threadIdx.x / LPP][q * 4 + k] = psum[k];
         __syncthreads();
-        if (threadIdx.x < C) atomicAdd(pool + n * C + threadIdx.x, spool[threadIdx.x]);
+        if (threadIdx.x < C) {
+            float a = 0.f;
+            for (int r = 0; r < PPB; ++r) a += part[r][threadIdx.x];
+            pool[((long long)n * gridDim.x + blockIdx.x) * C + threadIdx.x] = a;
+        }
     }
 }
 
@@ -202,14 +206,18 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ g
 // ------------------------------------------------------------------------------------------
 // squeeze-excite MLP (se_1, fm:253-260): s = sigmoid(W2 relu(W1 m + b1) + b2), m = pool/HW.
 // One block per sample.
-__global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ pool, float invHW,
+__global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ pool, int nparts, float invHW,
                                                     const float* __restrict__ W1, const float* __restrict__ b1,
                                                     const float* __restrict__ W2, const float* __restrict__ b2,
                                                     float* __restrict__ m, float* __restrict__ z1, float* __restrict__ s,
                                                     int C) {
     __shared__ float sm[256], sz[128];
     const int n = blockIdx.x, Ch = C / 2;
-    for (int c = threadIdx.x; c < C; c += 256) { sm[c] = pool[n * C + c] * invHW; m[n * C + c] = sm[c]; }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int r = 0; r < nparts; ++r) a += pool[((long long)n * nparts + r) * C + c];
+        sm[c] = a * invHW; m[n * C + c] = sm[c];
+    }
     __syncthreads();
     for (int j = threadIdx.x; j < Ch; j += 256) {
         float a = b1[j];
@@ -427,15 +435,16 @@ extern "C" int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, i
     return 0;
 }
 
+extern "C" int refid_dwconv_pool_parts(int h, int wd, int c) {
+    if (c != 16 && c != 32 && c != 64 && c != 128) return -1;
+    return blocks_for((long long)h * wd, 256 / (c / 4), 256);
+}
+
 extern "C" int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
                                         float* act, float* pool, int n, int h, int wd, int c, void* stream) {
     REFID_CHECK(in && w && b && pre && act && n > 0 && h > 0 && wd > 0, "dwconv3x3_gelu_fwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    if (pool) {
-        hipError_t e = hipMemsetAsync(pool, 0, sizeof(float) * n * c, st);
-        REFID_CHECK(e == hipSuccess, "dwconv3x3_gelu_fwd: memset failed: %s", hipGetErrorString(e));
-    }
-    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_fwd_kernel<LPP>, dim3(blocks_for((long long)h * wd, 256 / LPP, 256), n),
+    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_fwd_kernel<LPP>, dim3(refid_dwconv_pool_parts(h, wd, c), n),
                                        dim3(256), 0, st, in, ld_in, w, b, pre, act, pool, h, wd));
     REFID_LAUNCH_CHECK("dwconv3x3_gelu_fwd");
     return 0;
@@ -451,12 +460,13 @@ extern "C" int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, 
     return 0;
 }
 
-extern "C" int refid_se_fwd(const float* pool, float inv_hw, const float* w1, const float* b1, const float* w2,
-                            const float* b2, float* m, float* z1, float* s, int n, int c, void* stream) {
-    REFID_CHECK(pool && w1 && b1 && w2 && b2 && m && z1 && s && n > 0 && c > 0 && c <= 256 && c % 2 == 0,
+extern "C" int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const float* w1, const float* b1,
+                            const float* w2, const float* b2, float* m, float* z1, float* s, int n, int c,
+                            void* stream) {
+    REFID_CHECK(pool && w1 && b1 && w2 && b2 && m && z1 && s && n > 0 && n_parts > 0 && c > 0 && c <= 256 && c % 2 == 0,
                 "se_fwd: bad arguments (c=%d)", c);
-    hipLaunchKernelGGL(se_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pool, inv_hw, w1, b1, w2, b2, m, z1,
-                       s, c);
+    hipLaunchKernelGGL(se_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pool, n_parts, inv_hw, w1, b1, w2,
+                       b2, m, z1, s, c);
     REFID_LAUNCH_CHECK("se_fwd");
     return 0;
 }

@@ -1,0 +1,123 @@
+// Callers either side of the hot path (SURVEY.md section 8f "next" rows 1-3):
+//   * event voxelisation     basicsr/data/event_util.py:6-66  (events_to_voxel_grid)
+//   * validation tail        basicsr/utils/img_util.py:90-117 (tensor2img quantisation) +
+//                            basicsr/metrics/psnr_ssim.py:48-63 (calculate_psnr, float64 MSE)
+//   * tile overlap-averaging basicsr/models/twoImage_event_recurrent_model.py:252-268 (grids_inverse)
+// All HBM/atomic-bound streaming kernels.
+#include "common.h"
+
+namespace {
+
+// voxel[(ti) * H*W + y*W + x] += pol*(1-dt) ; voxel[(ti+1)...] += pol*dt   (bilinear in time)
+__global__ __launch_bounds__(256) void voxel_kernel(const double* __restrict__ ts, const int* __restrict__ xs,
+                                                   const int* __restrict__ ys, const float* __restrict__ ps,
+                                                   long long n, int bins, int W, int H, double first, double deltaT,
+                                                   float* __restrict__ voxel) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double t = (double)(bins - 1) * (ts[i] - first) / deltaT;       // event_util.py:36
+        const int ti = (int)t;                                                // astype(int): truncation
+        const double dt = t - (double)ti;
+        double pol = (double)ps[i];
+        if (pol == 0.0) pol = -1.0;                                           // event_util.py:41
+        const int x = xs[i], y = ys[i];
+        if (x < 0 || x >= W || y < 0 || y >= H) continue;
+        const long long base = (long long)y * W + x;
+        if (ti >= 0 && ti < bins) atomicAdd(voxel + (long long)ti * W * H + base, (float)(pol * (1.0 - dt)));
+        if (ti + 1 >= 0 && ti + 1 < bins) atomicAdd(voxel + (long long)(ti + 1) * W * H + base, (float)(pol * dt));
+    }
+}
+
+__device__ __forceinline__ float quant255(float v) {          // tensor2img: clamp [0,1], *255, round (half to even)
+    v = fminf(fmaxf(v, 0.f), 1.f);
+    return rintf(v * 255.f);
+}
+
+// sq[f] += sum over the frame of (q(a) - q(b))^2 ; grid = (chunks, frames)
+__global__ __launch_bounds__(256) void sqerr_u8_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      long long frame_elems, double* __restrict__ sq) {
+    __shared__ double sh[4];
+    const long long f = blockIdx.y;
+    const float* pa = a + f * frame_elems;
+    const float* pb = b + f * frame_elems;
+    double acc = 0.0;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < frame_elems; i += (long long)gridDim.x * 256) {
+        const float d = quant255(pa[i]) - quant255(pb[i]);
+        acc += (double)(d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sq + f, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// acc[c][i0+y][j0+x] += tile[c][y][x] ; cnt[i0+y][j0+x] += 1     (one tile)
+__global__ __launch_bounds__(256) void tile_add_kernel(const float* __restrict__ tile, float* __restrict__ acc,
+                                                      float* __restrict__ cnt, int C, int th, int tw, int H, int W,
+                                                      int i0, int j0) {
+    const long long total = (long long)C * th * tw;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int x = e % tw; long long r = e / tw;
+        const int y = r % th; const int c = r / th;
+        const long long d = ((long long)c * H + i0 + y) * W + j0 + x;
+        acc[d] += tile[e];
+        if (c == 0) cnt[(long long)(i0 + y) * W + j0 + x] += 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_norm_kernel(float* __restrict__ acc, const float* __restrict__ cnt, int C,
+                                                       long long HW) {
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < C * HW; e += (long long)gridDim.x * 256)
+        acc[e] /= cnt[e % HW];
+}
+
+int nb(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
+
+}  // namespace
+
+extern "C" int refid_events_to_voxel(const double* ts, const int* xs, const int* ys, const float* ps,
+                                     long long n_events, int num_bins, int width, int height, double first_stamp,
+                                     double last_stamp, float* voxel, void* stream) {
+    REFID_CHECK(ts && xs && ys && ps && voxel && n_events > 0 && num_bins > 0 && width > 0 && height > 0,
+                "events_to_voxel: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(voxel, 0, sizeof(float) * (size_t)num_bins * width * height, st);
+    REFID_CHECK(e == hipSuccess, "events_to_voxel: memset failed: %s", hipGetErrorString(e));
+    double deltaT = last_stamp - first_stamp;
+    if (deltaT == 0) deltaT = 1.0;                                            // event_util.py:33-34
+    hipLaunchKernelGGL(voxel_kernel, dim3(nb(n_events)), dim3(256), 0, st, ts, xs, ys, ps, n_events, num_bins, width,
+                       height, first_stamp, deltaT, voxel);
+    REFID_LAUNCH_CHECK("events_to_voxel");
+    return 0;
+}
+
+extern "C" int refid_sqerr_u8(const float* a, const float* b, int n_frames, long long frame_elems, double* sq,
+                              void* stream) {
+    REFID_CHECK(a && b && sq && n_frames > 0 && frame_elems > 0, "sqerr_u8: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sq, 0, sizeof(double) * n_frames, st);
+    REFID_CHECK(e == hipSuccess, "sqerr_u8: memset failed: %s", hipGetErrorString(e));
+    int chunks = nb(frame_elems);
+    if (chunks > 256) chunks = 256;
+    hipLaunchKernelGGL(sqerr_u8_kernel, dim3(chunks, n_frames), dim3(256), 0, st, a, b, frame_elems, sq);
+    REFID_LAUNCH_CHECK("sqerr_u8");
+    return 0;
+}
+
+extern "C" int refid_tile_add(const float* tile, float* acc, float* cnt, int c, int th, int tw, int h, int w, int i0,
+                              int j0, void* stream) {
+    REFID_CHECK(tile && acc && cnt && c > 0 && th > 0 && tw > 0 && i0 >= 0 && j0 >= 0 && i0 + th <= h && j0 + tw <= w,
+                "tile_add: tile (%d,%d)+(%d,%d) outside %dx%d", i0, j0, th, tw, h, w);
+    hipLaunchKernelGGL(tile_add_kernel, dim3(nb((long long)c * th * tw)), dim3(256), 0, (hipStream_t)stream, tile, acc,
+                       cnt, c, th, tw, h, w, i0, j0);
+    REFID_LAUNCH_CHECK("tile_add");
+    return 0;
+}
+
+extern "C" int refid_tile_normalize(float* acc, const float* cnt, int c, int h, int w, void* stream) {
+    REFID_CHECK(acc && cnt && c > 0 && h > 0 && w > 0, "tile_normalize: bad arguments");
+    hipLaunchKernelGGL(tile_norm_kernel, dim3(nb((long long)c * h * w)), dim3(256), 0, (hipStream_t)stream, acc, cnt, c,
+                       (long long)h * w);
+    REFID_LAUNCH_CHECK("tile_normalize");
+    return 0;
+}

@@ -394,8 +394,7 @@ class Engine:
         n, h, w, c = ev.shape
         ln_e = ops.layernorm2d_fwd(ev, A.p("norm1_e.weight"), A.p("norm1_e.bias"))
         c1e = A.conv1_e.fwd(ln_e)
-        pool = torch.empty((n, c), dtype=torch.float32, device=ev.device)
-        dwe, xe = ops.dwconv3x3_gelu_fwd(c1e, A.p("conv2_e.weight"), A.p("conv2_e.bias"), pool=pool)
+        dwe, xe, pool = ops.dwconv3x3_gelu_fwd(c1e, A.p("conv2_e.weight"), A.p("conv2_e.bias"), want_pool=True)
         m, z1, s = ops.se_fwd(pool, 1.0 / (h * w), A.p("se_1.1.weight"), A.p("se_1.1.bias"),
                               A.p("se_1.3.weight"), A.p("se_1.3.bias"))
         xs = ops.scale_cat(ip["xi"], xe, s)

@@ -254,15 +254,22 @@ def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, eps=1e-6):
     return gx
 
 
-def dwconv3x3_gelu_fwd(x, w, b, pool=None):
+def dwconv3x3_gelu_fwd(x, w, b, want_pool=False):
+    """Returns (pre, act) or (pre, act, pool_parts) with pool_parts (n, parts, c) per-workgroup sums of act."""
     px, ld = _nhwc(x, "x")
     n, h, wd, c = x.shape
     pre = torch.empty((n, h, wd, c), dtype=torch.float32, device=x.device)
     act = torch.empty_like(pre)
+    pool = None
+    if want_pool:
+        parts = lib().refid_dwconv_pool_parts(h, wd, c)
+        if parts <= 0:
+            raise _lib.RefidHipError(f"dwconv3x3: unsupported channel count {c}")
+        pool = torch.empty((n, parts, c), dtype=torch.float32, device=x.device)
     check(lib().refid_dwconv3x3_gelu_fwd(px, ld, _c(w, "w"), _c(b, "b"), pre.data_ptr(), act.data_ptr(),
                                          pool.data_ptr() if pool is not None else None, n, h, wd, c, _stream()),
           "refid_dwconv3x3_gelu_fwd")
-    return pre, act
+    return (pre, act, pool) if want_pool else (pre, act)
 
 
 def dwconv3x3_bwd(gd, x, w, dw, db):
@@ -275,11 +282,14 @@ def dwconv3x3_bwd(gd, x, w, dw, db):
 
 
 def se_fwd(pool, inv_hw, w1, b1, w2, b2):
-    n, c = pool.shape
-    m = torch.empty_like(pool)
+    """pool: (n, parts, c) partial sums (or (n, c))."""
+    if pool.dim() == 2:
+        pool = pool.unsqueeze(1)
+    n, parts, c = pool.shape
+    m = torch.empty((n, c), dtype=torch.float32, device=pool.device)
     z1 = torch.empty((n, c // 2), dtype=torch.float32, device=pool.device)
-    s = torch.empty_like(pool)
-    check(lib().refid_se_fwd(_c(pool, "pool"), inv_hw, _c(w1, "w1"), _c(b1, "b1"), _c(w2, "w2"), _c(b2, "b2"),
+    s = torch.empty_like(m)
+    check(lib().refid_se_fwd(_c(pool, "pool"), parts, inv_hw, _c(w1, "w1"), _c(b1, "b1"), _c(w2, "w2"), _c(b2, "b2"),
                              m.data_ptr(), z1.data_ptr(), s.data_ptr(), n, c, _stream()), "refid_se_fwd")
     return m, z1, s
 

@@ -65,11 +65,12 @@ def test_dwconv_gelu_fwd_bwd(C, H, W):
     pre = F.conv2d(x, w, b, 1, 1, 1, C)
     act = F.gelu(pre)
     xd = dev(x.detach().permute(0, 2, 3, 1))
-    pool = torch.empty(N, C, device="cuda")
-    pre_d, act_d = ops.dwconv3x3_gelu_fwd(xd, dev(w.detach()), dev(b.detach()), pool=pool)
+    pre_d, act_d, pool = ops.dwconv3x3_gelu_fwd(xd, dev(w.detach()), dev(b.detach()), want_pool=True)
     close(pre_d, pre.detach().permute(0, 2, 3, 1))
     close(act_d, act.detach().permute(0, 2, 3, 1))
-    close(pool, act.detach().sum((2, 3)), atol=1e-3)
+    close(pool.sum(1), act.detach().sum((2, 3)), atol=1e-3)
+    _, _, pool2 = ops.dwconv3x3_gelu_fwd(xd, dev(w.detach()), dev(b.detach()), want_pool=True)
+    assert torch.equal(pool, pool2)                      # deterministic (no atomics on the forward path)
     gd = rnd(N, C, H, W, seed=4)
     pre.backward(gd)
     dw = torch.zeros(C, 1, 3, 3, device="cuda"); db = torch.zeros(C, device="cuda")

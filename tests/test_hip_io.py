@@ -1,0 +1,122 @@
+"""GPU: voxelisation, PSNR tail and tiled inference against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refid_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["voxel_a", "voxel_b"])
+def test_voxelisation_kernel(golden_dir, name):
+    from refid_amd.data import events_to_voxel_grid, sliding_bin_pairs
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    bins, h, w = [int(v) for v in z["meta"]]
+    vox = events_to_voxel_grid(torch.from_numpy(z["events"]), bins, w, h)
+    # fp32 atomics add in a different order than np.add.at: round-off only
+    np.testing.assert_allclose(vox.cpu().numpy(), z["voxel"], rtol=1e-5, atol=2e-6)
+    pairs = sliding_bin_pairs(vox)
+    assert pairs.shape == (bins - 1, 2, h, w)
+    assert torch.equal(pairs[3, 0], vox[3]) and torch.equal(pairs[3, 1], vox[4])
+    # out-of-range coordinates are ignored, empty bins stay exactly zero
+    ev = torch.tensor([[0.0, -1, 0, 1], [0.5, 1, 1, 1], [1.0, 99, 0, 1]], dtype=torch.float64)
+    v = events_to_voxel_grid(ev, 3, 4, 3)
+    assert float(v.abs().sum()) == 1.0 and float(v[1, 1, 1]) == 1.0
+
+
+def test_psnr_tail():
+    from refid_amd.metrics import calculate_psnr_frames, split_deblur_interp
+    g = torch.Generator().manual_seed(0)
+    pred = torch.rand(2, 5, 3, 16, 24, generator=g) * 1.4 - 0.2            # exercises the clamp
+    gt = torch.rand(2, 5, 3, 16, 24, generator=g)
+    got = calculate_psnr_frames(pred.cuda(), gt.cuda())
+    ref = [O.psnr_u8(O.tensor2img_u8(pred[b, t]), O.tensor2img_u8(gt[b, t])) for b in range(2) for t in range(5)]
+    np.testing.assert_allclose(got, ref, rtol=1e-12)
+    assert calculate_psnr_frames(gt.cuda(), gt.cuda()) == [float("inf")] * 10
+    d, i = split_deblur_interp(got[:5], 2, 1)
+    assert abs(i - got[2]) < 1e-12 and abs(d - np.mean([got[0], got[1], got[3], got[4]])) < 1e-12
+
+
+def _net(img_chn, base=8, seed=3):
+    from refid_amd.archs import define_network
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=3,
+                              base_num_channels=base, num_block=1))
+    net.load_state_dict(P)
+    return net.cuda().eval(), P
+
+
+def test_tiled_inference():
+    from refid_amd.tiling import tiled_forward
+    net, P = _net(6)
+    x, ev, _ = O.make_inputs(1, 3, 48, 80, 6, seed=5)                       # 5-D sharp-VFI input
+    x, ev = x.cuda(), ev.cuda()
+    with torch.no_grad():
+        whole = net(x=x, event=ev)
+    # one tile covering the frame == whole-frame forward, exactly
+    one = tiled_forward(net, x, ev, crop=80)
+    assert torch.equal(one, whole)
+    # overlapping 32x32 tiles: every pixel covered, result finite and close to the whole-frame output in the
+    # tile interiors' average sense (the network's receptive field exceeds a tile: approximate by design)
+    til = tiled_forward(net, x, ev, crop=32, max_minibatch=2)
+    assert til.shape == whole.shape and bool(torch.isfinite(til).all())
+    # sharding tiles over two "ranks" and summing equals the single-rank result before normalisation
+    # (checked through the public API by normalising each shard's own accumulation is not possible; instead the
+    # rank partition must be a partition):
+    from refid_amd.tiling import grid_indices
+    idx, _, _ = grid_indices(48, 80, 32)
+    assert sorted(map(str, idx[0::2] + idx[1::2])) == sorted(map(str, idx))
+    # oracle check of the overlap-averaging itself (same tiles through the CPU oracle)
+    acc = torch.zeros_like(whole.cpu()); cnt = torch.zeros(1, 1, 1, 48, 80)
+    xc, ec = x.cpu(), ev.cpu()
+    with torch.no_grad():
+        for d in O.tile_grid(48, 80, 32):
+            i, j = d["i"], d["j"]
+            o = O.forward(P, xc[..., i:i + 32, j:j + 32], ec[..., i:i + 32, j:j + 32])
+            acc[..., i:i + 32, j:j + 32] += o
+            cnt[..., i:i + 32, j:j + 32] += 1
+    np.testing.assert_allclose(til.cpu().numpy(), (acc / cnt).numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_config4_sharp_vfi_512_inference():
+    """BASELINE config 4: 7-skip sharp-VFI, 512x512, T=7, img_chn=6, eval forward (full width)."""
+    from refid_amd.archs import define_network
+    P = O.make_params(6, mode="hash", seed=9)
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=6, ev_chn=2, num_encoders=3,
+                              base_num_channels=32, num_block=1, num_residual_blocks=2))
+    net.load_state_dict(P)
+    net = net.cuda().eval()
+    x, ev, _ = O.make_inputs(1, 7, 512, 512, 6, seed=9, mode="rng")
+    with torch.no_grad():
+        out = net(x=x.cuda(), event=ev.cuda())
+        ref = O.forward(P, x, ev)
+    assert out.shape == (1, 7, 3, 512, 512)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
+    assert abs(O.psnr_between(out.cpu(), ref)) > 100.0
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 shapes (B=8, 256x256, T=23, 26 channels): properties that need no oracle run --
+    samples are independent, so each sample of the batch equals the same sample run alone (bit exact),
+    and a B=1 crop of the same workload matches the oracle."""
+    from refid_amd.archs import define_network
+    P = O.make_params(26, mode="hash", seed=4)
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2, num_encoders=3,
+                              base_num_channels=32, num_block=1, num_residual_blocks=2))
+    net.load_state_dict(P)
+    net = net.cuda().eval()
+    x, ev, _ = O.make_inputs(8, 23, 256, 256, 26, seed=2, mode="rng")
+    x, ev = x.cuda(), ev.cuda()
+    with torch.no_grad():
+        full = net(x=x, event=ev)
+        assert full.shape == (8, 23, 3, 256, 256) and bool(torch.isfinite(full).all())
+        for b in (0, 5):
+            alone = net(x=x[b:b + 1], event=ev[b:b + 1])
+            assert torch.equal(alone[0], full[b])
+        # oracle on a bounded sample of the same workload: sample 3, first 4 steps of the event stream
+        ref = O.forward(P, x[3:4].cpu(), ev[3:4, :4].cpu())
+        got = net(x=x[3:4], event=ev[3:4, :4])
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)

@@ -120,6 +120,13 @@ typedef struct refid_wgrad_desc {
     int o_real;                                 /* rows of dw/db actually written (<= c_o); the
                                                    rest of g's channels is padding        */
     int algo;                                   /* 0 = direct; 1 = Winograd F(2x2,3x3) (3x3 stride 1) */
+    int phase;                                  /* 0 = partial products + reduction in one call;
+                                                   weights shared over the T recurrent steps can instead
+                                                   keep accumulating in their own `slabs`:
+                                                   1 = partial products, OVERWRITE slabs (first step),
+                                                   2 = partial products, ADD into slabs (later steps),
+                                                   3 = reduction of the slabs into dw/db only (after BPTT);
+                                                   the slab geometry depends on (c_o, i_total), not on c_a/c_b */
 } refid_wgrad_desc;
 
 size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d);

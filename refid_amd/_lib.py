@@ -43,6 +43,7 @@ class WgradDesc(C.Structure):
         ("n", C.c_int), ("h", C.c_int), ("w", C.c_int), ("ho", C.c_int), ("wo", C.c_int),
         ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("i_base", C.c_int), ("i_total", C.c_int), ("o_real", C.c_int), ("algo", C.c_int),
+        ("phase", C.c_int),
     ]
 
 

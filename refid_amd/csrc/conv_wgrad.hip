@@ -26,6 +26,7 @@ struct WgKArgs {
     int N, H, W, Ho, Wo, pad;
     int tilesX, tilesY, ntiles, nsplit;
     int CoP, CiP;
+    int accum;                 // add into the slabs instead of overwriting them
 };
 
 template <int KH_, int KW_, int S_, int TPW_, int SM_, int SN_, int WR_, int WC_, int WT_, int TH_, int TW_>
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
                     f32x4 v;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = acc[tt][sm][sn][4 * q + k];
-                    *reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci) = v;
+                    f32x4* dst = reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci);
+                    if (a.accum) v += *dst;
+                    *dst = v;
                 }
             }
     }
@@ -208,7 +211,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
         __syncthreads();
-        if (tid < C::COT) a.bslabs[(long long)split * a.CoP + co0 + tid] = sBias[tid];
+        if (tid < C::COT) {
+            float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
+            *dst = a.accum ? *dst + sBias[tid] : sBias[tid];
+        }
     }
 }
 
@@ -299,7 +305,8 @@ struct Geo { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
 Geo geo_of(const refid_wgrad_desc* d, const Plan& p) {
     Geo g;
     g.ncoT = cdiv(d->c_o, p.cot);
-    g.nciT = cdiv(d->c_a + d->c_b, p.cit);
+    const int ci_geo = (d->phase != 0) ? d->i_total - d->i_base : d->c_a + d->c_b;   // stable across steps
+    g.nciT = cdiv(ci_geo > d->c_a + d->c_b ? ci_geo : d->c_a + d->c_b, p.cit);
     g.tilesX = cdiv(d->wo, p.tw);
     g.tilesY = cdiv(d->ho, p.th);
     g.ntiles = g.tilesX * g.tilesY * d->n;
@@ -336,7 +343,7 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st);
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
     if (d->algo == 1) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
-    const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->c_a + d->c_b);
+    const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     if (!p.ok) return 0;
     const Geo g = geo_of(d, p);
     return ((size_t)g.nsplit * p.ntaps * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP) * sizeof(float);
@@ -345,7 +352,7 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
 extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     REFID_CHECK(d != nullptr, "wgrad: null descriptor");
-    const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->c_a + d->c_b);
+    const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     REFID_CHECK(p.ok, "wgrad: unsupported geometry k=%dx%d stride=%d", d->kh, d->kw, d->stride);
     REFID_CHECK(d->g && d->in_a && d->dw && d->slabs, "wgrad: null tensor pointer");
     REFID_CHECK(d->c_o > 0 && d->c_o % 4 == 0 && d->c_a > 0 && d->c_a % 4 == 0 && d->c_b >= 0 && d->c_b % 4 == 0,
@@ -371,8 +378,10 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pad = d->pad;
     a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
     a.CoP = g.CoP; a.CiP = g.CiP;
-    int rc = 1;
-    switch (p.id) {
+    a.accum = (d->phase == 2);
+    REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
+    int rc = (d->phase == 3) ? 0 : 1;
+    if (d->phase != 3) switch (p.id) {
         case P_W3: rc = launch_w<W3>(a, g, st); break;
         case P_W3_64x32: rc = launch_w<W3_64x32>(a, g, st); break;
         case P_W3_32x64: rc = launch_w<W3_32x64>(a, g, st); break;
@@ -384,12 +393,13 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
         default: break;
     }
     if (rc) return rc;
+    if (d->phase == 1 || d->phase == 2) return 0;          // reduction deferred (phase 3)
     RedArgs r;
     r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
     // channel-padded operands (e.g. 26 -> 28 image channels, 3 -> 4 output channels): only the
     // real rows / columns of the parameter-layout gradient exist
     r.nsplit = g.nsplit; r.ntaps = p.ntaps; r.Co = d->o_real;
-    r.Ci = a.Ctot < d->i_total - d->i_base ? a.Ctot : d->i_total - d->i_base;
+    r.Ci = (d->phase == 0 && a.Ctot < d->i_total - d->i_base) ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP;
     r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total4 = (long long)p.ntaps * g.CoP * (g.CiP / 4);

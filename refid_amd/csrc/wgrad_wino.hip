@@ -33,6 +33,7 @@ struct WwArgs {
     int N, H, W, Ho, Wo, pad;
     int tilesX, tilesY, ntiles, nsplit;
     int CoP, CiP;
+    int accum;
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
@@ -191,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
                 f32x4 vv;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) vv[k] = acc[j][sm][4 * qd + k];
-                *reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci) = vv;
+                f32x4* dst = reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci);
+                if (a.accum) vv += *dst;
+                *dst = vv;
             }
         }
     }
@@ -201,7 +204,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
         __syncthreads();
-        if (tid < COT) a.bslabs[(long long)split * a.CoP + co0 + tid] = sBias[tid];
+        if (tid < COT) {
+            float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
+            *dst = a.accum ? *dst + sBias[tid] : sBias[tid];
+        }
     }
 }
 
@@ -264,7 +270,8 @@ struct Geo { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
 Geo geo_of(const refid_wgrad_desc* d) {
     Geo g;
     g.ncoT = cdiv(d->c_o, COT);
-    g.nciT = cdiv(d->c_a + d->c_b, CIT);
+    const int ci_geo = (d->phase != 0) ? d->i_total - d->i_base : d->c_a + d->c_b;   // stable across steps
+    g.nciT = cdiv(ci_geo > d->c_a + d->c_b ? ci_geo : d->c_a + d->c_b, CIT);
     g.tilesX = cdiv(d->wo, TW);
     g.tilesY = cdiv(d->ho, TH);
     g.ntiles = g.tilesX * g.tilesY * d->n;
@@ -302,12 +309,16 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pad = d->pad;
     a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
     a.CoP = g.CoP; a.CiP = g.CiP;
-    hipLaunchKernelGGL(wgrad_wino_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS_BYTES, st, a);
-    REFID_LAUNCH_CHECK("wgrad_wino");
+    a.accum = (d->phase == 2);
+    if (d->phase != 3) {
+        hipLaunchKernelGGL(wgrad_wino_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS_BYTES, st, a);
+        REFID_LAUNCH_CHECK("wgrad_wino");
+    }
+    if (d->phase == 1 || d->phase == 2) return 0;          // reduction deferred (phase 3)
     WrArgs r;
     r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
     r.nsplit = g.nsplit; r.Co = d->o_real;
-    r.Ci = a.Ctot < d->i_total - d->i_base ? a.Ctot : d->i_total - d->i_base;
+    r.Ci = (d->phase == 0 && a.Ctot < d->i_total - d->i_base) ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP; r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total = (long long)r.Co * r.Ci;
     int groups = (int)(65536 / (total > 0 ? total : 1));

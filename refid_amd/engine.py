@@ -205,6 +205,11 @@ class ConvOp:
         self.b_eff = self.b
         if self.scale is not None and self.has_bias:
             self.b_eff = torch.empty_like(self.b)
+        # weight-gradient partial sums of the T recurrent steps accumulate in a private slab buffer
+        # and are reduced into the parameter gradient once per step (finish_wgrad)
+        self.wslab = None
+        self.w_calls = 0
+        self.w_last = None
 
     def repack(self):
         k = self.k
@@ -268,8 +273,21 @@ class ConvOp:
                 ops.colsum(g, self.gb)
             return
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci >= 32) else 0
+        self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
+                                      db=self.gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
+                                      slabs=self.wslab)
+        self.w_calls += 1
+        self.w_last = (g, a, b, algo)
+
+    def finish_wgrad(self):
+        """Reduce the accumulated slabs into the parameter gradient (once per step, after BPTT)."""
+        if self.w_calls == 0:
+            return
+        g, a, b, algo = self.w_last
         ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                         db=self.gb, i_total=self.ci, algo=algo)
+                         db=self.gb, i_total=self.ci, algo=algo, phase=3, slabs=self.wslab)
+        self.w_calls = 0
+        self.w_last = None
 
 
 class _Trunk:
@@ -365,6 +383,13 @@ class Engine:
             self.all_ops += [c1, c2]
         for d in self.dec:
             self.all_ops += [d["t2"]] + d["trunk"].ops()
+        self.early_ops = [self.pred]
+        for lv in self.enc_f:
+            self.early_ops += lv.ops()
+        for c1, c2 in self.res:
+            self.early_ops += [c1, c2]
+        for d in self.dec:
+            self.early_ops += [d["t2"]] + d["trunk"].ops()
         self.packed_version = -1
         self.param_version = 0
         self.ctx = None
@@ -667,6 +692,8 @@ class Engine:
         # forward-sweep, bottleneck, decoder and pred weights are final from here on -- except the
         # folded EGACA convs, un-folded now so the early bucket is complete
         self._egaca_img_bwd(self.enc_f[1].att, xb[0], g_xb[0], c["ip_f"])
+        for o in self.early_ops:
+            o.finish_wgrad()
         self._egaca_fold_back(self.enc_f[1].att)
         if grad_sync is not None:
             grad_sync("early")
@@ -687,7 +714,6 @@ class Engine:
 
         # ---------------- t-independent tails ----------------------------------------------------
         self._egaca_img_bwd(self.enc_b[1].att, xb[0], g_xb[0], c["ip_b"])
-        self._egaca_fold_back(self.enc_b[1].att)
         gz_e = ops.act_bwd(g_e, e_all, 0.2, out=g_e)
         self.head_ev.wgrad(gz_e, c["ev_in"])
         g = g_xb[2]
@@ -708,6 +734,9 @@ class Engine:
             else:
                 g = E["conv_1"].dgrad(g_c1, res=t1, mask=head, slope_mask=0.2)
         self.head_img.wgrad(g, c["x_in"])
+        for o in self.all_ops:
+            o.finish_wgrad()
+        self._egaca_fold_back(self.enc_b[1].att)
         if grad_sync is not None:
             grad_sync("late")
 

@@ -140,7 +140,10 @@ def _workspace(nbytes, device):
     return buf
 
 
-def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_base=0, i_total=None, algo=0):
+def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_base=0, i_total=None, algo=0,
+                 phase=0, slabs=None):
+    """phase 0: one-shot.  phase 1/2: partial products into the caller's persistent `slabs`
+    (overwrite / add); phase 3: reduce `slabs` into dw/db (see refid_wgrad_desc).  Returns `slabs`."""
     """dw (+)= wgrad, db (+)= sum g; dw in the reference layout (c_o, i_total, kh, kw)."""
     d = WgradDesc()
     d.g, d.ld_g = _nhwc(g, "g")
@@ -157,6 +160,7 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     d.i_total = i_total if i_total is not None else dw.shape[1]
     d.o_real = dw.shape[0]
     d.algo = algo
+    d.phase = phase
     if not dw.is_contiguous() or dw.dim() != 4 or dw.shape[1] != d.i_total or dw.shape[2:] != (kh, kw) \
             or d.o_real > d.c_o:
         raise _lib.RefidHipError(f"wgrad: dw shape {tuple(dw.shape)} does not match g/in channels "
@@ -166,11 +170,18 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     nbytes = lib().refid_wgrad_workspace_bytes(C.byref(d))
     if nbytes == 0:
         raise _lib.RefidHipError("wgrad: unsupported geometry")
-    ws = _workspace(nbytes, g.device)
+    if phase == 0:
+        ws = _workspace(nbytes, g.device)
+    else:
+        if slabs is None:
+            slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
+        elif slabs.numel() * 4 < nbytes:
+            raise _lib.RefidHipError("wgrad: persistent slab buffer too small for this geometry")
+        ws = slabs
     d.slabs = ws.data_ptr()
-    if PROFILE is None:
+    if PROFILE is None or phase == 3:
         check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
-        return
+        return slabs
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
@@ -178,6 +189,7 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
     PROFILE.append((("wgrad_wino_kernel+reduce" if algo == 1 else f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce"), flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None))))
+    return slabs
 
 
 def nchw_to_nhwc(src, c_pad=None, out=None):

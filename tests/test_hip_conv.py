@@ -362,3 +362,31 @@ def test_winograd_wgrad(cfg):
     scale = max(1.0, float(w.grad.abs().max()))
     np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
     np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
+
+
+@pytest.mark.parametrize("algo,cfg", [(0, (1, 16, 32, 64, 64, 64, 3)), (1, (1, 16, 32, 64, 64, 64, 3)),
+                                      (0, (2, 8, 16, 128, 0, 128, 1)), (0, (1, 16, 32, 64, 0, 64, 4))])
+def test_wgrad_slab_phases(algo, cfg):
+    """Persistent slabs: overwrite (1), add (2, here with the second source missing as at the first
+    recurrent step), reduce (3) == sum of the one-shot gradients."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co, k = cfg
+    s, p = (2, 1) if k == 4 else (1, k // 2)
+    Ho = (H + 2 * p - k) // s + 1
+    x = rnd(N, Ca + Cb, H, W, seed=1)
+    g1, g2 = rnd(N, Co, Ho, Ho * W // H, seed=2), rnd(N, Co, Ho, Ho * W // H, seed=3)
+    xa = nhwc(x[:, :Ca]); xb = nhwc(x[:, Ca:]) if Cb else None
+    ref = torch.zeros(Co, Ca + Cb, k, k, device="cuda"); rb = torch.zeros(Co, device="cuda")
+    ops.conv2d_wgrad(nhwc(g1), xa, ref, kh=k, kw=k, stride=s, pad=p, in_b=xb, db=rb, algo=algo)
+    ops.conv2d_wgrad(nhwc(g2), xa, ref, kh=k, kw=k, stride=s, pad=p, db=rb, algo=algo, i_total=Ca + Cb)
+    dw = torch.zeros_like(ref); db = torch.zeros_like(rb)
+    sl = ops.conv2d_wgrad(nhwc(g1), xa, dw, kh=k, kw=k, stride=s, pad=p, in_b=xb, db=db, algo=algo, phase=1,
+                          i_total=Ca + Cb)
+    ops.conv2d_wgrad(nhwc(g2), xa, dw, kh=k, kw=k, stride=s, pad=p, db=db, algo=algo, phase=2, slabs=sl,
+                     i_total=Ca + Cb)
+    assert float(dw.abs().max()) == 0.0                       # nothing reduced yet
+    ops.conv2d_wgrad(nhwc(g2), xa, dw, kh=k, kw=k, stride=s, pad=p, db=db, algo=algo, phase=3, slabs=sl,
+                     i_total=Ca + Cb)
+    scale = max(1.0, float(ref.abs().max()))
+    np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(db.cpu().numpy(), rb.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)

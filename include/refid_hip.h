@@ -244,6 +244,10 @@ int refid_events_to_voxel(const double* ts, const int* xs, const int* ys, const 
  * error of calculate_psnr (metrics/psnr_ssim.py:48-63): sq[f] = sum (q(a)-q(b))^2 per frame, float64. */
 int refid_sqerr_u8(const float* a, const float* b, int n_frames, long long frame_elems, double* sq,
                    void* stream);
+/* calculate_ssim -> _ssim_3d (metrics/psnr_ssim.py:135-182,225-303): separable 11^3 Gaussian (sigma 1.5,
+ * replicate padding) over (H, W, C=3) of the uint8-quantised frames, fp32; sum_out[f] = sum of the ssim
+ * map of frame f (divide by 3*h*w for the mean).  a, b: (n_frames, 3, h, w) in [0,1]. */
+int refid_ssim3d_u8(const float* a, const float* b, int n_frames, int h, int w, double* sum_out, void* stream);
 /* grids_inverse (twoImage_event_recurrent_model.py:252-268): acc[:, i0:i0+th, j0:j0+tw] += tile,
  * cnt += 1; then acc /= cnt. */
 int refid_tile_add(const float* tile, float* acc, float* cnt, int c, int th, int tw, int h, int w, int i0, int j0,

@@ -521,3 +521,29 @@ def tile_grid(h, w, crop):
             j = j + step_j
         i = i + step_i
     return idxes
+
+
+def ssim3d_u8(a: torch.Tensor, b: torch.Tensor) -> float:
+    """calculate_ssim -> _ssim_3d restated: metrics/psnr_ssim.py:135-182 (+ :283-290 max_value) on
+    tensor2img-quantised frames.  a, b: (3,H,W) float in [0,1].  (cv2.getGaussianKernel(11,1.5) =
+    normalised exp(-(i-5)^2/(2*1.5^2)); the reference runs the conv3d in fp32 on the GPU.)"""
+    import numpy as np
+    g = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2)); g = g / g.sum()
+    window = np.outer(g, g)
+    kernel = torch.tensor(np.stack([window * k for k in g], axis=0)).float()
+    conv3d = torch.nn.Conv3d(1, 1, (11, 11, 11), stride=1, padding=(5, 5, 5), bias=False, padding_mode="replicate")
+    conv3d.weight.requires_grad = False
+    conv3d.weight[0, 0] = kernel
+    img1 = tensor2img_u8(a).permute(1, 2, 0).float()          # HWC, values 0..255
+    img2 = tensor2img_u8(b).permute(1, 2, 0).float()
+    max_value = 1 if float(img1.max()) <= 1 else 255
+    C1, C2 = (0.01 * max_value) ** 2, (0.03 * max_value) ** 2
+    f = lambda t: conv3d(t.unsqueeze(0).unsqueeze(0)).squeeze(0).squeeze(0)   # noqa: E731
+    with torch.no_grad():
+        mu1, mu2 = f(img1), f(img2)
+        mu1_sq, mu2_sq, mu1_mu2 = mu1 ** 2, mu2 ** 2, mu1 * mu2
+        s1 = f(img1 ** 2) - mu1_sq
+        s2 = f(img2 ** 2) - mu2_sq
+        s12 = f(img1 * img2) - mu1_mu2
+        m = ((2 * mu1_mu2 + C1) * (2 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2))
+    return float(m.mean())

@@ -110,6 +110,7 @@ def _bind_extra(L):
     d = C.c_double
     L.refid_events_to_voxel.argtypes = [vp, vp, vp, vp, ll, i, i, i, d, d, vp, vp]
     L.refid_sqerr_u8.argtypes = [vp, vp, i, ll, vp, vp]
+    L.refid_ssim3d_u8.argtypes = [vp, vp, i, i, i, vp, vp]
     L.refid_tile_add.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     L.refid_tile_normalize.argtypes = [vp, vp, i, i, i, vp]
 

@@ -71,6 +71,70 @@ __global__ __launch_bounds__(256) void tile_norm_kernel(float* __restrict__ acc,
         acc[e] /= cnt[e % HW];
 }
 
+// ---- SSIM of the reference's _ssim_3d (metrics/psnr_ssim.py:135-182): 11x11x11 separable Gaussian
+// (sigma 1.5) over (H, W, C=3) with REPLICATE padding in all three axes, fp32, on the uint8-quantised
+// frames; ssim map mean over H*W*3.  One block = 16x16 output pixels x 3 channels.
+struct SsimConst { float g[11]; float mc[3][3]; };
+
+__global__ __launch_bounds__(256) void ssim3d_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    int H, int W, const SsimConst k, double* __restrict__ out) {
+    constexpr int T = 16, R = 5, HS = T + 2 * R;          // 26
+    __shared__ float sA[3][HS][HS + 1], sB[3][HS][HS + 1];
+    __shared__ float sH[5][3][HS][T + 1];
+    __shared__ double sred[4];
+    const int f = blockIdx.z;
+    const int y0 = blockIdx.y * T, x0 = blockIdx.x * T;
+    const float* pa = a + (long long)f * 3 * H * W;
+    const float* pb = b + (long long)f * 3 * H * W;
+    for (int e = threadIdx.x; e < 3 * HS * HS; e += 256) {
+        const int c = e / (HS * HS), r = (e / HS) % HS, q = e % HS;
+        const int y = min(max(y0 + r - R, 0), H - 1), x = min(max(x0 + q - R, 0), W - 1);   // replicate
+        sA[c][r][q] = quant255(pa[((long long)c * H + y) * W + x]);
+        sB[c][r][q] = quant255(pb[((long long)c * H + y) * W + x]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * HS * T; e += 256) {          // horizontal pass, 5 fields
+        const int c = e / (HS * T), r = (e / T) % HS, q = e % T;
+        float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const float va = sA[c][r][q + j], vb = sB[c][r][q + j], g = k.g[j];
+            m1 += g * va; m2 += g * vb; s11 += g * va * va; s22 += g * vb * vb; s12 += g * va * vb;
+        }
+        sH[0][c][r][q] = m1; sH[1][c][r][q] = m2; sH[2][c][r][q] = s11; sH[3][c][r][q] = s22; sH[4][c][r][q] = s12;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x / T, tx = threadIdx.x % T;
+    float v[5][3];
+#pragma unroll
+    for (int fi = 0; fi < 5; ++fi)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 11; ++j) s += k.g[j] * sH[fi][c][ty + j][tx];
+            v[fi][c] = s;
+        }
+    double acc = 0.0;
+    if (y0 + ty < H && x0 + tx < W) {
+        const float C1 = (0.01f * 255.f) * (0.01f * 255.f), C2 = (0.03f * 255.f) * (0.03f * 255.f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {                               // channel-axis pass (replicate-padded)
+            float w[5];
+#pragma unroll
+            for (int fi = 0; fi < 5; ++fi) w[fi] = k.mc[c][0] * v[fi][0] + k.mc[c][1] * v[fi][1] + k.mc[c][2] * v[fi][2];
+            const float mu1 = w[0], mu2 = w[1];
+            const float s1 = w[2] - mu1 * mu1, s2 = w[3] - mu2 * mu2, s12 = w[4] - mu1 * mu2;
+            acc += (double)(((2.f * mu1 * mu2 + C1) * (2.f * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + f, sred[0] + sred[1] + sred[2] + sred[3]);
+}
+
 int nb(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
 
 }  // namespace
@@ -119,5 +183,26 @@ extern "C" int refid_tile_normalize(float* acc, const float* cnt, int c, int h, 
     hipLaunchKernelGGL(tile_norm_kernel, dim3(nb((long long)c * h * w)), dim3(256), 0, (hipStream_t)stream, acc, cnt, c,
                        (long long)h * w);
     REFID_LAUNCH_CHECK("tile_normalize");
+    return 0;
+}
+
+extern "C" int refid_ssim3d_u8(const float* a, const float* b, int n_frames, int h, int w, double* sum_out,
+                               void* stream) {
+    REFID_CHECK(a && b && sum_out && n_frames > 0 && h > 0 && w > 0, "ssim3d_u8: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sum_out, 0, sizeof(double) * n_frames, st);
+    REFID_CHECK(e == hipSuccess, "ssim3d_u8: memset failed: %s", hipGetErrorString(e));
+    SsimConst k;
+    double g[11], s = 0.0;                                  // cv2.getGaussianKernel(11, 1.5)
+    for (int i = 0; i < 11; ++i) { g[i] = exp(-((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += g[i]; }
+    for (int i = 0; i < 11; ++i) { g[i] /= s; k.g[i] = (float)g[i]; }
+    for (int c = 0; c < 3; ++c) {                           // 11 taps along the 3-channel axis, replicate padding
+        double m[3] = {0, 0, 0};
+        for (int j = 0; j < 11; ++j) { int cc = c + j - 5; cc = cc < 0 ? 0 : (cc > 2 ? 2 : cc); m[cc] += g[j]; }
+        for (int q = 0; q < 3; ++q) k.mc[c][q] = (float)m[q];
+    }
+    dim3 grid(cdiv(w, 16), cdiv(h, 16), n_frames);
+    hipLaunchKernelGGL(ssim3d_kernel, grid, dim3(256), 0, st, a, b, h, w, k, sum_out);
+    REFID_LAUNCH_CHECK("ssim3d_u8");
     return 0;
 }

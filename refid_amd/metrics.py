@@ -30,6 +30,22 @@ def calculate_psnr_frames(pred, gt):
     return out
 
 
+def calculate_ssim_frames(pred, gt):
+    """The reference's calculate_ssim (3-D Gaussian variant, metrics/psnr_ssim.py:135-182,225-303) on the
+    uint8-quantised frames; pred, gt: (..., 3, H, W) float32 CUDA tensors.  Per-frame list."""
+    if pred.shape != gt.shape or pred.dim() < 3 or pred.shape[-3] != 3:
+        raise AssertionError(f"Image shapes are differnet: {tuple(pred.shape)}, {tuple(gt.shape)}.")
+    if not (pred.is_cuda and gt.is_cuda) or pred.dtype != torch.float32 or gt.dtype != torch.float32:
+        raise RefidHipError("calculate_ssim_frames: float32 CUDA tensors required")
+    pred, gt = pred.contiguous(), gt.contiguous()
+    h, w = pred.shape[-2], pred.shape[-1]
+    nf = pred.numel() // (3 * h * w)
+    acc = torch.empty(nf, dtype=torch.float64, device=pred.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib().refid_ssim3d_u8(pred.data_ptr(), gt.data_ptr(), nf, h, w, acc.data_ptr(), st), "refid_ssim3d_u8")
+    return [v / (3 * h * w) for v in acc.tolist()]
+
+
 def split_deblur_interp(psnrs, m, n):
     """Mean PSNR over 'interpolation' frames (index in [m, m+n)) and the rest ('deblur'), as the
     reference's validation does (twoImage_event_recurrent_model.py:426-507).  psnrs: per-frame list of

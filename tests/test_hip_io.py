@@ -40,6 +40,18 @@ def test_psnr_tail():
     assert abs(i - got[2]) < 1e-12 and abs(d - np.mean([got[0], got[1], got[3], got[4]])) < 1e-12
 
 
+def test_ssim_tail():
+    from refid_amd.metrics import calculate_ssim_frames
+    g = torch.Generator().manual_seed(1)
+    gt = torch.rand(3, 3, 40, 56, generator=g)
+    pred = (gt + 0.08 * torch.randn(3, 3, 40, 56, generator=g)).clamp(-0.1, 1.1)
+    got = calculate_ssim_frames(pred.cuda(), gt.cuda())
+    ref = [O.ssim3d_u8(pred[i], gt[i]) for i in range(3)]
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=2e-6)
+    same = calculate_ssim_frames(gt.cuda(), gt.cuda())
+    np.testing.assert_allclose(same, [1.0] * 3, rtol=0, atol=1e-6)
+
+
 def _net(img_chn, base=8, seed=3):
     from refid_amd.archs import define_network
     P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)

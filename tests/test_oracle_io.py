@@ -45,3 +45,16 @@ def test_tile_geometry_known_answers():
     for d in O.tile_grid(264, 520, 256):
         cover[d["i"]:d["i"] + 256, d["j"]:d["j"] + 256] += 1
     assert cover.min() >= 1
+
+
+def test_ssim_known_answers():
+    """No reference test pins calculate_ssim and it cannot be imported here (cv2 + CUDA): pin the
+    restatement with closed-form cases of the SSIM definition."""
+    import torch
+    a = torch.rand(3, 24, 24, generator=torch.Generator().manual_seed(0))
+    assert abs(O.ssim3d_u8(a, a) - 1.0) < 1e-6                           # identical images
+    c1 = torch.full((3, 24, 24), 100 / 255.0); c2 = torch.full((3, 24, 24), 140 / 255.0)
+    C1 = (0.01 * 255) ** 2                                               # constant images: variance terms vanish
+    expect = (2 * 100 * 140 + C1) / (100 ** 2 + 140 ** 2 + C1)
+    assert abs(O.ssim3d_u8(c1, c2) - expect) < 2e-3      # fp32 E[x^2]-mu^2 cancellation at x~100
+    assert O.ssim3d_u8(a, 1 - a) < 0.2                                    # anti-correlated

@@ -49,7 +49,7 @@ def options(args):
     return {
         "name": "bench", "is_train": True, "num_gpu": 1,
         "network_g": dict(type="FinalBidirectionAttenfusion", img_chn=args.img_chn, ev_chn=2, num_encoders=3,
-                          base_num_channels=32, num_block=1, num_residual_blocks=2),
+                          base_num_channels=32, num_block=1, num_residual_blocks=2, compute_dtype=args.dtype),
         "path": {"pretrain_network_g": None},
         "train": {"optim_g": dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.99]),
                   "scheduler": dict(type="TrueCosineAnnealingLR", T_max=200000, eta_min=1e-7),
@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", dest="cpu_frames", type=int, default=5, help="frames in the CPU-baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE configs[1] (headline); bf16 = config-3 style compute (bf16 MFMA operands)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,10 +166,13 @@ def main():
         # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
         # the SURVEY 8(d) direct-convolution figure beside it.
         executed = fl * (16.0 / 36.0) if "wino" in name else fl
+        peak = FP32_MFMA_PEAK_TFLOPS
+        if args.dtype == "bf16" and "wino" not in name and "wgrad" not in name:
+            peak = 2500.0                  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
         ach = executed / sec / 1e12
         conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None, "kernel": name, "launches": cnt,
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "launches": cnt,
                 "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
                 "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
@@ -181,9 +186,10 @@ def main():
             "metric": "interpolated frames/sec (train step) GoPro 256x256 11+1", "value": round(frames / dt, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": f"GoPro 11+1 blur-VFI train step, batch {args.batch}/GPU, {args.size}x{args.size}, "
-                                   f"T={args.T}, img_chn={args.img_chn}, fp32 (BASELINE configs[1])",
+                                   f"T={args.T}, img_chn={args.img_chn}, {args.dtype}" +
+                                   (" (BASELINE configs[1])" if args.dtype == "fp32" and args.T == 23 else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(loss, 6)},
         }
         if roof is not None:

@@ -82,7 +82,10 @@ typedef struct refid_conv_desc {
     float slope_pre, slope_post, slope_mask;
     int algo;                                   /* 0 = direct implicit GEMM; 1 = Winograd F(2x2,3x3)
                                                    (3x3, stride 1, mode 0 only; w_packed must come
-                                                   from the REFID_ROLE_WINO_* packings)          */
+                                                   from the REFID_ROLE_WINO_* packings);
+                                                   2 = direct tile with bf16 MFMA operands (fp32
+                                                   accumulate/epilogue/tensors; w_packed from
+                                                   refid_pack_conv_weights_bf16 with kc doubled)   */
 } refid_conv_desc;
 
 int refid_conv2d(const refid_conv_desc* d, void* stream);
@@ -154,6 +157,9 @@ int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int 
  * and the residual add run in the conv tile's epilogue. */
 int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* packed, int role, int o,
                                    int i, int kh, int kw, int kc, int bn, void* stream);
+/* bf16 copy of the same packed layout (RNE), kc = 2 * refid_conv_kc(...); oscale may be NULL. */
+int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* packed_bf16, int role, int o, int i,
+                                 int kh, int kw, int kc, int bn, void* stream);
 int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
 /* After BPTT, turn the gradients accumulated for the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r])
  * back into gradients of (W, b, scale):  dscale[r] += <W[r,:],G[r,:]> + b[r]*gb[r];

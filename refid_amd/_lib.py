@@ -89,6 +89,7 @@ def _bind_extra(L):
     """EGACA / train-step entry points (a stale .so without them fails loudly here)."""
     vp, i, f, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
     L.refid_pack_conv_weights_scaled.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
+    L.refid_pack_conv_weights_bf16.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
     L.refid_fold_back.argtypes = [vp] * 6 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]

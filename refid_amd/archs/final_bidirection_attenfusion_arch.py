@@ -38,8 +38,15 @@ class _HipForward(torch.autograd.Function):
 class FinalBidirectionAttenfusion(nn.Module):
     def __init__(self, img_chn, ev_chn, out_chn=3, skip_type='sum', recurrent_block_type='convlstm',
                  activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,
-                 use_recurrent_upsample_conv=True, num_block=3, use_first_dcn=False, use_reversed_voxel=False):
+                 use_recurrent_upsample_conv=True, num_block=3, use_first_dcn=False, use_reversed_voxel=False,
+                 compute_dtype='fp32'):
+        """compute_dtype (extension, keyword-only in practice; YAML: network_g.compute_dtype): 'fp32'
+        (default, the reference's arithmetic) or 'bf16' (BASELINE config 3: bf16 matrix-core operands for
+        the conv forward / input gradients, fp32 everything else)."""
         super().__init__()
+        if compute_dtype not in ('fp32', 'bf16'):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         assert ev_chn > 0 and img_chn > 0 and out_chn > 0                      # arch:45-47
         unsupported = []
         if num_encoders != 3:
@@ -121,7 +128,7 @@ class FinalBidirectionAttenfusion(nn.Module):
                 all(p.data_ptr() == self._engine.arena.p(k).data_ptr() for k, p in self._params.items()):
             return
         eng = Engine(self.img_chn, self.ev_chn, self.out_chn, self.base_num_channels, self.num_residual_blocks,
-                     device=dev)
+                     device=dev, compute_dtype=self.compute_dtype)
         with torch.no_grad():
             for k, p in self._params.items():
                 if p.dtype != torch.float32:

@@ -57,8 +57,17 @@ struct Cfg {
     static_assert(256 % NQ == 0, "thread -> channel-quad mapping must be static");
 };
 
-template <class C>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// BF = true: bf16 MFMA operands (v_mfma_f32_32x32x16_bf16), fp32 accumulate / epilogue / tensors.
+// A 16-byte LDS slot then holds 8 bf16 channels instead of 4 fp32 ones, so a K chunk is 16*NSUB
+// channels; activations are converted while they are staged (v_cvt_pk_bf16_f32, RNE), the packed
+// weights are already bf16.  Everything else (halo reuse, two-source input, fused epilogue) is shared.
+template <class C, bool BF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
+    constexpr int CPQ = BF ? 8 : 4;                 // channels per 16-byte slot
+    constexpr int KCC = C::NQ * CPQ;                // channels per K chunk
+    constexpr int AV = BF ? 2 : 1;                  // float4 global loads per activation slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sA = reinterpret_cast<f32x4*>(smem);
     f32x4* sB = sA + C::A_TOTAL;
@@ -91,24 +100,30 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         const bool ok = (hp < C::HP) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         apix[it] = ok ? ((long long)(n * a.H + iy) * a.W + ix) : -1;
     }
-    const float* wbase = a.w + (long long)cls * a.wClsStride;
+    const float* wbase = reinterpret_cast<const float*>(
+        reinterpret_cast<const char*>(a.w) + (long long)cls * a.wClsStride * (BF ? 2 : 4));
 
-    f32x4 ra[C::A_ITEMS], rb[C::B_ITEMS];
+    f32x4 ra[C::A_ITEMS * AV], rb[C::B_ITEMS];
 
     auto load_chunk = [&](int ch) {
-        const int c = ch * C::KC + q * 4;
+        const int c = ch * KCC + q * CPQ;
         const bool fromA = c < a.Ca;
         const float* src = fromA ? a.inA : a.inB;
         const int ld = fromA ? a.ldA : a.ldB;
         const int cc = fromA ? c : c - a.Ca;
-        const bool cok = c < a.Ctot;
 #pragma unroll
         for (int it = 0; it < C::A_ITEMS; ++it) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (cok && apix[it] >= 0) v = *reinterpret_cast<const f32x4*>(src + apix[it] * ld + cc);
-            ra[it] = v;
+#pragma unroll
+            for (int v4 = 0; v4 < AV; ++v4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c + 4 * v4 < a.Ctot && apix[it] >= 0)
+                    v = *reinterpret_cast<const f32x4*>(src + apix[it] * ld + cc + 4 * v4);
+                ra[it * AV + v4] = v;
+            }
         }
-        const float* wc = wbase + (long long)ch * (C::NTAPS * a.CoutPad * C::KC);
+        // packed weights: [chunk][tap][CoutPad][KCC] in fp32 (BF: bf16) -> a 16-byte slot per (row, q)
+        const char* wc = reinterpret_cast<const char*>(wbase) +
+                         (long long)ch * C::NTAPS * a.CoutPad * C::NQ * 16;
 #pragma unroll
         for (int it = 0; it < C::B_ITEMS; ++it) {
             const int r = tid / C::NQ + it * (256 / C::NQ);
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (r < C::NTAPS * C::BN && a.coBase + n0 + co < a.CoutPad)
                 v = *reinterpret_cast<const f32x4*>(
-                    wc + ((long long)(tap * a.CoutPad + a.coBase + n0 + co)) * C::KC + q * 4);
+                    wc + (((long long)(tap * a.CoutPad + a.coBase + n0 + co)) * C::NQ + q) * 16);
             rb[it] = v;
         }
     };
@@ -124,7 +139,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int it = 0; it < C::A_ITEMS; ++it) {
             const int hp = tid / C::NQ + it * (256 / C::NQ);
-            if (hp < C::HP) sA[q * C::HP + hp] = ra[it];
+            if (hp < C::HP) {
+                if constexpr (BF) {
+                    bf16x8 hv;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { hv[k] = (__bf16)ra[it * 2][k]; hv[4 + k] = (__bf16)ra[it * 2 + 1][k]; }
+                    sA[q * C::HP + hp] = __builtin_bit_cast(f32x4, hv);
+                } else {
+                    sA[q * C::HP + hp] = ra[it];
+                }
+            }
         }
 #pragma unroll
         for (int it = 0; it < C::B_ITEMS; ++it) {
@@ -180,14 +204,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 for (int m = 0; m < C::MT; ++m) af[m] = pA[hpb[m] + toff];
 #pragma unroll
                 for (int nn = 0; nn < C::NT; ++nn) bf[nn] = pB[t * C::BN + nn * 32];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+                if constexpr (BF) {
 #pragma unroll
                     for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                         for (int nn = 0; nn < C::NT; ++nn)
-                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nn][kk], af[m][kk],
-                                                                             acc[m][nn], 0, 0, 0);
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, bf[nn]), __builtin_bit_cast(bf16x8, af[m]), acc[m][nn], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                            for (int nn = 0; nn < C::NT; ++nn)
+                                acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[nn][kk], af[m][kk],
+                                                                                 acc[m][nn], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -259,11 +292,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
 }
 
-template <class C>
-int launch(const ConvKArgs& ka, int ncls, hipStream_t st) {
+template <class C, bool BF>
+int launch_t(const ConvKArgs& ka, int ncls, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<C, BF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         if (e != hipSuccess) { refid_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return 2; }
         attr_set = true;
@@ -271,11 +304,16 @@ int launch(const ConvKArgs& ka, int ncls, hipStream_t st) {
     ConvKArgs a = ka;
     a.tilesX = cdiv(a.Wo, C::TW);
     a.tilesY = cdiv(a.Ho, C::TH);
-    a.nchunks = cdiv(a.Ctot, C::KC);
+    a.nchunks = cdiv(a.Ctot, C::KC * (BF ? 2 : 1));
     dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, C::BN), ncls);
-    hipLaunchKernelGGL(conv_igemm_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<C, BF>), grid, dim3(256), C::LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_igemm");
     return 0;
+}
+
+template <class C>
+int launch(const ConvKArgs& ka, int ncls, hipStream_t st) {
+    return ka.bf16 ? launch_t<C, true>(ka, ncls, st) : launch_t<C, false>(ka, ncls, st);
 }
 
 // tile families: <KH,KW,S, WM,WN,MT,NT, NSUB, MODE>
@@ -360,8 +398,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     REFID_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
-    REFID_CHECK(d->algo == 0 || (d->algo == 1 && f == F_3x3), "conv2d: algo %d needs a 3x3 stride-1 mode-0 conv",
-                d->algo);
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3),
+                "conv2d: algo %d needs a 3x3 stride-1 mode-0 conv", d->algo);
+    REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
     REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
                 "conv2d: rows [%d, %d) exceed the packed weight's %d rows", d->co_base, d->co_base + d->cout,
@@ -390,7 +429,8 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     a.vecOK = al16(d->out) && d->ld_out % 4 == 0 && (!d->res || (al16(d->res) && d->ld_res % 4 == 0)) &&
               (!d->mask || (al16(d->mask) && d->ld_mask % 4 == 0)) && (!d->bias || al16(d->bias)) &&
               d->co_base % 4 == 0 && (d->mode != 1 || (d->cout / 4) % 4 == 0);
-    const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode);
+    a.bf16 = (d->algo == 2);
+    const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode) * (a.bf16 ? 2 : 1);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
     if (d->algo == 1) {
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");

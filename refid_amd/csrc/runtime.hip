@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const f32x4* __restrict__ 
 struct PackArgs {
     const float* w; float* dst; const float* oscale;   // oscale: optional per-output-channel factor
     int role, O, I, KH, KW, KC, rows, rowsPad, K, nchunks, ntaps, ncls;
+    int bf16;                  // write __bf16 (RNE) instead of float
 };
 
 __device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap, int row, int k) {
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs p) {
         const int k = chunk * p.KC + kk;
         float v = 0.f;
         if (row < p.rows && k < p.K) v = pack_fetch(p, cls, tap, row, k);
-        p.dst[e] = v;
+        if (p.bf16) reinterpret_cast<__bf16*>(p.dst)[e] = (__bf16)v;
+        else p.dst[e] = v;
     }
 }
 
@@ -192,6 +194,20 @@ extern "C" int refid_pack_conv_weights(const float* w, float* packed, int role, 
     return pack_impl(w, nullptr, packed, role, o, i, kh, kw, kc, bn, stream);
 }
 
+extern "C" int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* packed_bf16, int role, int o,
+                                            int i, int kh, int kw, int kc, int bn, void* stream) {
+    // same layout with bf16 elements (kc = twice the fp32 tile's chunk); used by refid_conv2d algo 2
+    PackArgs p;
+    REFID_CHECK(w && packed_bf16, "pack_bf16: null pointer");
+    REFID_CHECK(role != REFID_ROLE_WINO_FWD && role != REFID_ROLE_WINO_DGRAD, "pack_bf16: no Winograd roles");
+    REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack_bf16: unknown role %d", role);
+    p.w = w; p.dst = reinterpret_cast<float*>(packed_bf16); p.oscale = oscale; p.bf16 = 1;
+    const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    REFID_LAUNCH_CHECK("pack_conv_weights_bf16");
+    return 0;
+}
+
 extern "C" int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* packed, int role, int o,
                                               int i, int kh, int kw, int kc, int bn, void* stream) {
     REFID_CHECK(role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD || role == REFID_ROLE_WINO_FWD ||
@@ -203,6 +219,7 @@ static int pack_impl(const float* w, const float* oscale, float* packed, int rol
                      int kw, int kc, int bn, void* stream) {
     PackArgs p;
     p.oscale = oscale;
+    p.bf16 = 0;
     REFID_CHECK(w && packed, "pack: null pointer");
     REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack: unknown role %d", role);
     REFID_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),

@@ -140,8 +140,9 @@ USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
 class ConvOp:
     """One convolution of the network: geometry + packed weights + the three kernels."""
 
-    def __init__(self, arena, name, kind="conv", need_dgrad=True, scale_name=None):
+    def __init__(self, arena, name, kind="conv", need_dgrad=True, scale_name=None, bf16=False):
         self.arena, self.name, self.kind = arena, name, kind
+        self.bf16 = bf16
         self.w = arena.p(name + ".weight")
         self.gw = arena.g(name + ".weight")
         self.has_bias = (name + ".bias") in arena.shapes
@@ -180,14 +181,20 @@ class ConvOp:
         self.f_kc = ops.conv_kc(kh, kw, st, md)
         self.f_bn = ops.conv_bn(kh, kw, st, md, self.f_rows)
         self.f_algo = self.d_algo = 0
-        if USE_WINOGRAD and kind == "conv" and k == 3:
+        if bf16:
+            # bf16 MFMA operands on the direct tile (fp32 accumulate / epilogue / tensors); no Winograd:
+            # its transforms would amplify the operand rounding, and bf16 MFMA is 16x the fp32 rate anyway
+            self.f_algo = self.d_algo = 2
+            self.f_kc *= 2
+        elif USE_WINOGRAD and kind == "conv" and k == 3:
             if self.co >= 16:                  # pred (3 channels) stays on the direct tile
                 self.f_algo, self.f_role, self.f_kc, self.f_bn = 1, ops.ROLE_WINO_FWD, 8, 64
             self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
         self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
         dev = self.w.device
+        pdt = torch.bfloat16 if bf16 else torch.float32
         self.wp = torch.empty(ops.packed_weight_floats(self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci),
-                              dtype=torch.float32, device=dev)
+                              dtype=pdt, device=dev)
         self.wd = None
         self.d_bn_cache = {}
         if need_dgrad:
@@ -199,9 +206,11 @@ class ConvOp:
                 self.d_bn = ops.conv_bn(kh, kw, st, md, self.co)     # issued as two halves of co rows
             if self.d_algo == 1:
                 self.d_kc, self.d_bn = 8, 64
+            if bf16:
+                self.d_kc *= 2
             self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
             self.wd = torch.empty(ops.packed_weight_floats(self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci),
-                                  dtype=torch.float32, device=dev)
+                                  dtype=pdt, device=dev)
         self.b_eff = self.b
         if self.scale is not None and self.has_bias:
             self.b_eff = torch.empty_like(self.b)
@@ -213,11 +222,10 @@ class ConvOp:
 
     def repack(self):
         k = self.k
-        ops.pack_conv_weights(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp,
-                              oscale=self.scale)
+        pack = ops.pack_conv_weights_bf16 if self.bf16 else ops.pack_conv_weights
+        pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp, oscale=self.scale)
         if self.wd is not None:
-            ops.pack_conv_weights(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd,
-                                  oscale=self.scale)
+            pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd, oscale=self.scale)
         if self.scale is not None and self.has_bias:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 
@@ -291,10 +299,10 @@ class ConvOp:
 
 
 class _Trunk:
-    def __init__(self, arena, prefix):
-        self.c0 = ConvOp(arena, prefix + ".0")
-        self.c1 = ConvOp(arena, prefix + ".2.0.conv1")
-        self.c2 = ConvOp(arena, prefix + ".2.0.conv2")
+    def __init__(self, arena, prefix, bf16=False):
+        self.c0 = ConvOp(arena, prefix + ".0", bf16=bf16)
+        self.c1 = ConvOp(arena, prefix + ".2.0.conv1", bf16=bf16)
+        self.c2 = ConvOp(arena, prefix + ".2.0.conv2", bf16=bf16)
         self.C = self.c0.co
 
     def ops(self):
@@ -302,15 +310,15 @@ class _Trunk:
 
 
 class _Egaca:
-    def __init__(self, arena, a):
+    def __init__(self, arena, a, bf16=False):
         self.a = a
         P, G = arena.p, arena.g
-        self.conv1 = ConvOp(arena, a + ".conv1")
-        self.conv1_e = ConvOp(arena, a + ".conv1_e")
-        self.conv3 = ConvOp(arena, a + ".conv3", scale_name=a + ".beta")
-        self.conv4 = ConvOp(arena, a + ".conv4")
-        self.conv5 = ConvOp(arena, a + ".conv5", scale_name=a + ".gamma")
-        self.side = ConvOp(arena, a + ".conv_y_side")
+        self.conv1 = ConvOp(arena, a + ".conv1", bf16=bf16)
+        self.conv1_e = ConvOp(arena, a + ".conv1_e", bf16=bf16)
+        self.conv3 = ConvOp(arena, a + ".conv3", scale_name=a + ".beta", bf16=bf16)
+        self.conv4 = ConvOp(arena, a + ".conv4", bf16=bf16)
+        self.conv5 = ConvOp(arena, a + ".conv5", scale_name=a + ".gamma", bf16=bf16)
+        self.side = ConvOp(arena, a + ".conv_y_side", bf16=bf16)
         self.c = self.conv1.ci
         self.names = {n: (P(f"{a}.{n}"), G(f"{a}.{n}")) for n in (
             "norm1.weight", "norm1.bias", "norm1_e.weight", "norm1_e.bias", "norm2.weight", "norm2.bias",
@@ -328,13 +336,13 @@ class _Egaca:
 
 
 class _EvrLevel:
-    def __init__(self, arena, prefix, level, fuse, dead_down=False):
+    def __init__(self, arena, prefix, level, fuse, dead_down=False, bf16=False):
         self.level = level
-        self.conv = ConvOp(arena, prefix + ".conv.conv2d") if level != 1 else None
-        self.att = _Egaca(arena, prefix + ".atten_fuse") if level == 1 else None
-        self.trunk = _Trunk(arena, prefix + ".recurrent_block.forward_trunk.main")
-        self.fuse = ConvOp(arena, prefix + ".fuse_two_dir.conv2d") if fuse else None
-        self.down = None if dead_down else ConvOp(arena, prefix + ".down", kind="down")
+        self.conv = ConvOp(arena, prefix + ".conv.conv2d", bf16=bf16) if level != 1 else None
+        self.att = _Egaca(arena, prefix + ".atten_fuse", bf16=bf16) if level == 1 else None
+        self.trunk = _Trunk(arena, prefix + ".recurrent_block.forward_trunk.main", bf16=bf16)
+        self.fuse = ConvOp(arena, prefix + ".fuse_two_dir.conv2d", bf16=bf16) if fuse else None
+        self.down = None if dead_down else ConvOp(arena, prefix + ".down", kind="down", bf16=bf16)
         self.C = self.trunk.C
 
     def ops(self):
@@ -350,30 +358,39 @@ class _EvrLevel:
 class Engine:
     """Forward + BPTT backward of FinalBidirectionAttenfusion on one GPU."""
 
-    def __init__(self, img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, device="cuda"):
+    def __init__(self, img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, device="cuda",
+                 compute_dtype="fp32"):
         if base % 8 != 0:
             raise ValueError("base_num_channels must be a multiple of 8")
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        # "bf16": BASELINE config 3 -- conv forward / input-gradient operands in bf16 on the matrix cores,
+        # fp32 accumulation, fp32 master weights, activations, weight gradients, loss, grad-norm, optimizer
+        self.compute_dtype = compute_dtype
+        bf = compute_dtype == "bf16"
         self.img_chn, self.ev_chn, self.out_chn, self.base = img_chn, ev_chn, out_chn, base
         self.nres = num_residual_blocks
         self.device = torch.device(device)
         self.shapes = param_shapes(img_chn, ev_chn, out_chn, base, num_residual_blocks)
         self.arena = A = ParamArena(self.shapes, self.device)
-        self.head_ev = ConvOp(A, "head.conv2d", need_dgrad=False)
-        self.head_img = ConvOp(A, "head_img.conv2d", need_dgrad=False)
-        self.enc_b = [_EvrLevel(A, f"encoders_backward.{i}", i, False, dead_down=(i == 2)) for i in range(3)]
-        self.enc_f = [_EvrLevel(A, f"encoders_forward.{i}", i, True) for i in range(3)]
+        self.head_ev = ConvOp(A, "head.conv2d", need_dgrad=False, bf16=bf)
+        self.head_img = ConvOp(A, "head_img.conv2d", need_dgrad=False, bf16=bf)
+        self.enc_b = [_EvrLevel(A, f"encoders_backward.{i}", i, False, dead_down=(i == 2), bf16=bf) for i in range(3)]
+        self.enc_f = [_EvrLevel(A, f"encoders_forward.{i}", i, True, bf16=bf) for i in range(3)]
         self.img = []
         for i in range(3):
             p = f"img_encoders.{i}"
-            self.img.append(dict(identity=ConvOp(A, p + ".identity"), conv_1=ConvOp(A, p + ".conv_1"),
-                                 conv_2=ConvOp(A, p + ".conv_2"), down=ConvOp(A, p + ".down", kind="down")))
-        self.res = [(ConvOp(A, f"resblocks.{i}.conv1"), ConvOp(A, f"resblocks.{i}.conv2")) for i in range(self.nres)]
+            self.img.append(dict(identity=ConvOp(A, p + ".identity", bf16=bf), conv_1=ConvOp(A, p + ".conv_1", bf16=bf),
+                                 conv_2=ConvOp(A, p + ".conv_2", bf16=bf),
+                                 down=ConvOp(A, p + ".down", kind="down", bf16=bf)))
+        self.res = [(ConvOp(A, f"resblocks.{i}.conv1", bf16=bf), ConvOp(A, f"resblocks.{i}.conv2", bf16=bf))
+                    for i in range(self.nres)]
         self.dec = []
         for j in range(3):
             p = f"decoders.{j}"
-            self.dec.append(dict(t2=ConvOp(A, p + ".transposed_conv2d", kind="convT"),
-                                 trunk=_Trunk(A, p + ".forward_trunk.main")))
-        self.pred = ConvOp(A, "pred.conv2d")
+            self.dec.append(dict(t2=ConvOp(A, p + ".transposed_conv2d", kind="convT", bf16=bf),
+                                 trunk=_Trunk(A, p + ".forward_trunk.main", bf16=bf)))
+        self.pred = ConvOp(A, "pred.conv2d", bf16=bf)
         self.all_ops = [self.head_ev, self.head_img, self.pred]
         for lv in self.enc_b + self.enc_f:
             self.all_ops += lv.ops()

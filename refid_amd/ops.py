@@ -76,6 +76,20 @@ def pack_conv_weights(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None):
     return out
 
 
+def pack_conv_weights_bf16(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None):
+    """bf16 packed weights for conv2d(algo=2); kc = 2 * conv_kc(...)."""
+    L = lib()
+    n = L.refid_packed_weight_floats(role, o, i, kh, kw, kc, bn)
+    if n == 0:
+        raise _lib.RefidHipError("pack_conv_weights_bf16: bad geometry")
+    if out is None:
+        out = torch.empty(n, dtype=torch.bfloat16, device=w.device)
+    check(L.refid_pack_conv_weights_bf16(w.data_ptr(), oscale.data_ptr() if oscale is not None else None,
+                                         out.data_ptr(), role, o, i, kh, kw, kc, bn, _stream()),
+          "refid_pack_conv_weights_bf16")
+    return out
+
+
 def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_pad, co_base=0,
            in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0):
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc."""

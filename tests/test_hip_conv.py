@@ -390,3 +390,71 @@ def test_wgrad_slab_phases(algo, cfg):
     scale = max(1.0, float(ref.abs().max()))
     np.testing.assert_allclose(dw.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
     np.testing.assert_allclose(db.cpu().numpy(), rb.cpu().numpy(), rtol=1e-4, atol=2e-5 * scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16-operand direct tile (algo=2): operands rounded to bf16 (RNE), products/accumulation in fp32
+# ---------------------------------------------------------------------------------------------
+def _bf(t):
+    return t.float().bfloat16().double()
+
+
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co, k, s, p, mode
+    (2, 16, 32, 32, 0, 64, 3, 1, 1, 0), (1, 24, 40, 64, 64, 64, 3, 1, 1, 0), (1, 8, 8, 128, 128, 128, 3, 1, 1, 0),
+    (1, 12, 20, 64, 0, 256, 3, 1, 1, 0), (2, 16, 16, 32, 32, 32, 3, 1, 1, 0), (1, 16, 32, 32, 0, 3, 3, 1, 1, 0),
+    (1, 16, 24, 4, 0, 32, 5, 1, 2, 0), (1, 16, 24, 28, 0, 32, 5, 1, 2, 0), (2, 8, 16, 64, 64, 64, 1, 1, 0, 0),
+    (1, 16, 16, 32, 0, 64, 1, 1, 0, 0), (2, 16, 32, 64, 0, 64, 4, 2, 1, 0), (1, 16, 16, 32, 0, 64, 2, 2, 0, 0),
+])
+def test_bf16_tile_forward(cfg):
+    ops = _ops()
+    N, H, W, Ca, Cb, Co, k, s, p, mode = cfg
+    Ci = Ca + Cb
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=1.0 / np.sqrt(Ci * k * k))
+    b = rnd(Co, seed=3)
+    r = None
+    ref = lrelu(F.conv2d(_bf(x), _bf(w), b, s, p), 0.1)
+    kc, bn = 2 * ops.conv_kc(k, k, s), ops.conv_bn(k, k, s, 0, Co)
+    wp = ops.pack_conv_weights_bf16(w.float().cuda(), ops.ROLE_FWD, bn, kc, k, k, Co, Ci)
+    Cop = -(-Co // 4) * 4
+    outbuf = torch.zeros(N, ref.shape[2], ref.shape[3], Cop, device="cuda")
+    out = outbuf[..., :Co]
+    ops.conv2d(nhwc(x[:, :Ca]), wp, out, kh=k, kw=k, stride=s, pad=p, cout=Co, cout_pad=-(-Co // bn) * bn,
+               in_b=nhwc(x[:, Ca:]) if Cb else None, bias=b.float().cuda(), slope_pre=0.1, algo=2)
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_bf16_tile_dgrad_and_special_modes():
+    ops = _ops()
+    # stride-1 dgrad
+    N, H, W, Ci, Co = 1, 8, 24, 128, 64
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
+    g = rnd(N, Co, H, W, seed=3)
+    F.conv2d(x, _bf(w), None, 1, 1).backward(_bf(g))
+    wd = ops.pack_conv_weights_bf16(w.float().cuda(), ops.ROLE_DGRAD, 128, 16, 3, 3, Co, Ci)
+    out = torch.empty(N, H, W, Ci, device="cuda")
+    ops.conv2d(nhwc(g), wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=128, algo=2)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+    # conv_down input gradient (mode 2) and ConvTranspose2d forward (mode 1)
+    C = 64
+    x = rnd(1, C, 16, 32, seed=4).requires_grad_(True)
+    w4 = rnd(C, C, 4, 4, seed=5, scale=0.1)
+    y = F.conv2d(x, _bf(w4), None, 2, 1)
+    g = rnd(*y.shape, seed=6)
+    y.backward(_bf(g))
+    kc = 2 * ops.conv_kc(4, 4, 2, 2)
+    wd = ops.pack_conv_weights_bf16(w4.float().cuda(), ops.ROLE_DOWN_DGRAD, 64, kc, 4, 4, C, C)
+    out = torch.empty(1, 16, 32, C, device="cuda")
+    ops.conv2d(nhwc(g), wd, out, kh=4, kw=4, stride=2, pad=1, mode=2, cout=C, cout_pad=64, algo=2)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+    wt = rnd(128, 64, 2, 2, seed=7, scale=0.1)
+    xi = rnd(1, 128, 8, 16, seed=8)
+    bt = rnd(64, seed=9)
+    yt = F.conv_transpose2d(_bf(xi), _bf(wt), bt, stride=2)
+    kc = 2 * ops.conv_kc(1, 1, 1, 1)
+    wp = ops.pack_conv_weights_bf16(wt.float().cuda(), ops.ROLE_CONVT, 128, kc, 2, 2, 64, 128)
+    o = torch.empty(1, 16, 32, 64, device="cuda")
+    ops.conv2d(nhwc(xi), wp, o, kh=1, kw=1, stride=1, pad=0, mode=1, cout=256, cout_pad=256, bias=bt.float().cuda(), algo=2)
+    np.testing.assert_allclose(nchw(o).numpy(), yt.numpy(), rtol=RTOL, atol=ATOL)

@@ -26,7 +26,6 @@ class _HipForward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, event, anchor, net):
         ctx.net = net
-        save = torch.is_grad_enabled() or anchor.requires_grad
         return net._engine.forward(x, event, save=net._save_for_backward)
 
     @staticmethod

@@ -4,7 +4,8 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from refid_amd import ops
-from tools.bench_kernels import timeit, B
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from bench_kernels import timeit, B
 
 def one(name, H, Ca, Cb, Co):
     Ci = Ca + Cb

@@ -1,0 +1,97 @@
+"""GPU: the fused train step (S1-S4 mirror, refid_amd/train.py) against the oracle's restatement of
+optimize_parameters over several iterations: loss, clipped AdamW trajectory (incl. decoupled weight
+decay on the 13 gradient-less tensors), cosine LR stepping, eval chunking, checkpoint round trip."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import refid_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(img_chn, base, T_max=50, clip=True, dtype="fp32"):
+    return {
+        "name": "t", "is_train": True, "num_gpu": 1,
+        "network_g": dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=3,
+                          base_num_channels=base, num_block=1, num_residual_blocks=2, compute_dtype=dtype),
+        "path": {"pretrain_network_g": None},
+        "train": {"optim_g": dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.99]),
+                  "scheduler": dict(type="TrueCosineAnnealingLR", T_max=T_max, eta_min=1e-7),
+                  "pixel_opt": dict(type="CharbonnierLoss", loss_weight=1, reduction="mean"),
+                  "use_grad_clip": clip},
+        "val": {"max_minibatch": 2},
+    }
+
+
+def test_three_train_steps_match_oracle():
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    img_chn, base, B, T, H, W = 26, 8, 2, 3, 32, 32
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=5)
+    model = TwoImageEventRecurrentRestorationModel(_opt(img_chn, base))
+    model.net_g.load_state_dict(P, strict=True)
+    Pc = {k: v.clone() for k, v in P.items()}
+    st = O.TrainState(Pc)
+    epoch = 0
+    for it in range(1, 4):
+        x, ev, gt = O.make_inputs(B, T, H, W, img_chn, seed=10 + it, mode="hash")
+        model.update_learning_rate(it)
+        if it > 1:
+            epoch += 1
+        lr = O.cosine_lr(2e-4, epoch, 50, 1e-7)
+        assert abs(model.get_current_learning_rate()[0] - lr) < 1e-15
+        model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+        model.optimize_parameters(it)
+        loss_ref, gnorm_ref, _, _ = O.train_step(Pc, st, x, ev, gt, lr=lr)
+        assert abs(model.get_current_log()["l_pix"] - float(loss_ref)) < 2e-5 * abs(float(loss_ref)) + 1e-7
+        assert abs(model.grad_norm() - float(gnorm_ref)) < 2e-3 * float(gnorm_ref)
+    sd = model.net_g.state_dict()
+    worst = 0.0
+    for k in P:
+        a, b = sd[k].double().cpu(), Pc[k].double()
+        # parameters move by ~lr per step (normalised-gradient AdamW): compare the DISPLACEMENT
+        disp = (b - P[k].double()).abs().max().item()
+        err = (a - b).abs().max().item()
+        worst = max(worst, err / max(disp, 1e-12))
+        assert err <= 0.05 * disp + 1e-9, (k, err, disp)
+    # gradient-less tensors: pure decoupled weight decay p *= (1 - lr*wd) each step
+    k = "encoders_forward.1.conv.conv2d.weight"
+    np.testing.assert_allclose(sd[k].cpu().numpy(), Pc[k].numpy(), rtol=1e-6, atol=1e-9)
+
+
+def test_eval_step_chunks_and_checkpoint_roundtrip(tmp_path):
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    model = TwoImageEventRecurrentRestorationModel(_opt(6, 8))
+    P = O.make_params(6, base_num_channels=8, mode="hash", seed=2)
+    model.net_g.load_state_dict(P)
+    x, ev, gt = O.make_inputs(3, 2, 16, 24, 6, seed=3)
+    model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+    model.test()                                               # max_minibatch 2 -> chunks of 2 + 1
+    with torch.no_grad():
+        ref = O.forward(P, x, ev)
+    np.testing.assert_allclose(model.output.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
+    path = os.path.join(tmp_path, "net_g_1.pth")
+    model.save_network(model.net_g, path)
+    ck = torch.load(path)
+    assert list(ck.keys()) == ["params"] and list(ck["params"].keys()) == list(P.keys())
+    m2 = TwoImageEventRecurrentRestorationModel({**_opt(6, 8), "path": {"pretrain_network_g": path, "strict_load_g": True}})
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(m2.net_g.state_dict().values(), model.net_g.state_dict().values()))
+    # a DDP-style "module." prefixed checkpoint loads too (base_model.py:256-281)
+    torch.save({"params": {"module." + k: v for k, v in ck["params"].items()}}, path)
+    m3 = TwoImageEventRecurrentRestorationModel({**_opt(6, 8), "path": {"pretrain_network_g": path}})
+    assert torch.equal(m3.net_g.state_dict()["pred.conv2d.weight"].cpu(), P["pred.conv2d.weight"])
+
+
+def test_unsupported_training_options_raise():
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    o = _opt(6, 8)
+    o["train"]["optim_g"]["type"] = "SGD"
+    with pytest.raises(NotImplementedError):
+        TwoImageEventRecurrentRestorationModel(o)
+    o = _opt(6, 8)
+    o["train"]["pixel_opt"] = None
+    with pytest.raises(ValueError):
+        TwoImageEventRecurrentRestorationModel(o)

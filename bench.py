@@ -162,10 +162,22 @@ def main():
     if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
-        for name, fl, e0, e1, _shape in prof:
-            a = agg.setdefault(name, [0.0, 0.0, 0])
-            a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1
-        name, (fl, sec, cnt) = max(agg.items(), key=lambda kv: kv[1][1])
+        for name, fl, e0, e1, _shape, nb in prof:
+            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
+            a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1; a[3] += nb
+        name, (fl, sec, cnt, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
+        # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+        # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
+        traffic = None
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                rec = json.load(open(path)).get(name)
+            except (OSError, ValueError):
+                rec = None
+            if rec:
+                traffic = rec["hbm_bytes_per_launch"]
+                break
         # Winograd F(2x2,3x3) executes 16/36 of the direct convolution's multiplies on the matrix
         # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
         # the SURVEY 8(d) direct-convolution figure beside it.
@@ -176,7 +188,8 @@ def main():
         ach = executed / sec / 1e12
         conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "kernel": name, "launches": cnt,
+                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
+                "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
                 "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
                 "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),

@@ -14,6 +14,7 @@ struct ConvKArgs {
     float slopePre, slopePost, slopeMask;
     long long wClsStride;
     int vecOK;                 // out/res/mask/bias allow 16-byte channel-quad accesses
+    int ncot;                  // output-channel tiles (Winograd tile's XCD-aware work mapping)
     int bf16;                  // bf16 MFMA operands (packed weights are bf16), fp32 everything else
 };
 

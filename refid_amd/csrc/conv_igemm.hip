@@ -430,6 +430,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
               (!d->mask || (al16(d->mask) && d->ld_mask % 4 == 0)) && (!d->bias || al16(d->bias)) &&
               d->co_base % 4 == 0 && (d->mode != 1 || (d->cout / 4) % 4 == 0);
     a.bf16 = (d->algo == 2);
+    a.ncot = 0;
     const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode) * (a.bf16 ? 2 : 1);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
     if (d->algo == 1) {

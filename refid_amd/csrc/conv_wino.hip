@@ -61,12 +61,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     const int h = wave & 1;
     const int nt = (NTN == 2) ? (wave >> 1) : 0, mt = (MTN == 2) ? (wave >> 1) : 0;
 
-    int bt = blockIdx.x;
+    // XCD-aware work mapping: workgroup b runs on XCD b % 8 (observed dispatch order; used for L2
+    // affinity only).  The ncot channel tiles of one pixel tile are consecutive on the SAME XCD, so
+    // the input halo they all read is fetched into that XCD's L2 once instead of ncot times.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int bt = (slot / a.ncot) * 8 + xcd;                    // pixel-tile index
+    if (bt >= a.tilesX * a.tilesY * a.N) return;
+    const int n0 = (slot % a.ncot) * BN;
     const int tx = bt % a.tilesX; bt /= a.tilesX;
     const int ty = bt % a.tilesY;
     const int n = bt / a.tilesY;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int n0 = blockIdx.y * BN;
 
     // ---- loaders: buffer loads (wave-uniform descriptor + per-chunk scalar offset + a per-thread
     // byte offset that never changes across chunks); out-of-image pixels / out-of-range weight rows
@@ -277,7 +282,8 @@ int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
     a.tilesX = cdiv(a.Wo, TW);
     a.tilesY = cdiv(a.Ho, th);
     a.nchunks = cdiv(a.Ctot, KC);
-    dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, bn));
+    a.ncot = cdiv(a.Cout, bn);
+    dim3 grid(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
     if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, a);
     else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_wino");

@@ -135,9 +135,13 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     flops = 2.0 * d.n * d.ho * d.wo * cout * (d.c_a + d.c_b) * taps
     name = "conv_igemm_kernel<" + lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode() + ">"
     if algo == 1:
-        name = "conv_wino_kernel"
+        name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
+    opix = d.n * out.shape[1] * out.shape[2]
+    nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + opix * out.shape[3] * (1 + (res is not None) + (mask is not None))
+                    + cout * (d.c_a + d.c_b) * taps)
     PROFILE.append((name, flops, e0, e1,
-                    (d.n, d.h, d.w, d.c_a, d.c_b, cout, int(res is not None), int(mask is not None), int(bias is not None))))
+                    (d.n, d.h, d.w, d.c_a, d.c_b, cout, int(res is not None), int(mask is not None), int(bias is not None)),
+                    nbytes))
     return out
 
 
@@ -201,8 +205,9 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
     e1.record()
     flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
-    PROFILE.append((("wgrad_wino_kernel+reduce" if algo == 1 else f"wgrad_kernel<{kh}x{kw}s{stride}>+reduce"), flops, e0, e1,
-                    (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None))))
+    nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + d.n * d.ho * d.wo * d.c_o)
+    PROFILE.append((("wgrad_wino_kernel" if algo == 1 else f"wgrad_kernel<{kh}x{kw}s{stride}>"), flops, e0, e1,
+                    (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None)), nbytes))
     return slabs
 
 

@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 prof, ops.PROFILE = ops.PROFILE, None
 step_ms = e0.elapsed_time(e1)
 agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
-for name, fl, s, e, shape in prof:
+for name, fl, s, e, shape, _nb in prof:
     k = (name.replace("conv_igemm_kernel", "conv").replace("Cfg", ""), shape)
     v = agg[k]; v[0] += fl; v[1] += s.elapsed_time(e); v[2] += 1
 tot = sum(v[1] for v in agg.values())

@@ -212,6 +212,9 @@ int refid_colsum(const float* g, int ld_g, float* db, long long npix, int c, voi
 /* *loss_sum = sum sqrt((pred-gt)^2+eps); grad = (pred-gt)/sqrt(.)*grad_scale (grad may be NULL) */
 int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, long long count,
                       float eps, float grad_scale, void* stream);
+/* out[0] = sum g^2 (deterministic two-stage reduction: replicas of a data-parallel job must agree bit for
+ * bit); `out` must hold REFID_SQNORM_WORDS doubles (out[1..] is scratch). */
+#define REFID_SQNORM_WORDS 2049
 int refid_grad_sqnorm(const float* g, double* out, long long count, void* stream);
 /* clip_grad_norm_(max_norm) (max_norm <= 0: off) + AdamW step over flat arenas; gradients are
  * pre-multiplied by grad_scale (1/world_size after a SUM all-reduce). */

@@ -49,7 +49,22 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const f32x4* __restrict__ g
         acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
     const double t = block_sum_double((double)acc, sh);
-    if (threadIdx.x == 0) atomicAdd(out, t);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;             // per-block partial (deterministic 2nd stage)
+}
+
+// fixed-order sum of the per-block partials: every rank of a data-parallel job must derive the SAME
+// clip coefficient from the same all-reduced gradients, so no atomics here
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += part[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0];
 }
 
 // torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.AdamW single step.
@@ -98,12 +113,14 @@ extern "C" int refid_charbonnier(const float* pred, const float* gt, float* grad
 }
 
 extern "C" int refid_grad_sqnorm(const float* g, double* out, long long count, void* stream) {
+    // out: REFID_SQNORM_WORDS doubles; out[0] receives the result, out[1..] is scratch for the partials
     REFID_CHECK(g && out && count > 0 && count % 4 == 0, "grad_sqnorm: bad arguments (count=%lld)", count);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(double), st);
-    REFID_CHECK(e == hipSuccess, "grad_sqnorm: memset failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(sqnorm_kernel, dim3(nblocks(count / 4)), dim3(256), 0, st, (const f32x4*)g, out, count / 4);
+    const int nb = nblocks(count / 4);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(256), 0, st, (const f32x4*)g, out + 1, count / 4);
     REFID_LAUNCH_CHECK("grad_sqnorm");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, out + 1, nb, out);
+    REFID_LAUNCH_CHECK("grad_sqnorm/sum");
     return 0;
 }
 

@@ -403,9 +403,15 @@ def charbonnier(pred, gt, grad=None, eps=1e-12, grad_scale=None):
     return loss_sum
 
 
+SQNORM_WORDS = 2049
+
+
 def grad_sqnorm(flat_g, out=None):
+    """out[0] = sum g^2; `out` holds SQNORM_WORDS doubles (result + scratch for the block partials)."""
     if out is None:
-        out = torch.empty(1, dtype=torch.float64, device=flat_g.device)
+        out = torch.empty(SQNORM_WORDS, dtype=torch.float64, device=flat_g.device)
+    elif out.numel() < SQNORM_WORDS:
+        raise _lib.RefidHipError("grad_sqnorm: out needs SQNORM_WORDS doubles")
     check(lib().refid_grad_sqnorm(_c(flat_g, "g"), out.data_ptr(), flat_g.numel(), _stream()), "refid_grad_sqnorm")
     return out
 

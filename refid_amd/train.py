@@ -64,7 +64,7 @@ class TwoImageEventRecurrentRestorationModel:
         eng = self.net_g.engine
         self.exp_avg = torch.zeros_like(eng.arena.flat_p)
         self.exp_avg_sq = torch.zeros_like(eng.arena.flat_p)
-        self.sqnorm = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.sqnorm = torch.zeros(ops.SQNORM_WORDS, dtype=torch.float64, device=self.device)
         self.step_count = 0
         self.cur_lr = self.base_lr
         self.sched_epoch = 0
@@ -128,7 +128,7 @@ class TwoImageEventRecurrentRestorationModel:
         return self.log_dict
 
     def grad_norm(self):
-        return math.sqrt(float(self.sqnorm.item())) / self.world
+        return math.sqrt(float(self.sqnorm[0].item())) / self.world
 
     # ---- S4: evaluation -----------------------------------------------------------------------------
     def test(self):

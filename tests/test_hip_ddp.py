@@ -1,0 +1,83 @@
+"""GPU: the data-parallel train step end to end on real kernels.  Two ranks share the one GPU of the
+test box (gloo carries the collectives because RCCL refuses two ranks on one device; the code path --
+GradSync's early/late all-reduces of the flat gradient arena, rank-0 parameter broadcast, 1/world
+folded into clip+AdamW, loss reduce -- is the one bench.py uses with backend 'nccl').
+Equivalence: 2 ranks x B=1 == 1 rank x B=2 on the concatenated batch (mean loss, averaged grads)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from oracle import refid_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(img_chn, base):
+    return {
+        "name": "t", "is_train": True, "num_gpu": 1,
+        "network_g": dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=3,
+                          base_num_channels=base, num_block=1, num_residual_blocks=2),
+        "path": {"pretrain_network_g": None},
+        "train": {"optim_g": dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.99]),
+                  "scheduler": dict(type="TrueCosineAnnealingLR", T_max=50, eta_min=1e-7),
+                  "pixel_opt": dict(type="CharbonnierLoss", loss_weight=1, reduction="mean")},
+        "val": {},
+    }
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    from refid_amd.dist import shard_batch
+    torch.cuda.set_device(0)
+    model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5 + rank)     # ranks start DIFFERENT ...
+    model.net_g.load_state_dict(P)
+    torch.distributed.broadcast(model.net_g.engine.arena.flat_p, src=0)        # ... rank 0 wins (DDP semantics)
+    model.net_g.notify_params_changed()
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    mine = shard_batch(2, rank, world)
+    for it in (1, 2):
+        model.update_learning_rate(it)
+        model.feed_data({"lq": x[mine], "voxel": ev[mine], "gt": gt[mine]})
+        model.optimize_parameters(it)
+    loss = model.get_current_log()["l_pix"]
+    ret[rank] = (loss, model.grad_norm(), {k: v.cpu() for k, v in model.net_g.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_rank_on_the_full_batch():
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert set(ret.keys()) == {0, 1}
+    loss0, gn0, sd0 = ret[0]
+    loss1, gn1, sd1 = ret[1]
+    assert loss0 == loss1 and gn0 == gn1                       # reduced quantities agree across ranks
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k                  # replicas stay bit-identical
+    # single process, B=2
+    model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    model.net_g.load_state_dict(P)
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    for it in (1, 2):
+        model.update_learning_rate(it)
+        model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+        model.optimize_parameters(it)
+    assert abs(model.get_current_log()["l_pix"] - loss0) < 1e-6
+    assert abs(model.grad_norm() - gn0) < 1e-3 * gn0
+    sd = model.net_g.state_dict()
+    for k in sd:
+        a, b = sd[k].double().cpu(), sd0[k].double()
+        disp = (a - P[k].double()).abs().max().item()
+        assert (a - b).abs().max().item() <= 0.02 * disp + 1e-9, k

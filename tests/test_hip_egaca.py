@@ -180,6 +180,7 @@ def test_charbonnier_norm_adamw():
         opt.step()
         gd = g.cuda()
         sq = ops.grad_sqnorm(gd)
-        assert abs(math.sqrt(sq.item()) - float(tn)) < 1e-5 * float(tn)
+        assert abs(math.sqrt(sq[0].item()) - float(tn)) < 1e-5 * float(tn)
+        assert torch.equal(ops.grad_sqnorm(gd)[0], sq[0])          # deterministic
         ops.clip_adamw(p, gd, m, v, sq, max_norm=0.01, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, step=step)
         close(p, p_t.detach(), rtol=1e-5, atol=1e-7)

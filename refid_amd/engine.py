@@ -135,6 +135,30 @@ def _pad4(c):
 # (csrc/conv_wino.hip) when they are wide enough for its 64-channel tile; REFID_WINOGRAD=0
 # forces the direct implicit-GEMM tile everywhere.
 USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
+# weight-gradient kernels on a side HIP stream (REFID_OVERLAP_WGRAD=0: everything on one stream)
+OVERLAP_WGRAD = os.environ.get("REFID_OVERLAP_WGRAD", "1") != "0"
+
+
+class _SideStreams:
+    def __init__(self):
+        self._s = {}
+
+    def get(self, device):
+        if device.type != "cuda":
+            return None
+        s = self._s.get(device.index)
+        if s is None:
+            s = self._s[device.index] = torch.cuda.Stream(device=device)
+        return s
+
+    def join(self, device):
+        """Make the current stream wait for everything issued on the side stream."""
+        s = self._s.get(device.index)
+        if s is not None:
+            torch.cuda.current_stream().wait_stream(s)
+
+
+WGRAD_STREAM = _SideStreams()
 
 
 class ConvOp:
@@ -273,7 +297,21 @@ class ConvOp:
 
     # ---- weight / bias gradient ----------------------------------------------------------------
     def wgrad(self, g, a, b=None):
-        """g: gradient w.r.t. this conv's (pre-epilogue) output; (a|b): its input sources."""
+        """g: gradient w.r.t. this conv's (pre-epilogue) output; (a|b): its input sources.
+
+        Weight gradients are off BPTT's critical path (only input gradients feed the next step), so they are
+        issued on a side stream: their kernels fill the tails/gaps of the dependent dgrad chain."""
+        side = WGRAD_STREAM.get(g.device) if OVERLAP_WGRAD else None
+        if side is None:
+            return self._wgrad(g, a, b)
+        side.wait_stream(torch.cuda.current_stream())      # producers of g / a / b are already enqueued
+        for t in (g, a, b):
+            if t is not None:
+                t.record_stream(side)                       # allocator must not recycle them early
+        with torch.cuda.stream(side):
+            self._wgrad(g, a, b)
+
+    def _wgrad(self, g, a, b=None):
         if self.kind == "convT":
             # roles swapped (refid_hip.h): "g" := layer input (low res), "src" := output gradient
             ops.conv2d_wgrad(a, g, self.gw, kh=2, kw=2, stride=2, pad=0)
@@ -291,6 +329,14 @@ class ConvOp:
         """Reduce the accumulated slabs into the parameter gradient (once per step, after BPTT)."""
         if self.w_calls == 0:
             return
+        side = WGRAD_STREAM.get(self.w.device) if OVERLAP_WGRAD else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                self._finish_wgrad()
+        else:
+            self._finish_wgrad()
+
+    def _finish_wgrad(self):
         g, a, b, algo = self.w_last
         ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
                          db=self.gb, i_total=self.ci, algo=algo, phase=3, slabs=self.wslab)
@@ -711,6 +757,7 @@ class Engine:
         self._egaca_img_bwd(self.enc_f[1].att, xb[0], g_xb[0], c["ip_f"])
         for o in self.early_ops:
             o.finish_wgrad()
+        WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_f[1].att)
         if grad_sync is not None:
             grad_sync("early")
@@ -753,6 +800,7 @@ class Engine:
         self.head_img.wgrad(g, c["x_in"])
         for o in self.all_ops:
             o.finish_wgrad()
+        WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_b[1].att)
         if grad_sync is not None:
             grad_sync("late")

@@ -153,12 +153,18 @@ def main():
         # one extra, instrumented step (every rank runs it: the step contains collectives; only rank 0
         # records): HIP events around every conv-tile / wgrad launch on the launch stream; the dominant
         # kernel = the kernel with the largest accumulated time
+        # The timed steps run the weight-gradient kernels on a side stream, concurrently with the dgrad chain;
+        # for a per-kernel duration that means something against the roofline the instrumented step runs
+        # every kernel alone on one stream (same as REFID_OVERLAP_WGRAD=0).
+        from refid_amd import engine as _engine
+        overlap, _engine.OVERLAP_WGRAD = _engine.OVERLAP_WGRAD, False
         if rank == 0:
             ops.PROFILE = []
         it += 1
         model.update_learning_rate(it)
         model.optimize_parameters(it)
         torch.cuda.synchronize()
+        _engine.OVERLAP_WGRAD = overlap
     if not args.no_roofline and rank == 0:
         prof, ops.PROFILE = ops.PROFILE, None
         agg = {}
@@ -192,6 +198,8 @@ def main():
                 "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
                 "avg_launch_us": round(sec / cnt * 1e6, 2),
                 "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
+                "note": "per-kernel timing from one extra single-stream step (kernels run alone; the timed steps "
+                        "overlap wgrad kernels on a side stream); rocprof counterpart: profiles/*_nooverlap_kernel_stats.csv",
                 "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
                                      "share_of_step": round(conv_t / (dt / args.steps), 3)}}
     if world > 1:

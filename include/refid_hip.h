@@ -83,6 +83,9 @@ typedef struct refid_conv_desc {
     int algo;                                   /* 0 = direct implicit GEMM; 1 = Winograd F(2x2,3x3)
                                                    (3x3, stride 1, mode 0 only; w_packed must come
                                                    from the REFID_ROLE_WINO_* packings);
+                                                   3 = register-operand pointwise tile (1x1, stride 1,
+                                                   mode 0; w_packed = REFID_ROLE_FWD/DGRAD packing with
+                                                   kc = 8);
                                                    2 = direct tile with bf16 MFMA operands (fp32
                                                    accumulate/epilogue/tensors; w_packed from
                                                    refid_pack_conv_weights_bf16 with kc doubled)   */
@@ -173,10 +176,11 @@ int refid_fold_back(const float* w, const float* b, const float* scale, float* g
  * ---------------------------------------------------------------------------------- */
 int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float* b, float* out,
                           int ld_out, long long npix, int c, float eps, void* stream);
-/* LayerNormFunction.backward, fusion_modules.py:110-122; gx (+)= ... when accumulate != 0 */
+/* LayerNormFunction.backward, fusion_modules.py:110-122; gx = (res ? res : 0) + dL/dx.  res may be
+ * NULL or alias gx (in-place accumulate); pass a distinct gx when another stream still reads res. */
 int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
-                          int ld_gx, int accumulate, float* dw, float* db, long long npix, int c,
-                          float eps, void* stream);
+                          int ld_gx, const float* res, int ld_res, float* dw, float* db, long long npix,
+                          int c, float eps, void* stream);
 /* pre = dwconv3x3(in)+b ; act = GELU(pre) ; pool[n][part][c] = per-workgroup partial sums of act
  * (fm:304-309 + se_1's AdaptiveAvgPool2d, fm:253-254; pool may be NULL; parts =
  * refid_dwconv_pool_parts(h,w,c); deterministic, no atomics).  w is the reference (c,1,3,3) tensor. */

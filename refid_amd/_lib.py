@@ -93,7 +93,7 @@ def _bind_extra(L):
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
     L.refid_fold_back.argtypes = [vp] * 6 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
-    L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, i, vp, vp, ll, i, f, vp]
+    L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, ll, i, f, vp]
     L.refid_dwconv3x3_gelu_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
     L.refid_dwconv3x3_bwd.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, i, vp]
     L.refid_se_fwd.argtypes = [vp, i, f, vp, vp, vp, vp, vp, vp, vp, i, i, vp]

@@ -21,3 +21,5 @@ struct ConvKArgs {
 
 // conv_wino.hip
 int refid_launch_wino3x3(const ConvKArgs& a, hipStream_t st);
+// conv_pw.hip
+int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st);

@@ -398,8 +398,8 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     REFID_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
-    REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3),
-                "conv2d: algo %d needs a 3x3 stride-1 mode-0 conv", d->algo);
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3) || (d->algo == 3 && f == F_1x1),
+                "conv2d: algo %d does not fit this geometry (1 = 3x3 stride 1, 3 = 1x1)", d->algo);
     REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
     REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
@@ -433,6 +433,14 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     a.ncot = 0;
     const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode) * (a.bf16 ? 2 : 1);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
+    if (d->algo == 3) {
+        REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: pointwise tile needs c_a %% 8 == 0 for two sources");
+        const long long lim = 0x7fffffffLL;
+        REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
+                        (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
+                    "conv2d: tensor too large for the pointwise tile's 32-bit offsets (use algo 0)");
+        return refid_launch_pointwise(a, st);
+    }
     if (d->algo == 1) {
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");
         const long long lim = 0x7fffffffLL;      // buffer-load byte offsets are 32-bit

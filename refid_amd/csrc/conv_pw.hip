@@ -1,0 +1,149 @@
+// Pointwise (1x1, stride 1) convolution tile for the short-K layers of the REFID hot path:
+// fuse_two_dir (rsm:291-293), ImageEncoderConvBlock.identity (rsm:28,47), the five 1x1 convs of
+// EGACA (fm:300-331) and their input gradients.
+//
+//   out = mask( post( pre(W [a|b] + bias) + res ) )        -- same contract as conv_igemm.hip
+//
+// These layers have K = 64..512 and are bandwidth/latency bound (5-40 FLOP/B): a workgroup-tiled
+// GEMM spends most of its time in prologue/epilogue.  Here there is NO LDS and NO barrier: a 1x1
+// conv has no spatial structure, so each wave owns 32 consecutive pixels x all (<=128) output
+// channels of its column tile and feeds v_mfma_f32_32x32x2_f32 straight from registers --
+// activations: one 16-byte buffer load per lane per 8-channel chunk (lane = pixel, K quad = l>>5);
+// weights: the packed [chunk][1][cout][8] rows, one 16-byte buffer load per lane per 32 channels
+// (1 KB contiguous per wave, L2 resident).  Loads of chunk c+1 are in flight during the MFMAs of chunk
+// c; ~100 VGPRs => 4-5 waves per SIMD hide the rest.  Fused 16-byte epilogue as everywhere else.
+#include "common.h"
+#include "conv_args.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int KC = 8;
+constexpr int OOB = -1;
+
+template <int NT>      // 32-channel column tiles per wave (Cout tile = 32*NT)
+__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const long long npix = (long long)a.N * a.H * a.W;
+    const long long p0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    if (p0 >= npix) return;
+    const long long p = p0 + li;
+    const int n0 = blockIdx.y * (32 * NT);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.inA), 0, (int)min(npix * a.ldA * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.inB ? a.inB : a.inA), 0, (int)min(npix * (a.inB ? a.ldB : a.ldA) * 4, 0x7fffffffLL),
+        0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * a.CoutPad * KC * 4, 0x7fffffffLL), 0x00020000);
+    const bool pok = p < npix;
+    const int voA = pok ? (int)(p * a.ldA * 4) + kh * 16 : OOB;
+    const int voB = pok ? (int)(p * a.ldB * 4) + kh * 16 : OOB;
+    int voW[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int row = a.coBase + n0 + nt * 32 + li;
+        voW[nt] = (row < a.CoutPad) ? (row * KC + kh * 4) * 4 : OOB;
+    }
+    const int wChunk = a.CoutPad * KC * 4;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+
+    auto load_x = [&](int ch) -> f32x4 {
+        const int c0 = ch * KC;
+        const bool fromA = c0 < a.Ca;
+        const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
+        const int vo = (c0 + kh * 4 < a.Ctot) ? (fromA ? voA : voB) : OOB;
+        const u32x4 v = fromA ? __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, soff, 0);
+        return __builtin_bit_cast(f32x4, v);
+    };
+    auto load_w = [&](int ch, f32x4 (&dst)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            dst[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[nt], ch * wChunk, 0));
+    };
+
+    f32x4 xa = load_x(0), xb;
+    f32x4 wa[NT], wb[NT];
+    load_w(0, wa);
+    for (int ch = 0; ch < a.nchunks; ch += 2) {
+        if (ch + 1 < a.nchunks) { xb = load_x(ch + 1); load_w(ch + 1, wb); }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nt][kk], xa[kk], acc[nt], 0, 0, 0);
+        if (ch + 1 >= a.nchunks) break;
+        if (ch + 2 < a.nchunks) { xa = load_x(ch + 2); load_w(ch + 2, wa); }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nt][kk], xb[kk], acc[nt], 0, 0, 0);
+    }
+
+    // ---- fused epilogue: D[cout][pixel]; lane li = pixel, register quad g = 4 consecutive channels -----
+    if (!pok) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int j0 = n0 + nt * 32 + 8 * g + 4 * kh;
+            if (j0 >= a.Cout) continue;
+            const bool vec = a.vecOK && (j0 + 3 < a.Cout);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                const float* bp = a.bias + a.coBase + j0;
+                if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
+            }
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(acc[nt][4 * g + k] + bv[k], a.slopePre);
+            if (vec) {
+                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + p * a.ldR + j0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                if (a.mask) {
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + p * a.ldM + j0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+                }
+                *reinterpret_cast<f32x4*>(a.out + p * a.ldO + j0) = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 + k >= a.Cout) break;
+                    float t = v[k];
+                    if (a.res) t += a.res[p * a.ldR + j0 + k];
+                    t = lrelu(t, a.slopePost);
+                    if (a.mask) t *= (a.mask[p * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                    a.out[p * a.ldO + j0 + k] = t;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st) {
+    ConvKArgs a = ka;
+    a.nchunks = cdiv(a.Ctot, KC);
+    const long long npix = (long long)a.N * a.H * a.W;
+    const int nb = (int)((npix + 127) / 128);
+    if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1>), dim3(nb, cdiv(a.Cout, 32)), dim3(256), 0, st, a);
+    else if (a.Cout <= 64) hipLaunchKernelGGL((conv_pw_kernel<2>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<4>), dim3(nb, cdiv(a.Cout, 128)), dim3(256), 0, st, a);
+    REFID_LAUNCH_CHECK("conv_pw");
+    return 0;
+}

@@ -56,9 +56,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 template <int LPP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, int ldg,
                                                     const float* __restrict__ x, int ldx,
-                                                    const float* __restrict__ w, float* __restrict__ gx, int ldgx,
-                                                    int acc, float* __restrict__ dw, float* __restrict__ db,
-                                                    long long npix, float eps) {
+                                                    const float* __restrict__ w, float* gx, int ldgx,
+                                                    const float* res, int ldr, float* __restrict__ dw,
+                                                    float* __restrict__ db, long long npix, float eps) {
     constexpr int C = LPP * 4, PPB = 256 / LPP;
     __shared__ float sdw[C], sdb[C];
     const int q = threadIdx.x % LPP;
@@ -78,9 +78,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
         const float m1 = group_sum<LPP>(gh[0] + gh[1] + gh[2] + gh[3]) * (1.f / C);
         const float m2 = group_sum<LPP>(gh[0] * y[0] + gh[1] * y[1] + gh[2] * y[2] + gh[3] * y[3]) * (1.f / C);
         f32x4 r = (gh - y * m2 - m1) * rstd;
-        float* o = gx + p * ldgx + q * 4;
-        if (acc) r += *reinterpret_cast<const f32x4*>(o);
-        *reinterpret_cast<f32x4*>(o) = r;
+        if (res) r += *reinterpret_cast<const f32x4*>(res + p * ldr + q * 4);     // res may alias gx
+        *reinterpret_cast<f32x4*>(gx + p * ldgx + q * 4) = r;
         pdw += gv * y;
         pdb += gv;
     }
@@ -425,12 +424,12 @@ extern "C" int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, c
 }
 
 extern "C" int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
-                                     int ld_gx, int accumulate, float* dw, float* db, long long npix, int c,
-                                     float eps, void* stream) {
+                                     int ld_gx, const float* res, int ld_res, float* dw, float* db, long long npix,
+                                     int c, float eps, void* stream) {
     REFID_CHECK(g && x && w && gx && dw && db && npix > 0, "layernorm2d_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     LPP_DISPATCH(c, hipLaunchKernelGGL(ln_bwd_kernel<LPP>, dim3(blocks_for(npix, 256 / LPP, 512)), dim3(256), 0, st,
-                                       g, ld_g, x, ld_x, w, gx, ld_gx, accumulate, dw, db, npix, eps));
+                                       g, ld_g, x, ld_x, w, gx, ld_gx, res, ld_res, dw, db, npix, eps));
     REFID_LAUNCH_CHECK("layernorm2d_bwd");
     return 0;
 }

@@ -135,6 +135,7 @@ def _pad4(c):
 # (csrc/conv_wino.hip) when they are wide enough for its 64-channel tile; REFID_WINOGRAD=0
 # forces the direct implicit-GEMM tile everywhere.
 USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
+USE_POINTWISE = os.environ.get("REFID_POINTWISE", "1") != "0"     # register-operand tile for 1x1 convs
 # weight-gradient kernels on a side HIP stream (REFID_OVERLAP_WGRAD=0: everything on one stream)
 OVERLAP_WGRAD = os.environ.get("REFID_OVERLAP_WGRAD", "1") != "0"
 
@@ -214,6 +215,9 @@ class ConvOp:
             if self.co >= 16:                  # pred (3 channels) stays on the direct tile
                 self.f_algo, self.f_role, self.f_kc, self.f_bn = 1, ops.ROLE_WINO_FWD, 8, 64
             self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
+        elif USE_POINTWISE and kind == "conv" and k == 1 and self.ci % 16 == 0 and self.co % 16 == 0:
+            self.f_algo = self.d_algo = 3
+            self.f_kc, self.f_bn = 8, 32
         self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
         dev = self.w.device
         pdt = torch.bfloat16 if bf16 else torch.float32
@@ -230,6 +234,8 @@ class ConvOp:
                 self.d_bn = ops.conv_bn(kh, kw, st, md, self.co)     # issued as two halves of co rows
             if self.d_algo == 1:
                 self.d_kc, self.d_bn = 8, 64
+            if self.d_algo == 3:
+                self.d_kc, self.d_bn = 8, 32
             if bf16:
                 self.d_kc *= 2
             self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
@@ -523,9 +529,10 @@ class Engine:
         A.conv1_e.wgrad(g_c1e, e["ln_e"])
         g_lne = A.conv1_e.dgrad(g_c1e)
         ops.add(img_grad, g_y, out=img_grad)              # y = ev + img + ...: image gets g_y
-        ops.layernorm2d_bwd(g_lne, e["ev"], A.p("norm1_e.weight"), g_y, A.g("norm1_e.weight"),
-                            A.g("norm1_e.bias"), accumulate=True)
-        return g_y                                        # = g_y + LN1e-backward: gradient w.r.t. ev
+        # NOT in place: conv3's weight-gradient kernel may still be reading g_y on the side stream
+        g_ev = ops.layernorm2d_bwd(g_lne, e["ev"], A.p("norm1_e.weight"), torch.empty_like(g_y),
+                                   A.g("norm1_e.weight"), A.g("norm1_e.bias"), res=g_y)
+        return g_ev                                       # = g_y + LN1e-backward: gradient w.r.t. ev
 
     def _egaca_img_bwd(self, A, img, img_grad, ip):
         if ip["gxi"] is None:
@@ -703,14 +710,14 @@ class Engine:
         g_xb = [zeros(t) for t in xb]
         g_Sb = [None, None, None]
         g_e = torch.empty_like(e_all)
-        g4 = torch.empty((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
 
         # ---------------- forward sweep, t = T-1 .. 0 -------------------------------------------
         g_hf = [None, None, None]
         g_hd = [None, None, None]
         for t in range(T - 1, -1, -1):
             S = c["steps_f"][t]
-            ops.nchw_to_nhwc(gout[:, t], _pad4(self.out_chn), out=g4)
+            # a fresh buffer per step: pred's weight-gradient kernel reads it on the side stream
+            g4 = ops.nchw_to_nhwc(gout[:, t], _pad4(self.out_chn))
             self.pred.wgrad(g4, S["pi"])
             g_pi = self.pred.dgrad(g4)
             ops.add(g_head, g_pi, out=g_head)

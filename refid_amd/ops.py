@@ -136,6 +136,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     name = "conv_igemm_kernel<" + lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode() + ">"
     if algo == 1:
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
+    if algo == 3:
+        name = "conv_pw_kernel<%d>" % (1 if cout <= 32 else (2 if cout <= 64 else 4))
     opix = d.n * out.shape[1] * out.shape[2]
     nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + opix * out.shape[3] * (1 + (res is not None) + (mask is not None))
                     + cout * (d.c_a + d.c_b) * taps)
@@ -275,12 +277,16 @@ def layernorm2d_fwd(x, w, b, out=None, eps=1e-6):
     return out
 
 
-def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, eps=1e-6):
+def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, res=None, eps=1e-6):
+    """gx = (res or 0) + LayerNorm2d backward; accumulate=True is res=gx (in place)."""
     pg, ldg = _nhwc(g, "g")
     px, ldx = _nhwc(x, "x")
     pgx, ldgx = _nhwc(gx, "gx")
+    if accumulate and res is None:
+        res = gx
+    pr, ldr = _nhwc(res, "res") if res is not None else (None, 0)
     npix = x.shape[0] * x.shape[1] * x.shape[2]
-    check(lib().refid_layernorm2d_bwd(pg, ldg, px, ldx, _c(w, "w"), pgx, ldgx, int(accumulate), _c(dw, "dw"),
+    check(lib().refid_layernorm2d_bwd(pg, ldg, px, ldx, _c(w, "w"), pgx, ldgx, pr, ldr, _c(dw, "dw"),
                                       _c(db, "db"), npix, x.shape[3], eps, _stream()), "refid_layernorm2d_bwd")
     return gx
 

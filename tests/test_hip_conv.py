@@ -458,3 +458,38 @@ def test_bf16_tile_dgrad_and_special_modes():
     o = torch.empty(1, 16, 32, 64, device="cuda")
     ops.conv2d(nhwc(xi), wp, o, kh=1, kw=1, stride=1, pad=0, mode=1, cout=256, cout_pad=256, bias=bt.float().cuda(), algo=2)
     np.testing.assert_allclose(nchw(o).numpy(), yt.numpy(), rtol=RTOL, atol=ATOL)
+
+
+# ---------------------------------------------------------------------------------------------
+# register-operand pointwise tile (algo=3)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co
+    (2, 8, 16, 64, 64, 64), (1, 16, 16, 32, 0, 64), (1, 8, 8, 128, 0, 128), (1, 8, 8, 64, 0, 32),
+    (1, 5, 7, 256, 256, 256), (1, 9, 11, 64, 0, 128), (1, 6, 10, 128, 0, 64), (1, 4, 4, 16, 0, 16),
+])
+def test_pointwise_tile(cfg):
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    Ci = Ca + Cb
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 1, 1, seed=2, scale=1.0 / np.sqrt(Ci))
+    b = rnd(Co, seed=3)
+    r = rnd(N, Co, H, W, seed=4)
+    m = rnd(N, Co, H, W, seed=5)
+    ref = lrelu(lrelu(F.conv2d(x, w, b), 0.2) + r, 0.5) * torch.where(m > 0, 1.0, 0.3)
+    wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_FWD, 32, 8, 1, 1, Co, Ci)
+    out = torch.empty(N, H, W, Co, device="cuda")
+    ops.conv2d(nhwc(x[:, :Ca]), wp, out, kh=1, kw=1, cout=Co, cout_pad=-(-Co // 32) * 32, algo=3,
+               in_b=nhwc(x[:, Ca:]) if Cb else None, bias=b.float().cuda(), res=nhwc(r), mask=nhwc(m),
+               slope_pre=0.2, slope_post=0.5, slope_mask=0.3)
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+    # input gradient = the same tile on the transposed packing, issued as a row range
+    if Cb:
+        xg = x.clone().requires_grad_(True)
+        g = rnd(N, Co, H, W, seed=6)
+        F.conv2d(xg, w, None).backward(g)
+        wd = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_DGRAD, 32, 8, 1, 1, Co, Ci)
+        o2 = torch.empty(N, H, W, Cb, device="cuda")
+        ops.conv2d(nhwc(g), wd, o2, kh=1, kw=1, cout=Cb, cout_pad=-(-Ci // 32) * 32, co_base=Ca, algo=3)
+        np.testing.assert_allclose(nchw(o2).numpy(), xg.grad[:, Ca:].numpy(), rtol=RTOL, atol=ATOL)

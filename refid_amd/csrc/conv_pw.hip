@@ -10,8 +10,8 @@
 // channels of its column tile and feeds v_mfma_f32_32x32x2_f32 straight from registers --
 // activations: one 16-byte buffer load per lane per 8-channel chunk (lane = pixel, K quad = l>>5);
 // weights: the packed [chunk][1][cout][8] rows, one 16-byte buffer load per lane per 32 channels
-// (1 KB contiguous per wave, L2 resident).  Loads of chunk c+1 are in flight during the MFMAs of chunk
-// c; ~100 VGPRs => 4-5 waves per SIMD hide the rest.  Fused 16-byte epilogue as everywhere else.
+// (1 KB contiguous per wave, L2 resident).  Activations are prefetched 64 channels ahead (one HBM
+// latency per wave for the K = 64 layers), weights one chunk ahead.  Fused 16-byte epilogue as everywhere else.
 #include "common.h"
 #include "conv_args.h"
 
@@ -70,23 +70,31 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKArgs a) {
             dst[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[nt], ch * wChunk, 0));
     };
 
-    f32x4 xa = load_x(0), xb;
-    f32x4 wa[NT], wb[NT];
-    load_w(0, wa);
-    for (int ch = 0; ch < a.nchunks; ch += 2) {
-        if (ch + 1 < a.nchunks) { xb = load_x(ch + 1); load_w(ch + 1, wb); }
+    // Activations are prefetched XD chunks (= 8*XD channels, HBM latency) ahead, weights one chunk
+    // (L2 latency) ahead.  vmcnt retires in issue order, so inside iteration c the weight load of c+1
+    // is issued BEFORE the activation load of c+XD: waiting for the former never waits for the latter.
+    constexpr int XD = 8;
+    f32x4 xr[2 * XD];
+    f32x4 wr[2][NT];
+    const int nch = a.nchunks;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+    for (int j = 0; j < XD; ++j)
+        if (j < nch) xr[j] = load_x(j);
+    load_w(0, wr[0]);
+    for (int c0 = 0; c0 < nch; c0 += 2 * XD) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nt][kk], xa[kk], acc[nt], 0, 0, 0);
-        if (ch + 1 >= a.nchunks) break;
-        if (ch + 2 < a.nchunks) { xa = load_x(ch + 2); load_w(ch + 2, wa); }
+        for (int j = 0; j < 2 * XD; ++j) {
+            const int c = c0 + j;
+            if (c < nch) {
+                if (c + 1 < nch) load_w(c + 1, wr[(j + 1) & 1]);
+                if (c + XD < nch) xr[(j + XD) % (2 * XD)] = load_x(c + XD);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+                for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nt][kk], xb[kk], acc[nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+            }
+        }
     }
 
     // ---- fused epilogue: D[cout][pixel]; lane li = pixel, register quad g = 4 consecutive channels -----

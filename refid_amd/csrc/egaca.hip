@@ -210,25 +210,53 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ p
                                                     const float* __restrict__ W2, const float* __restrict__ b2,
                                                     float* __restrict__ m, float* __restrict__ z1, float* __restrict__ s,
                                                     int C) {
-    __shared__ float sm[256], sz[128];
+    __shared__ float sm[256], sz[128], part[256];
     const int n = blockIdx.x, Ch = C / 2;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    // fixed-order sum of the per-workgroup pool partials: 256/C segments per channel, 4 independent
+    // accumulators each, then a serial pass over the segments (deterministic, no atomics)
+    {
+        const int nseg = 256 / C, c = threadIdx.x % C, seg = threadIdx.x / C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (seg < nseg) {
+            const float* pp = pool + (long long)n * nparts * C + c;
+            int r = seg;
+            for (; r + 3 * nseg < nparts; r += 4 * nseg) {
+                a0 += pp[(long long)r * C];
+                a1 += pp[(long long)(r + nseg) * C];
+                a2 += pp[(long long)(r + 2 * nseg) * C];
+                a3 += pp[(long long)(r + 3 * nseg) * C];
+            }
+            for (; r < nparts; r += nseg) a0 += pp[(long long)r * C];
+        }
+        part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float a = 0.f;
+            for (int g = 0; g < nseg; ++g) a += part[g * C + threadIdx.x];
+            sm[threadIdx.x] = a * invHW; m[n * C + threadIdx.x] = sm[threadIdx.x];
+        }
+    }
+    __syncthreads();
+    // the two mat-vecs: one wave per output row, lanes over the reduction index (coalesced rows of W)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < Ch; j += 4) {
         float a = 0.f;
-        for (int r = 0; r < nparts; ++r) a += pool[((long long)n * nparts + r) * C + c];
-        sm[c] = a * invHW; m[n * C + c] = sm[c];
+        for (int c = lane; c < C; c += 64) a += W1[j * C + c] * sm[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) {
+            a += b1[j];
+            a = a > 0.f ? a : 0.f;
+            sz[j] = a; z1[n * Ch + j] = a;
+        }
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < Ch; j += 256) {
-        float a = b1[j];
-        for (int c = 0; c < C; ++c) a += W1[j * C + c] * sm[c];
-        a = a > 0.f ? a : 0.f;
-        sz[j] = a; z1[n * Ch + j] = a;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a = b2[c];
-        for (int j = 0; j < Ch; ++j) a += W2[c * Ch + j] * sz[j];
-        s[n * C + c] = 1.f / (1.f + __expf(-a));
+    for (int c = wave; c < C; c += 4) {
+        float a = 0.f;
+        for (int j = lane; j < Ch; j += 64) a += W2[c * Ch + j] * sz[j];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) s[n * C + c] = 1.f / (1.f + __expf(-(a + b2[c])));
     }
 }
 
@@ -462,8 +490,8 @@ extern "C" int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, 
 extern "C" int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const float* w1, const float* b1,
                             const float* w2, const float* b2, float* m, float* z1, float* s, int n, int c,
                             void* stream) {
-    REFID_CHECK(pool && w1 && b1 && w2 && b2 && m && z1 && s && n > 0 && n_parts > 0 && c > 0 && c <= 256 && c % 2 == 0,
-                "se_fwd: bad arguments (c=%d)", c);
+    REFID_CHECK(pool && w1 && b1 && w2 && b2 && m && z1 && s && n > 0 && n_parts > 0 && c > 0 && c <= 256 && c % 2 == 0 && 256 % c == 0,
+                "se_fwd: bad arguments (c=%d; must divide 256)", c);
     hipLaunchKernelGGL(se_fwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pool, n_parts, inv_hw, w1, b1, w2,
                        b2, m, z1, s, c);
     REFID_LAUNCH_CHECK("se_fwd");

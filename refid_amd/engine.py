@@ -706,7 +706,8 @@ class Engine:
         gout = gout.contiguous()
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]
         zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)  # noqa: E731
-        g_head = zeros(head)
+        # pred has no activation (arch:215), so head's share sum_t dgrad(g_t) is dgrad(sum_t g_t): one launch
+        g_head = self.pred.dgrad(ops.nchw_to_nhwc(gout.sum(dim=1), _pad4(self.out_chn)))
         g_xb = [zeros(t) for t in xb]
         g_Sb = [None, None, None]
         g_e = torch.empty_like(e_all)
@@ -719,9 +720,7 @@ class Engine:
             # a fresh buffer per step: pred's weight-gradient kernel reads it on the side stream
             g4 = ops.nchw_to_nhwc(gout[:, t], _pad4(self.out_chn))
             self.pred.wgrad(g4, S["pi"])
-            g_pi = self.pred.dgrad(g4)
-            ops.add(g_head, g_pi, out=g_head)
-            g_sd = g_pi if g_hd[2] is None else ops.add(g_pi, g_hd[2])
+            g_sd = self.pred.dgrad(g4, res=g_hd[2])           # + decoder 2's state gradient, fused
             g_skip = [None, None, None]
             for j in (2, 1, 0):
                 D, dst = self.dec[j], S["ds"][j]

@@ -104,10 +104,12 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("REFID_FORCE_GRADSYNC") == "1"    # 1-rank RCCL dry run of the N>1 path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -125,7 +127,7 @@ def main():
     model.feed_data({"lq": x, "voxel": ev, "gt": gt})
 
     def sync():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -142,7 +144,7 @@ def main():
         model.optimize_parameters(it)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
@@ -202,7 +204,7 @@ def main():
                         "overlap wgrad kernels on a side stream); rocprof counterpart: profiles/*_nooverlap_kernel_stats.csv",
                 "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
                                      "share_of_step": round(conv_t / (dt / args.steps), 3)}}
-    if world > 1:
+    if use_dist:
         torch.distributed.barrier()
 
     if rank == 0:
@@ -222,7 +224,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -11,6 +11,7 @@ forward + BPTT in the HIP engine, Charbonnier forward+backward in one kernel, gl
 norm + clip + AdamW fused over the flat arenas, gradient all-reduce (RCCL) overlapped with BPTT.
 """
 import math
+import os
 from collections import OrderedDict
 from copy import deepcopy
 
@@ -68,8 +69,12 @@ class TwoImageEventRecurrentRestorationModel:
         self.step_count = 0
         self.cur_lr = self.base_lr
         self.sched_epoch = 0
-        self.grad_sync = GradSync(eng.arena.flat_g, eng.arena.offsets) if self.world > 1 else None
-        if self.world > 1:          # DDP's parameter broadcast from rank 0 (base_model.py:66-72)
+        # the collectives also run in a 1-rank process group (REFID_FORCE_GRADSYNC=1): lets a single-GPU box
+        # exercise the exact RCCL code path of the multi-GPU job
+        self.dist_on = self.world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized()
+                                          and os.environ.get("REFID_FORCE_GRADSYNC") == "1")
+        self.grad_sync = GradSync(eng.arena.flat_g, eng.arena.offsets) if self.dist_on else None
+        if self.dist_on:            # DDP's parameter broadcast from rank 0 (base_model.py:66-72)
             torch.distributed.broadcast(eng.arena.flat_p, src=0)
             eng.mark_params_changed()
 
@@ -121,7 +126,7 @@ class TwoImageEventRecurrentRestorationModel:
         """reduce_loss_dict (base_model.py:325-350): mean over ranks, evaluated lazily (one sync)."""
         if self.log_dict is None:
             l = self._loss_sum.clone()
-            if self.world > 1:
+            if self.dist_on:
                 torch.distributed.all_reduce(l)
                 l /= self.world
             self.log_dict = OrderedDict(l_pix=float(l.item()) * self.loss_weight / self._loss_n)

@@ -29,10 +29,13 @@ def _opt(img_chn, base):
     }
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        os.environ["REFID_FORCE_GRADSYNC"] = "1"       # run the collectives in a 1-rank group
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from refid_amd.train import TwoImageEventRecurrentRestorationModel
     from refid_amd.dist import shard_batch
     torch.cuda.set_device(0)
@@ -66,6 +69,33 @@ def test_two_rank_step_equals_single_rank_on_the_full_batch():
     for k in sd0:
         assert torch.equal(sd0[k], sd1[k]), k                  # replicas stay bit-identical
     # single process, B=2
+    model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    model.net_g.load_state_dict(P)
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    for it in (1, 2):
+        model.update_learning_rate(it)
+        model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+        model.optimize_parameters(it)
+    assert abs(model.get_current_log()["l_pix"] - loss0) < 1e-6
+    assert abs(model.grad_norm() - gn0) < 1e-3 * gn0
+    sd = model.net_g.state_dict()
+    for k in sd:
+        a, b = sd[k].double().cpu(), sd0[k].double()
+        disp = (a - P[k].double()).abs().max().item()
+        assert (a - b).abs().max().item() <= 0.02 * disp + 1e-9, k
+
+
+def test_one_rank_rccl_group_runs_the_same_collectives():
+    """The box has one GPU, and RCCL refuses two ranks on one device: a 1-rank 'nccl' group still drives
+    GradSync's async all-reduces, the parameter broadcast and the loss reduce through RCCL."""
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(1, port, ret, "nccl"), nprocs=1, join=True)
+    loss0, gn0, sd0 = ret[0]
     model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
     P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
     model.net_g.load_state_dict(P)

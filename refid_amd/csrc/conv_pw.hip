@@ -10,8 +10,9 @@
 // channels of its column tile and feeds v_mfma_f32_32x32x2_f32 straight from registers --
 // activations: one 16-byte buffer load per lane per 8-channel chunk (lane = pixel, K quad = l>>5);
 // weights: the packed [chunk][1][cout][8] rows, one 16-byte buffer load per lane per 32 channels
-// (1 KB contiguous per wave, L2 resident).  Activations are prefetched 64 channels ahead (one HBM
-// latency per wave for the K = 64 layers), weights one chunk ahead.  Fused 16-byte epilogue as everywhere else.
+// (1 KB contiguous per wave, L2 resident).  Activations are prefetched 32-64 channels ahead, weights one
+// chunk ahead; <= 128 registers => 4 waves per SIMD overlap the load / MFMA / store phases of different
+// waves (measured: occupancy matters more here than activation re-use across column tiles).  Fused 16-byte epilogue as everywhere else.
 #include "common.h"
 #include "conv_args.h"
 
@@ -21,13 +22,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 8;
 constexpr int OOB = -1;
 
-template <int NT>      // 32-channel column tiles per wave (Cout tile = 32*NT)
-__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKArgs a) {
+template <int NT, int XD>      // NT: 32-channel column tiles per wave (Cout tile = 32*NT); XD: activation prefetch depth
+__global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const long long npix = (long long)a.N * a.H * a.W;
     const long long p0 = ((long long)blockIdx.x * 4 + wave) * 32;
-    if (p0 >= npix) return;
     const long long p = p0 + li;
     const int n0 = blockIdx.y * (32 * NT);
 
@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKArgs a) {
     // Activations are prefetched XD chunks (= 8*XD channels, HBM latency) ahead, weights one chunk
     // (L2 latency) ahead.  vmcnt retires in issue order, so inside iteration c the weight load of c+1
     // is issued BEFORE the activation load of c+XD: waiting for the former never waits for the latter.
-    constexpr int XD = 8;
     f32x4 xr[2 * XD];
     f32x4 wr[2][NT];
     const int nch = a.nchunks;
@@ -97,46 +96,69 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvKArgs a) {
         }
     }
 
-    // ---- fused epilogue: D[cout][pixel]; lane li = pixel, register quad g = 4 consecutive channels -----
+    // ---- fused epilogue ------------------------------------------------------------------------------
+    // D[cout][pixel]: lane (li = pixel, kh) holds, per register quad g, channels 8g + 4kh + {0..3}.  Written
+    // straight from that layout a store instruction touches 32 B in each of 32 rows; instead the wave's tile is
+    // transposed through a private LDS slab so that consecutive lanes handle consecutive 16-byte pieces of a
+    // pixel: bias / residual / mask loads and the output store are then fully coalesced (256 B runs).
+    if (a.vecOK) {
+        constexpr int HN = (NT > 2) ? 2 : NT;          // column tiles per pass
+        constexpr int PITCH = 8 * HN + 1;              // float4 per pixel row (+1: bank spread)
+        __shared__ f32x4 sT[4][32 * PITCH];
+        f32x4* t = sT[wave];
+#pragma unroll
+        for (int h0 = 0; h0 < NT; h0 += HN) {
+            if (h0) __syncthreads();
+#pragma unroll
+            for (int nt = 0; nt < HN; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[h0 + nt][4 * g + k];
+                    t[li * PITCH + nt * 8 + 2 * g + kh] = v;
+                }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4 * HN; ++it) {
+                const int f = it * 64 + lane;
+                const int px = f / (8 * HN), c4 = f % (8 * HN);
+                const long long pp = p0 + px;
+                const int j0 = n0 + h0 * 32 + c4 * 4;
+                if (pp >= npix || j0 >= a.Cout) continue;
+                f32x4 v = t[px * PITCH + c4];
+                if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + a.coBase + j0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePre);
+                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pp * a.ldR + j0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                if (a.mask) {
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + pp * a.ldM + j0);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+                }
+                *reinterpret_cast<f32x4*>(a.out + pp * a.ldO + j0) = v;
+            }
+        }
+        return;
+    }
+    // scalar tail path (channel counts / pitches that are not multiples of 4)
     if (!pok) return;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int j0 = n0 + nt * 32 + 8 * g + 4 * kh;
-            if (j0 >= a.Cout) continue;
-            const bool vec = a.vecOK && (j0 + 3 < a.Cout);
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias) {
-                const float* bp = a.bias + a.coBase + j0;
-                if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
-                else
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
-            }
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(acc[nt][4 * g + k] + bv[k], a.slopePre);
-            if (vec) {
-                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + p * a.ldR + j0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
-                if (a.mask) {
-                    const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + p * a.ldM + j0);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
-                }
-                *reinterpret_cast<f32x4*>(a.out + p * a.ldO + j0) = v;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (j0 + k >= a.Cout) break;
-                    float t = v[k];
-                    if (a.res) t += a.res[p * a.ldR + j0 + k];
-                    t = lrelu(t, a.slopePost);
-                    if (a.mask) t *= (a.mask[p * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
-                    a.out[p * a.ldO + j0 + k] = t;
-                }
+            for (int k = 0; k < 4; ++k) {
+                if (j0 + k >= a.Cout) break;
+                float tv = acc[nt][4 * g + k] + (a.bias ? a.bias[a.coBase + j0 + k] : 0.f);
+                tv = lrelu(tv, a.slopePre);
+                if (a.res) tv += a.res[p * a.ldR + j0 + k];
+                tv = lrelu(tv, a.slopePost);
+                if (a.mask) tv *= (a.mask[p * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                a.out[p * a.ldO + j0 + k] = tv;
             }
         }
     }
@@ -149,9 +171,9 @@ int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st) {
     a.nchunks = cdiv(a.Ctot, KC);
     const long long npix = (long long)a.N * a.H * a.W;
     const int nb = (int)((npix + 127) / 128);
-    if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1>), dim3(nb, cdiv(a.Cout, 32)), dim3(256), 0, st, a);
-    else if (a.Cout <= 64) hipLaunchKernelGGL((conv_pw_kernel<2>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_pw_kernel<4>), dim3(nb, cdiv(a.Cout, 128)), dim3(256), 0, st, a);
+    // wider layers run as 64-channel column tiles (grid.y): 4 waves/SIMD beat re-using the activations
+    if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1, 8>), dim3(nb, 1), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<2, 4>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a);
     REFID_LAUNCH_CHECK("conv_pw");
     return 0;
 }

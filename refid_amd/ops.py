@@ -137,7 +137,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     if algo == 1:
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
     if algo == 3:
-        name = "conv_pw_kernel<%d>" % (1 if cout <= 32 else (2 if cout <= 64 else 4))
+        name = "conv_pw_kernel<1, 8>" if cout <= 32 else "conv_pw_kernel<2, 4>"
     opix = d.n * out.shape[1] * out.shape[2]
     nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + opix * out.shape[3] * (1 + (res is not None) + (mask is not None))
                     + cout * (d.c_a + d.c_b) * taps)

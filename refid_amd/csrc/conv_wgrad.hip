@@ -16,6 +16,7 @@
 // second kernel reduces the slabs and ACCUMULATES into the parameter-layout gradient,
 // because weights are shared over the T recurrent steps.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -218,6 +219,122 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 (pointwise) weight gradient, register-operand tile.
+//   dW[co][ci] = sum_p g[p][co] * x[p][ci]   -- a plain GEMM whose K index is the PIXEL, at 20-40 FLOP/B.
+// The LDS-tiled kernel above spends its time in barriers (a 64-pixel tile is 32 K steps); here a wave
+// streams its pixel range straight from global memory into MFMA operands: one 4-byte buffer load per lane
+// per operand row (a half wave reads 128 contiguous bytes of one pixel), PD pixel pairs in flight, no LDS,
+// no barrier.  Workgroup = WR x WC waves, wave tile = 32 output channels x 32*SN input channels.
+// Same slab layout / reduce kernel / phases as wgrad_kernel.
+struct WpArgs {
+    const float* g; int ldG, Co;
+    const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
+    float* slabs; float* bslabs;
+    long long npix; int chunk;          // pixels per split (even)
+    int CoP, CiP, WR, accum;
+};
+typedef unsigned int u32;
+
+template <int SN>
+__global__ __launch_bounds__(256) void wgrad_pw_kernel(const WpArgs a) {
+    constexpr int PD = 8;                               // pixel pairs per prefetch block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int wr = wave % a.WR, wc = wave / a.WR;
+    const int WC = 4 / a.WR;
+    const int co0 = (blockIdx.z * a.WR + wr) * 32;
+    const int ci0 = (blockIdx.y * WC + wc) * (32 * SN);
+    const int split = blockIdx.x;
+    const long long k0 = (long long)split * a.chunk;
+
+    const int lim = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.g), 0, (int)min(a.npix * a.ldG * 4, (long long)lim), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.inA), 0, (int)min(a.npix * a.ldA * 4, (long long)lim), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.inB ? a.inB : a.inA), 0, (int)min(a.npix * (a.inB ? a.ldB : a.ldA) * 4, (long long)lim),
+        0x00020000);
+    // per-lane byte offsets (pixel kh of a pair, channel li of the row); -1 = out of range -> reads 0
+    const int voG = (co0 + li < a.Co) ? (kh * a.ldG + co0 + li) * 4 : -1;
+    int voX[SN]; bool fromA[SN];
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn) {
+        const int c = ci0 + sn * 32 + li;
+        fromA[sn] = (ci0 + sn * 32) < a.Ca;             // wave-uniform: Ca % 32 == 0 for two sources
+        const int cc = fromA[sn] ? c : c - a.Ca;
+        const int ld = fromA[sn] ? a.ldA : a.ldB;
+        voX[sn] = (c < a.Ctot) ? (kh * ld + cc) * 4 : -1;
+    }
+    const int npairs = a.chunk / 2;
+
+    f32x16 acc[SN];
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[sn][r] = 0.f;
+    float bsum = 0.f;
+
+    float gv[2][PD], xv[2][PD][SN];
+    auto load_block = [&](int blk, float (&gd)[PD], float (&xd)[PD][SN]) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            const long long p = k0 + 2ll * (blk * PD + j);
+            const bool ok = blk * PD + j < npairs;
+            gd[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, ok ? voG : -1, (int)(p * a.ldG * 4), 0));
+#pragma unroll
+            for (int sn = 0; sn < SN; ++sn) {
+                const u32 v = fromA[sn] ? __builtin_amdgcn_raw_buffer_load_b32(rsA, ok ? voX[sn] : -1, (int)(p * a.ldA * 4), 0)
+                                        : __builtin_amdgcn_raw_buffer_load_b32(rsB, ok ? voX[sn] : -1, (int)(p * a.ldB * 4), 0);
+                xd[j][sn] = __builtin_bit_cast(float, v);
+            }
+        }
+    };
+    auto mma_block = [&](const float (&gd)[PD], const float (&xd)[PD][SN]) {
+#pragma unroll
+        for (int j = 0; j < PD; ++j) {
+            bsum += gd[j];
+#pragma unroll
+            for (int sn = 0; sn < SN; ++sn)
+                acc[sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(xd[j][sn], gd[j], acc[sn], 0, 0, 0);
+        }
+    };
+    const int nblk = (npairs + PD - 1) / PD;
+    load_block(0, gv[0], xv[0]);
+    for (int b = 0; b < nblk; b += 2) {
+        if (b + 1 < nblk) load_block(b + 1, gv[1], xv[1]);
+        mma_block(gv[0], xv[0]);
+        if (b + 1 >= nblk) break;
+        if (b + 2 < nblk) load_block(b + 2, gv[0], xv[0]);
+        mma_block(gv[1], xv[1]);
+    }
+
+    // ---- partial slab [split][co][ci] (one tap): D[ci][co], lane li = co, register quad q = 4 consecutive ci
+    float* sl = a.slabs + (long long)split * a.CoP * a.CiP;
+    const int co = co0 + li;
+#pragma unroll
+    for (int sn = 0; sn < SN; ++sn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ci = ci0 + sn * 32 + 8 * q + 4 * kh;
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = acc[sn][4 * q + k];
+            f32x4* dst = reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci);
+            if (a.accum) v += *dst;
+            *dst = v;
+        }
+    if (a.bslabs != nullptr && blockIdx.y == 0 && wc == 0) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (kh == 0) {
+            float* dst = a.bslabs + (long long)split * a.CoP + co;
+            *dst = a.accum ? *dst + bsum : bsum;
+        }
+    }
+}
+
 struct RedArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
@@ -280,7 +397,8 @@ using W4S2 = WCfg<4, 4, 2, 8, 1, 1, 2, 1, 2, 2, 16>;
 using W5 = WCfg<5, 5, 1, 7, 1, 1, 1, 1, 4, 2, 32>;
 using W2S2 = WCfg<2, 2, 2, 4, 1, 1, 2, 2, 1, 2, 16>;
 
-enum PlanId { P_W3, P_W3_64x32, P_W3_32x64, P_W3_32x32, P_W1, P_W4S2, P_W5, P_W2S2, P_NONE };
+enum PlanId { P_W3, P_W3_64x32, P_W3_32x64, P_W3_32x32, P_W1, P_W4S2, P_W5, P_W2S2, P_PW, P_NONE };
+const bool USE_PW_WGRAD = !(getenv("REFID_PW_WGRAD") && getenv("REFID_PW_WGRAD")[0] == '0');
 struct Plan { PlanId id; int cot, cit, th, tw, ntaps; bool ok; };
 
 template <class C>
@@ -293,7 +411,18 @@ Plan plan_of(int kh, int kw, int s, int co, int ci) {
         if (co <= 32) return mk<W3_32x64>(P_W3_32x64);
         return mk<W3>(P_W3);
     }
-    if (kh == 1 && kw == 1 && s == 1) return mk<W1>(P_W1);
+    if (kh == 1 && kw == 1 && s == 1) {
+        if (USE_PW_WGRAD && co % 32 == 0 && ci % 32 == 0) {
+            // register-operand tile: WR x WC waves of 32 x 32*SN channels (see wgrad_pw_kernel)
+            const int wr = co >= 128 ? 4 : (co >= 64 ? 2 : 1), wc = 4 / wr;
+            int sn = ci / (32 * wc);
+            sn = sn >= 2 ? 2 : 1;                   // SN = 4 costs occupancy (PD x 5 operand registers)
+            // only where one workgroup tile covers the whole weight matrix: with several channel tiles every
+            // operand is re-streamed per tile and the LDS-tiled kernel's 128 x 128 tile wins (measured)
+            if (co <= 32 * wr && ci <= 32 * sn * wc) return {P_PW, 32 * wr, 32 * sn * wc, 2, 32, 1, true};
+        }
+        return mk<W1>(P_W1);
+    }
     if (kh == 4 && kw == 4 && s == 2) return mk<W4S2>(P_W4S2);
     if (kh == 5 && kw == 5 && s == 1) return mk<W5>(P_W5);
     if (kh == 2 && kw == 2 && s == 2) return mk<W2S2>(P_W2S2);
@@ -381,7 +510,27 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     a.accum = (d->phase == 2);
     REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
     int rc = (d->phase == 3) ? 0 : 1;
-    if (d->phase != 3) switch (p.id) {
+    if (d->phase != 3 && p.id == P_PW) {
+        const long long npix = (long long)d->n * d->h * d->w;
+        REFID_CHECK(d->c_b == 0 || d->c_a % 32 == 0, "wgrad: pointwise tile needs c_a %% 32 == 0 for two sources");
+        REFID_CHECK(npix * d->ld_g * 4 < 0x7fffffffLL && npix * d->ld_a * 4 < 0x7fffffffLL &&
+                        (d->c_b == 0 || npix * d->ld_b * 4 < 0x7fffffffLL),
+                    "wgrad: tensor too large for the pointwise tile's 32-bit offsets");
+        WpArgs w;
+        w.g = d->g; w.ldG = d->ld_g; w.Co = d->c_o;
+        w.inA = d->in_a; w.inB = d->in_b; w.ldA = d->ld_a; w.ldB = d->ld_b; w.Ca = d->c_a; w.Ctot = d->c_a + d->c_b;
+        w.slabs = a.slabs; w.bslabs = a.bslabs;
+        w.npix = npix;
+        long long chunk = (npix + g.nsplit - 1) / g.nsplit;
+        w.chunk = (int)((chunk + 1) & ~1ll);
+        w.CoP = g.CoP; w.CiP = g.CiP; w.WR = p.cot / 32; w.accum = a.accum;
+        const int sn = p.cit / (32 * (4 / w.WR));
+        dim3 grid(g.nsplit, g.nciT, g.ncoT);
+        if (sn == 2) hipLaunchKernelGGL(wgrad_pw_kernel<2>, grid, dim3(256), 0, st, w);
+        else hipLaunchKernelGGL(wgrad_pw_kernel<1>, grid, dim3(256), 0, st, w);
+        REFID_LAUNCH_CHECK("wgrad_pw");
+        rc = 0;
+    } else if (d->phase != 3) switch (p.id) {
         case P_W3: rc = launch_w<W3>(a, g, st); break;
         case P_W3_64x32: rc = launch_w<W3_64x32>(a, g, st); break;
         case P_W3_32x64: rc = launch_w<W3_32x64>(a, g, st); break;

@@ -192,6 +192,11 @@ def test_conv_transpose_fwd_and_dgrad(cfg):
     (1, 16, 24, 28, 0, 32, 5, 1, 2),
     (2, 8, 16, 128, 128, 128, 1, 1, 0),
     (1, 16, 16, 32, 0, 64, 1, 1, 0),
+    (2, 9, 13, 64, 0, 128, 1, 1, 0),          # pointwise tile: odd pixel count, 4x1 waves
+    (1, 8, 8, 128, 0, 64, 1, 1, 0),           # 2x2 waves, SN=2
+    (1, 7, 5, 64, 64, 32, 1, 1, 0),           # 1x4 waves, two sources
+    (1, 8, 8, 256, 256, 256, 1, 1, 0),        # several channel tiles
+    (1, 8, 8, 16, 0, 16, 1, 1, 0),            # narrow: LDS-tiled fallback
     (2, 16, 32, 64, 0, 64, 4, 2, 1),
     (1, 24, 40, 128, 0, 128, 4, 2, 1),
     (1, 16, 16, 32, 0, 64, 2, 2, 0),

@@ -181,6 +181,29 @@ int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float*
 int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
                           int ld_gx, const float* res, int ld_res, float* dw, float* db, long long npix,
                           int c, float eps, void* stream);
+/* ------------------------------------------------------------------------------------
+ * SingleMultiConnectEVHINet non-GEMM pieces (SURVEY.md 8f row 4;
+ * archs/single_multiconnect_evhinet_arch.py:233-237 HIN + LeakyReLU, archs/arch_util.py:421-426 FAC_bias).
+ * Deterministic (two-stage reductions, no atomics).
+ * ---------------------------------------------------------------------------------- */
+int refid_hin_parts(int hw);                 /* partial-sum rows the scratch buffers must hold per sample */
+/* out = LeakyReLU( [ InstanceNorm(x[:, :ch]) * gamma + beta | x[:, ch:] ] ); biased variance, eps inside the
+ * root; stats (n,2,ch) receives mean / rstd; parts = scratch (n, refid_hin_parts(hw), 2, ch).  ch = 0: plain
+ * LeakyReLU.  ch must be 4 * 2^k. */
+int refid_hin_lrelu_fwd(const float* x, int ld_x, const float* gamma, const float* beta, float* out, int ld_out,
+                        float* stats, float* parts, int n, int hw, int c, int ch, float eps, float slope,
+                        void* stream);
+/* gx = d/dx of the above given g = dL/dout; dgamma/dbeta ACCUMULATE; sums = scratch (n,2,ch). */
+int refid_hin_lrelu_bwd(const float* g, int ld_g, const float* out, int ld_out, const float* x, int ld_x,
+                        const float* gamma, const float* stats, float* gx, int ld_gx, float* dgamma,
+                        float* dbeta, float* sums, float* parts, int n, int hw, int c, int ch, float slope,
+                        void* stream);
+/* FAC_bias: out = feat * filt[:, :c] + filt[:, c:2c]  and its backward (gfilt = [g*feat | g]). */
+int refid_fac_fwd(const float* feat, int ld_feat, const float* filt, int ld_filt, float* out, int ld_out,
+                  long long npix, int c, void* stream);
+int refid_fac_bwd(const float* g, int ld_g, const float* feat, int ld_feat, const float* filt, int ld_filt,
+                  float* gfeat, int ld_gfeat, float* gfilt, int ld_gfilt, long long npix, int c, void* stream);
+
 /* pre = dwconv3x3(in)+b ; act = GELU(pre) ; pool[n][part][c] = per-workgroup partial sums of act
  * (fm:304-309 + se_1's AdaptiveAvgPool2d, fm:253-254; pool may be NULL; parts =
  * refid_dwconv_pool_parts(h,w,c); deterministic, no atomics).  w is the reference (c,1,3,3) tensor. */

@@ -183,11 +183,49 @@ def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wa
           f"out mean|.|={pred.abs().mean():.4f}")
 
 
+def run_evhinet(losses, name, wf, B, H, W, seed, train, out_dir, sub=1):
+    """the reference's SingleMultiConnectEVHINet on closed-form weights / inputs.
+    arch_util.py imports timm (absent here) for classes this path never touches: stub the three names."""
+    from oracle import evhinet_oracle as E
+    for nm in ("timm", "timm.models", "timm.models.layers"):
+        sys.modules.setdefault(nm, types.ModuleType(nm))
+    lay = sys.modules["timm.models.layers"]
+    lay.DropPath, lay.trunc_normal_, lay.to_2tuple = torch.nn.Identity, torch.nn.init.trunc_normal_, (lambda v: (v, v))
+    mod = importlib.import_module("basicsr.models.archs.single_multiconnect_evhinet_arch")
+    net = mod.SingleMultiConnectEVHINet(wf=wf)
+    P = E.make_params(seed=seed, wf=wf)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(P.keys()), "state-dict keys/order differ from oracle.evhinet_oracle.param_shapes"
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(P[k].shape), k
+    net.load_state_dict(P, strict=True)
+    x, ev, gt = E.make_inputs(B, H, W, seed=seed)
+    out = net(x=x, event=ev)
+    assert isinstance(out, list) and len(out) == 1
+    rec = {"meta": np.array([wf, B, H, W, seed]), "out": out[0].detach().numpy()[..., ::sub, ::sub]}
+    if train:
+        loss = losses.PSNRLoss()(out[0], gt)
+        loss.backward()
+        rec["loss"] = np.array(float(loss))
+        for k, p in net.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            rec["grad/" + k] = g.numpy()
+        rec["no_grad_keys"] = np.array([k for k, p in net.named_parameters() if p.grad is None])
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+    print(name, "out mean", float(out[0].mean()), "loss", float(rec.get("loss", np.nan)))
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
     arch, losses = import_reference()
+    if os.environ.get("ONLY") != "refid":
+        run_evhinet(losses, "evhinet_tiny_train", 8, 2, 32, 32, 1, True, out_dir)
+        run_evhinet(losses, "evhinet_odd_train", 16, 1, 40, 24, 2, True, out_dir)
+        run_evhinet(losses, "evhinet_full_fwd", 64, 1, 64, 64, 3, False, out_dir, sub=2)
+        if os.environ.get("ONLY") == "evhinet":
+            return
     # dense taps + full train step, blur-VFI (26 ch) and sharp-VFI (5-D x, 6 ch)
     run_case(arch, losses, "tiny26_train", 26, 8, 2, 3, 32, 32, 1, True, True, out_dir)
     run_case(arch, losses, "tiny6_train", 6, 8, 2, 3, 32, 32, 2, True, True, out_dir)

@@ -114,6 +114,11 @@ def _bind_extra(L):
     L.refid_ssim3d_u8.argtypes = [vp, vp, i, i, i, vp, vp]
     L.refid_tile_add.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     L.refid_tile_normalize.argtypes = [vp, vp, i, i, i, vp]
+    L.refid_hin_parts.argtypes = [i]
+    L.refid_hin_lrelu_fwd.argtypes = [vp, i, vp, vp, vp, i, vp, vp, i, i, i, i, f, f, vp]
+    L.refid_hin_lrelu_bwd.argtypes = [vp, i, vp, i, vp, i, vp, vp, vp, i, vp, vp, vp, vp, i, i, i, i, f, vp]
+    L.refid_fac_fwd.argtypes = [vp, i, vp, i, vp, i, ll, i, vp]
+    L.refid_fac_bwd.argtypes = [vp, i, vp, i, vp, i, vp, i, vp, i, ll, i, vp]
 
 
 def check(rc, what):

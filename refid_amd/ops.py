@@ -427,3 +427,69 @@ def clip_adamw(p, g, m, v, sqnorm, *, max_norm, lr, betas, eps, weight_decay, st
                                  sqnorm.data_ptr() if sqnorm is not None else None, max_norm, grad_scale, lr,
                                  betas[0], betas[1], eps, weight_decay, step, p.numel(), _stream()),
           "refid_clip_adamw")
+
+
+# ---------------------------------------------------------------------------------------------
+# SingleMultiConnectEVHINet non-GEMM pieces (csrc/evhinet.hip)
+# ---------------------------------------------------------------------------------------------
+def hin_lrelu_fwd(x, gamma, beta, slope=0.2, eps=1e-5):
+    """LeakyReLU([InstanceNorm(x[..., :ch]) * gamma + beta | x[..., ch:]]), ch = len(gamma) (None: plain LeakyReLU).
+    Returns (out, stats) with stats (n, 2, ch) = mean / rstd (None when ch == 0)."""
+    px, ld = _nhwc(x, "x")
+    n, h, w, c = x.shape
+    ch = 0 if gamma is None else gamma.numel()
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    stats = parts = None
+    if ch:
+        stats = torch.empty((n, 2, ch), dtype=torch.float32, device=x.device)
+        parts = torch.empty((n, lib().refid_hin_parts(h * w), 2, ch), dtype=torch.float32, device=x.device)
+    check(lib().refid_hin_lrelu_fwd(px, ld, _c(gamma, "gamma") if ch else None, _c(beta, "beta") if ch else None,
+                                    out.data_ptr(), c, stats.data_ptr() if ch else None,
+                                    parts.data_ptr() if ch else None, n, h * w, c, ch, eps, slope, _stream()),
+          "refid_hin_lrelu_fwd")
+    return out, stats
+
+
+def hin_lrelu_bwd(g, out, x, gamma, stats, dgamma, dbeta, slope=0.2):
+    """Gradient w.r.t. x of hin_lrelu_fwd; dgamma / dbeta accumulate."""
+    pg, ldg = _nhwc(g, "g")
+    po, ldo = _nhwc(out, "out")
+    n, h, w, c = out.shape
+    ch = 0 if gamma is None else gamma.numel()
+    gx = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+    px, ldx = _nhwc(x, "x") if ch else (None, 0)
+    sums = parts = None
+    if ch:
+        sums = torch.empty((n, 2, ch), dtype=torch.float32, device=g.device)
+        parts = torch.empty((n, lib().refid_hin_parts(h * w), 2, ch), dtype=torch.float32, device=g.device)
+    check(lib().refid_hin_lrelu_bwd(pg, ldg, po, ldo, px, ldx, _c(gamma, "gamma") if ch else None,
+                                    _c(stats, "stats") if ch else None, gx.data_ptr(), c,
+                                    _c(dgamma, "dgamma") if ch else None, _c(dbeta, "dbeta") if ch else None,
+                                    sums.data_ptr() if ch else None, parts.data_ptr() if ch else None, n, h * w, c, ch,
+                                    slope, _stream()), "refid_hin_lrelu_bwd")
+    return gx
+
+
+def fac_fwd(feat, filt):
+    """FAC_bias: feat * filt[..., :C] + filt[..., C:]."""
+    pf, ldf = _nhwc(feat, "feat")
+    pi, ldi = _nhwc(filt, "filt")
+    n, h, w, c = feat.shape
+    if filt.shape[3] != 2 * c:
+        raise _lib.RefidHipError(f"fac_fwd: filter has {filt.shape[3]} channels, expected {2 * c}")
+    out = torch.empty((n, h, w, c), dtype=torch.float32, device=feat.device)
+    check(lib().refid_fac_fwd(pf, ldf, pi, ldi, out.data_ptr(), c, n * h * w, c, _stream()), "refid_fac_fwd")
+    return out
+
+
+def fac_bwd(g, feat, filt):
+    """Returns (g_feat, g_filt)."""
+    pg, ldg = _nhwc(g, "g")
+    pf, ldf = _nhwc(feat, "feat")
+    pi, ldi = _nhwc(filt, "filt")
+    n, h, w, c = feat.shape
+    gfeat = torch.empty((n, h, w, c), dtype=torch.float32, device=g.device)
+    gfilt = torch.empty((n, h, w, 2 * c), dtype=torch.float32, device=g.device)
+    check(lib().refid_fac_bwd(pg, ldg, pf, ldf, pi, ldi, gfeat.data_ptr(), c, gfilt.data_ptr(), 2 * c, n * h * w, c,
+                              _stream()), "refid_fac_bwd")
+    return gfeat, gfilt

@@ -23,6 +23,8 @@ from .dist import GradSync, get_dist_info
 
 
 class TwoImageEventRecurrentRestorationModel:
+    PIXEL_LOSSES = ("CharbonnierLoss",)            # the only one the reference's configs for this model use
+
     def __init__(self, opt):
         self.opt = opt
         self.device = torch.device("cuda" if opt.get("num_gpu", 1) != 0 else "cpu")
@@ -43,8 +45,9 @@ class TwoImageEventRecurrentRestorationModel:
         pix = train_opt.get("pixel_opt")
         if not pix:
             raise ValueError("Both pixel and perceptual losses are None.")
-        if pix.get("type") != "CharbonnierLoss" or pix.get("reduction", "mean") != "mean":
-            raise NotImplementedError("only CharbonnierLoss(reduction=mean) is used by the reference configs")
+        if pix.get("type") not in self.PIXEL_LOSSES or pix.get("reduction", "mean") != "mean":
+            raise NotImplementedError(f"pixel loss {pix.get('type')!r}: supported here: {self.PIXEL_LOSSES} (reduction=mean)")
+        self.pixel_type = pix["type"]
         self.loss_weight = float(pix.get("loss_weight", 1.0))
         self.loss_eps = float(pix.get("eps", 1e-12))
         og = dict(train_opt["optim_g"])
@@ -104,10 +107,7 @@ class TwoImageEventRecurrentRestorationModel:
         eng = self.net_g.engine
         eng.zero_grad()                                          # optimizer_g.zero_grad()
         pred = eng.forward(self.lq, self.voxel, save=True)       # net_g(x=lq, event=voxel)
-        gpred = torch.empty_like(pred)
-        n = pred.numel()
-        loss_sum = ops.charbonnier(pred, self.gt.contiguous(), gpred, eps=self.loss_eps,
-                                   grad_scale=self.loss_weight / n)          # cri_pix + d/dpred
+        gpred, loss_sum, n = self._loss_and_grad(pred)           # cri_pix + d/dpred
         eng.backward(gpred, grad_sync=self.grad_sync)            # l_total.backward() (+ RCCL all-reduce)
         flat_g = eng.arena.flat_g
         max_norm = 0.01 if self.use_grad_clip else 0.0           # clip_grad_norm_(params, 0.01)
@@ -121,6 +121,13 @@ class TwoImageEventRecurrentRestorationModel:
         self.output = pred
         self._loss_sum, self._loss_n = loss_sum, n
         self.log_dict = None
+
+    def _loss_and_grad(self, pred):
+        """Returns (dL/dpred, un-weighted loss sum (1-element tensor), count): l_pix = weight * sum / count."""
+        gpred = torch.empty_like(pred)
+        n = pred.numel()
+        loss_sum = ops.charbonnier(pred, self.gt.contiguous(), gpred, eps=self.loss_eps, grad_scale=self.loss_weight / n)
+        return gpred, loss_sum, n
 
     def get_current_log(self):
         """reduce_loss_dict (base_model.py:325-350): mean over ranks, evaluated lazily (one sync)."""
@@ -162,3 +169,36 @@ class TwoImageEventRecurrentRestorationModel:
             load_net = load_net[param_key]
         load_net = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in load_net.items())
         net.load_state_dict(load_net, strict=strict)
+
+
+class ImageEventRestorationModel(TwoImageEventRecurrentRestorationModel):
+    """Single-image event deblurring model (reference image_event_restoration_model.py:21-345) around
+    ``SingleMultiConnectEVHINet``: same method names (``feed_data``, ``optimize_parameters``, ``test``, ...), 4-D tensors,
+    ``net_g`` returns a list whose last element is the output (:275-280, :337-340).  Pixel losses: ``PSNRLoss``
+    (losses.py:95-120, toY=False) and ``CharbonnierLoss``; clip_grad_norm_(0.01) + AdamW as in :317-320."""
+    PIXEL_LOSSES = ("PSNRLoss", "CharbonnierLoss")
+
+    def _loss_and_grad(self, pred):
+        if self.pixel_type != "PSNRLoss":
+            return super()._loss_and_grad(pred)
+        # PSNRLoss = w * 10/ln10 * mean_b log(mse_b + 1e-8): a (B,C,H,W)-sized elementwise expression, on the GPU
+        scale = 10.0 / math.log(10.0)
+        d = pred - self.gt
+        mse = (d * d).mean(dim=(1, 2, 3))
+        loss = scale * torch.log(mse + 1e-8).mean()
+        coef = self.loss_weight * scale * 2.0 / (d[0].numel() * d.shape[0]) / (mse + 1e-8)
+        return d * coef.view(-1, 1, 1, 1), loss.double().reshape(1), 1
+
+    def test(self):
+        self.net_g.eval()
+        with torch.no_grad():
+            n = self.lq.size(0)
+            m = self.opt.get("val", {}).get("max_minibatch", n) or n
+            outs, i = [], 0
+            while i < n:
+                j = min(i + m, n)
+                pred = self.net_g(x=self.lq[i:j], event=self.voxel[i:j])
+                outs.append(pred[-1] if isinstance(pred, list) else pred)
+                i = j
+            self.output = torch.cat(outs, dim=0)
+        self.net_g.train()

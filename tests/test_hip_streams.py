@@ -39,8 +39,29 @@ def _grads(stall):
     return {k: p.grad.detach().double().cpu() for k, p in net.named_parameters()}
 
 
-def test_weight_gradients_survive_a_stalled_side_stream(monkeypatch):
+def _grads_evhinet(stall):
+    from oracle import evhinet_oracle as E
     from refid_amd import engine
+    from refid_amd.archs import define_network
+    net = define_network(dict(type="SingleMultiConnectEVHINet", wf=8))
+    net.load_state_dict(E.make_params(seed=2, wf=8), strict=True)
+    net = net.cuda()
+    x, ev, gt = E.make_inputs(2, 32, 32, seed=2)
+    out = net(x=x.cuda(), event=ev.cuda())[0]
+    loss = torch.sqrt((out - gt.cuda()) ** 2 + 1e-12).mean()
+    torch.cuda.synchronize()
+    if stall:
+        with torch.cuda.stream(engine.WGRAD_STREAM.get(torch.device("cuda", 0))):
+            torch.cuda._sleep(stall)
+    loss.backward()
+    torch.cuda.synchronize()
+    return {k: p.grad.detach().double().cpu() for k, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("which", ["refid", "evhinet"])
+def test_weight_gradients_survive_a_stalled_side_stream(monkeypatch, which):
+    from refid_amd import engine
+    _grads = globals()["_grads"] if which == "refid" else _grads_evhinet
     monkeypatch.setattr(engine, "OVERLAP_WGRAD", False)
     ref = _grads(0)
     monkeypatch.setattr(engine, "OVERLAP_WGRAD", True)

@@ -162,3 +162,18 @@ def test_cosine_schedule_matches_reference_stepping():
             opt.step(); sch.step(); epoch += 1
         mine = 1e-7 + (2e-4 - 1e-7) * (1 + math.cos(math.pi * epoch / 100)) / 2
         assert abs(opt.param_groups[0]["lr"] - mine) < 1e-12
+
+
+def test_evhinet_module_mirrors_reference_state_dict_on_cpu():
+    """SURVEY 8f row 4: keys / shapes / order of the HIP module == the reference's (via the pinned oracle inventory);
+    on CPU the module exists but refuses to run (no fallback)."""
+    from oracle import evhinet_oracle as E
+    from refid_amd.archs import define_network
+    from refid_amd._lib import RefidHipError
+    net = define_network(dict(type="SingleMultiConnectEVHINet"))
+    want = E.param_shapes()
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(want.keys()) and len(sd) == 156
+    assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
+    with pytest.raises(RefidHipError):
+        net(x=torch.zeros(1, 3, 16, 16), event=torch.zeros(1, 6, 16, 16))

@@ -112,3 +112,42 @@ def test_cosine_lr_matches_torch():
     for i in range(1, 20):
         opt.step(); sch.step()
         assert abs(opt.param_groups[0]["lr"] - O.cosine_lr(2e-4, i, 50, 1e-7)) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# SingleMultiConnectEVHINet restatement vs the reference class's own outputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["evhinet_tiny_train", "evhinet_odd_train", "evhinet_full_fwd"])
+def test_evhinet_oracle_matches_reference(golden_dir, name):
+    from oracle import evhinet_oracle as E
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    wf, B, H, W, seed = [int(v) for v in z["meta"]]
+    P = E.make_params(seed=seed, wf=wf)
+    x, ev, gt = E.make_inputs(B, H, W, seed=seed)
+    train = "loss" in z.files
+    if train:
+        for p in P.values():
+            p.requires_grad_(True)
+    out = E.forward(P, x, ev)
+    sub = 2 if name == "evhinet_full_fwd" else 1
+    np.testing.assert_allclose(out.detach().numpy()[..., ::sub, ::sub], z["out"], rtol=1e-4, atol=1e-5)
+    if not train:
+        return
+    loss = E.psnr_loss(out, gt)
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    loss.backward()
+    dead = set(str(k) for k in z["no_grad_keys"])
+    for k, p in P.items():
+        ref = z["grad/" + k]
+        if k in dead:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        scale = max(float(np.abs(ref).max()), 1e-8)
+        assert float(np.abs(p.grad.numpy() - ref).max()) <= 2e-4 * scale + 1e-9, k
+    # the dead set is what the module docstring says it is
+    live_prefixes = ("conv_ev1", "down_path_ev.0", "down_path_ev.1", "conv_01", "down_path_1", "skip_conv_1",
+                     "up_path_1", "sam12.conv2")
+    for k in P:
+        if not k.startswith(live_prefixes):
+            assert k in dead, k
+    assert "down_path_ev.1.downsample.weight" in dead

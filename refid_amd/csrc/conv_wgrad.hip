@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
             if (gcok && p < C::PX && oy < a.Ho && ox < a.Wo)
                 v = *reinterpret_cast<const f32x4*>(a.g + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
             rg[it] = v;
-            bsum += v;
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {
@@ -129,6 +128,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
         for (int it = 0; it < C::G_ITEMS; ++it) {
             const int p = tid / C::G4 + it * (256 / C::G4);
             if (p < C::PX) sG4[p * C::G4 + gq] = rg[it];
+            bsum += rg[it];          // bias partial: summed HERE, not at load time -- using a prefetched register right
+                                     // after its load was issued forced a vmcnt(0) before the MFMA section
         }
 #pragma unroll
         for (int it = 0; it < C::X_ITEMS; ++it) {

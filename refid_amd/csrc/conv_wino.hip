@@ -76,11 +76,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     // ---- loaders: buffer loads (wave-uniform descriptor + per-chunk scalar offset + a per-thread
     // byte offset that never changes across chunks); out-of-image pixels / out-of-range weight rows
     // carry an out-of-range offset and come back as zeros -- no branches, no per-chunk address math.
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.inA), 0, (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.inB ? a.inB : a.inA), 0,
-        (int)min((long long)a.N * a.H * a.W * (a.inB ? a.ldB : a.ldA) * 4, 0x7fffffffLL), 0x00020000);
+    const int limA = (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL);
+    const int limB = a.inB ? (int)min((long long)a.N * a.H * a.W * a.ldB * 4, 0x7fffffffLL) : 0;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * 16 * a.CoutPad * KC * 4, 0x7fffffffLL), 0x00020000);
     const int q = tid & 1;
@@ -109,12 +106,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         const bool fromA = c0 < a.Ca;
         const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
         const bool qok = c0 + q * 4 < a.Ctot;              // Ctot % 8 == 4: upper quad of the last chunk
+        // ONE descriptor, selected with scalar ops: a per-lane choice between two descriptors makes the compiler
+        // emit a readfirstlane "waterfall" loop plus full vmcnt(0) drains inside the phase
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
 #pragma unroll
         for (int it = 0; it < R_ITEMS; ++it) {
             const int vo = qok ? (fromA ? voA[it] : voB[it]) : OOB;
-            const u32x4 v = fromA ? __builtin_amdgcn_raw_buffer_load_b128(rsA, vo, soff, 0)
-                                  : __builtin_amdgcn_raw_buffer_load_b128(rsB, vo, soff, 0);
-            rr[it] = __builtin_bit_cast(f32x4, v);
+            rr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
         }
     };
     auto store_raw = [&](int buf) {
@@ -147,6 +146,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     // one K chunk: cur = this chunk's U fragments, nxt = register set the next chunk's are prefetched into
     auto phase = [&](int ch, f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
         const bool more = ch + 1 < a.nchunks;
+        // Everything still in flight was issued one phase ago and is needed NOW (U(ch) by the MFMAs, raw(ch+1) by
+        // store_raw).  Stating that as an explicit vmcnt(0) keeps the compiler's conservative, path-merged counters
+        // from draining THIS phase's prefetches inside the MFMA section (which made every other phase last a full
+        // memory latency).  simm16: vmcnt = 0, expcnt = 7, lgkmcnt = 15 (gfx9 encoding).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (more) {
             store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
             load_u(ch + 1, nxt);

@@ -92,7 +92,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
             if (gcok && oy < a.Ho && ox < a.Wo)
                 v = *reinterpret_cast<const f32x4*>(a.g + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
             rg[it] = v;
-            bsum += v;
         }
 #pragma unroll
         for (int it = 0; it < X_ITEMS; ++it) {
@@ -109,6 +108,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         for (int it = 0; it < G_ITEMS; ++it) {
             const int p = tid / G4 + it * (256 / G4);
             sG4[p * G4 + gq] = rg[it];
+            bsum += rg[it];          // bias partial: summed HERE, not at load time -- using a prefetched register right
+                                     // after its load was issued forced a vmcnt(0) before the MFMA section
         }
 #pragma unroll
         for (int it = 0; it < X_ITEMS; ++it) {

@@ -16,19 +16,21 @@
 //   * workgroup tile = 4x32 output pixels = 32 Winograd tiles (2 tile rows x 16 tile cols)
 //     x 64 output channels; K walks input channels in chunks of 8.
 //   * the 16 transform-domain GEMMs  M_xi[cout][tile] += U_xi[cout][c] * V_xi[c][tile]  run on
-//     v_mfma_f32_32x32x2_f32.  A wave owns 8 of the 16 xi (transform rows i = 2h, 2h+1) for 32
-//     output channels: 8 accumulators = 128 AGPRs, so two waves fit per SIMD.  4 waves =
-//     {xi half h} x {channel half nt}.
+//     v_mfma_f32_32x32x2_f32.  Wave w owns transform ROW i = w (xi = 4i..4i+3) for all 64 output channels:
+//     8 accumulators = 128 registers, two waves per SIMD.
+//   * on gfx950 VALU and LDS instructions do NOT hide under MFMAs (tools/probes/mfma_valu_overlap.hip: ~2.3
+//     matrix-pipe cycles per VALU instruction, ~28 per ds_read_b128, from either wave of the SIMD), so the
+//     loop is organised to minimise non-MFMA instructions per MFMA: a wave transforms only its own row of
+//     B^T d B (8 x ds_read_b128 + 32 VALU per chunk) and feeds 32 MFMAs from it (both column tiles reuse it).
 //   * both MFMA operands live in REGISTERS: the raw 6x34-pixel input halo of the next chunk is
 //     prefetched global->VGPR->LDS (double buffered, 6.5 KB each) while the current chunk's MFMAs
-//     run; each lane reads the 3x4 patch rows of ITS tile / channel quad (12 x ds_read_b128) and
-//     computes its own 8 fragments of B^T d B (16 float4 adds).  One barrier per chunk.
+//     run.  One barrier per chunk.
 //   * transformed weights U = G g G^T are produced once per step by the pack kernel in the
-//     [chunk][xi][cout][8] layout; a lane's fragment is one 16-byte buffer load per xi (a wave reads
-//     1 KB contiguous), prefetched one chunk ahead -- weights never pass through LDS.
-//   * output transform: each lane reduces its 8 accumulators along j in registers, the two xi
-//     halves swap one half of the row-partials through LDS (32 KB, after the K loop), and every
-//     wave finishes one output row parity with the fused 16-byte epilogue.
+//     [chunk][xi][cout][8] layout; a lane's fragment is one 16-byte buffer load per (xi, column tile) (a wave
+//     reads 1 KB contiguous), prefetched one chunk ahead -- weights never pass through LDS.
+//   * output transform: each lane reduces its 4 accumulators along j in registers, the four rows are combined
+//     through LDS once (64 KB, after the K loop), and every wave finishes one output row parity of one column
+//     tile with the fused 16-byte epilogue.
 #include "common.h"
 #include "conv_args.h"
 
@@ -37,16 +39,15 @@ namespace {
 constexpr int TW = 32;                  // output pixels per workgroup row
 constexpr int KC = 8;                   // input channels per chunk
 constexpr int HWD = TW + 2;
-constexpr int LDS_BYTES = 32768;        // 2 raw buffers (13-22 KB) in the K loop; 32 KB exchange afterwards
+constexpr int LDS_BYTES = 65536;        // 2 raw buffers (13-22 KB) in the K loop; 64 KB row exchange afterwards
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 
-// <NTN, MTN>: the two waves that are not xi-halves split either the 64 output channels (NTN = 2:
-// tile 4x32 pixels x 64 channels) or the pixels (MTN = 2: tile 8x32 pixels x 32 channels, for the
-// 32-channel layers).
+// <NTN, MTN>: a wave's second dimension is either two 32-channel column tiles (NTN = 2: workgroup tile
+// 4x32 pixels x 64 channels) or two 4-row pixel tiles (MTN = 2: 8x32 pixels x 32 channels, 32-channel layers).
 template <int NTN, int MTN>
 __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
-    static_assert(NTN * MTN == 2, "4 waves = 2 xi halves x 2");
+    static_assert(NTN * MTN == 2, "a wave owns one transform row x 2 (column | pixel) tiles");
     constexpr int TH = 4 * MTN;             // output rows per workgroup
     constexpr int BN = 32 * NTN;            // output channels per workgroup
     constexpr int HP = (TH + 2) * HWD;      // raw input halo pixels
@@ -58,8 +59,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
-    const int h = wave & 1;
-    const int nt = (NTN == 2) ? (wave >> 1) : 0, mt = (MTN == 2) ? (wave >> 1) : 0;
+    const int ti = wave;                                   // transform row i owned by this wave (xi = 4i .. 4i+3)
 
     // XCD-aware work mapping: workgroup b runs on XCD b % 8 (observed dispatch order; used for L2
     // affinity only).  The ncot channel tiles of one pixel tile are consecutive on the SAME XCD, so
@@ -91,15 +91,18 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         voA[it] = ok ? pix * a.ldA * 4 + q * 16 : OOB;
         voB[it] = ok ? pix * a.ldB * 4 + q * 16 : OOB;
     }
-    // U fragment of this lane: row (cout) nt*32+li, K quad kh, for the wave's 8 xi -- read straight
-    // from the packed [chunk][xi][cout][8] weights (a wave reads 1 KB contiguous per xi): weights
-    // never pass through LDS.
-    const int urow = a.coBase + n0 + nt * 32 + li;
-    const int voU = (urow < a.CoutPad) ? ((h * 8 * a.CoutPad + urow) * KC + kh * 4) * 4 : OOB;
+    // U fragments of this lane: rows (cout) n0 + nt*32 + li, K quad kh, the wave's 4 xi -- straight from the
+    // packed [chunk][xi][cout][8] weights (a wave reads 1 KB contiguous per fragment), never through LDS.
+    int voU[NTN];
+#pragma unroll
+    for (int nt = 0; nt < NTN; ++nt) {
+        const int urow = a.coBase + n0 + nt * 32 + li;
+        voU[nt] = (urow < a.CoutPad) ? ((ti * 4 * a.CoutPad + urow) * KC + kh * 4) * 4 : OOB;
+    }
     const int uStep = a.CoutPad * KC * 4;                  // bytes between xi and xi+1
     const int uChunk = 16 * a.CoutPad * KC * 4;            // bytes per K chunk
 
-    f32x4 rr[R_ITEMS], ufA[8], ufB[8];
+    f32x4 rr[R_ITEMS], ufA[4 * NTN], ufB[4 * NTN];
 
     auto load_raw = [&](int ch) {
         const int c0 = ch * KC;                            // chunk-uniform: Ca % 8 == 0 for two sources
@@ -123,69 +126,67 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
             if (hp < HP) sR[buf * R_F4 + q * HP + hp] = rr[it];
         }
     };
-    auto load_u = [&](int ch, f32x4 (&dst)[8]) {
+    auto load_u = [&](int ch, f32x4 (&dst)[4 * NTN]) {
 #pragma unroll
-        for (int x = 0; x < 8; ++x)
-            dst[x] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voU, ch * uChunk + x * uStep, 0));
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int nt = 0; nt < NTN; ++nt)
+                dst[j * NTN + nt] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voU[nt], ch * uChunk + j * uStep, 0));
     };
 
-    f32x16 acc[8];
+    // acc[j][t]: transform column j, second-dimension tile t (column tile nt or pixel tile mt)
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int x = 0; x < 8; ++x)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
-    // input patch of this lane's tile: halo rows r0..r0+2 (h=0: patch rows 0,1,2; h=1: rows 1,2,3), 4 cols
-    const int hp0 = (4 * mt + 2 * (li >> 4) + h) * HWD + 2 * (li & 15);
-    // transform row 2h   = p - m with (p,m) = halo rows (0,2) for h=0, (1,0) for h=1   [d0-d2 | d2-d1]
-    // transform row 2h+1 =            rows (1)+(2) for h=0, (0)-(2) for h=1            [d1+d2 | d1-d3]
-    const int rAp = h ? HWD : 0, rAm = h ? 0 : 2 * HWD;
-    const int rBp = h ? 0 : HWD, rBm = 2 * HWD;
-    const float sB = h ? -1.f : 1.f;
+    // B^T row i of the 4x4 input patch of this lane's tile: t = d[P] + sgn * d[M]
+    //   i=0: d0 - d2   i=1: d1 + d2   i=2: d2 - d1   i=3: d1 - d3
+    const int rowP = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
+    const int rowM = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
+    const float sgn = (ti == 1) ? 1.f : -1.f;
+    const int hp0 = (2 * (li >> 4)) * HWD + 2 * (li & 15);           // tile origin inside a 4-row pixel tile
+    const int offP = hp0 + rowP * HWD, offM = hp0 + rowM * HWD;
 
     // one K chunk: cur = this chunk's U fragments, nxt = register set the next chunk's are prefetched into
-    auto phase = [&](int ch, f32x4 (&cur)[8], f32x4 (&nxt)[8]) {
+    auto phase = [&](int ch, f32x4 (&cur)[4 * NTN], f32x4 (&nxt)[4 * NTN]) {
         const bool more = ch + 1 < a.nchunks;
         // Everything still in flight was issued one phase ago and is needed NOW (U(ch) by the MFMAs, raw(ch+1) by
         // store_raw).  Stating that as an explicit vmcnt(0) keeps the compiler's conservative, path-merged counters
-        // from draining THIS phase's prefetches inside the MFMA section (which made every other phase last a full
-        // memory latency).  simm16: vmcnt = 0, expcnt = 7, lgkmcnt = 15 (gfx9 encoding).
+        // from draining THIS phase's prefetches inside the MFMA section.  simm16: vmcnt 0, expcnt 7, lgkmcnt 15.
         __builtin_amdgcn_s_waitcnt(0x0F70);
         if (more) {
             store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
             load_u(ch + 1, nxt);
             if (ch + 2 < a.nchunks) load_raw(ch + 2);
         }
-        // B^T d B for this lane's tile / channel quad, one transform row at a time, in registers
-        const f32x4* r = sR + (ch & 1) * R_F4 + kh * HP + hp0;
+        // Measured on gfx950 (tools/probes/mfma_valu_overlap.hip): every VALU instruction costs ~2.3 and every
+        // ds_read_b128 ~28 cycles of matrix-pipe time, from either wave of the SIMD -- they do not hide under
+        // MFMAs.  So a wave transforms only ITS row of B^T d B (8 reads, 32 VALU per pixel tile) and reuses it for
+        // both column tiles.
+        const f32x4* r = sR + (ch & 1) * R_F4 + kh * HP;
         __builtin_amdgcn_s_setprio(1);
-        {
+#pragma unroll
+        for (int mt = 0; mt < MTN; ++mt) {
+            const f32x4* rp = r + offP + mt * 4 * HWD;
+            const f32x4* rm = r + offM + mt * 4 * HWD;
             f32x4 t[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) t[b] = r[rAp + b] - r[rAm + b];
-            const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
+            for (int b = 0; b < 4; ++b) t[b] = rp[b] + rm[b] * sgn;
+            f32x4 v[4];
+            v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[0][kk], v0[kk], acc[0], 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[1][kk], v1[kk], acc[1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[2][kk], v2[kk], acc[2], 0, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[3][kk], v3[kk], acc[3], 0, 0, 0);
-        }
-        {
-            f32x4 t[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) t[b] = r[rBp + b] + r[rBm + b] * sB;
-            const f32x4 v0 = t[0] - t[2], v1 = t[1] + t[2], v2 = t[2] - t[1], v3 = t[1] - t[3];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[4][kk], v0[kk], acc[4], 0, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[5][kk], v1[kk], acc[5], 0, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[6][kk], v2[kk], acc[6], 0, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur[7][kk], v3[kk], acc[7], 0, 0, 0);
+                    for (int nt = 0; nt < NTN; ++nt)          // consecutive MFMAs hit different accumulators
+                        acc[j][NTN == 2 ? nt : mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            cur[j * NTN + nt][kk], v[j][kk], acc[j][NTN == 2 ? nt : mt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();                             // raw(ch) consumed by every wave; raw(ch+1) visible
@@ -204,32 +205,44 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     }
 
     // ---- output transform --------------------------------------------------------------------------
-    // lane: tile li, channels (r&3)+8(r>>2)+4kh of the wave's 32;  acc[i'*4+j] = M[2h+i'][j]
-    // R[i'][b] = sum_j M[i'][j] A^T[b][j] :  b=0: M0+M1+M2   b=1: M1-M2-M3
-    f32x16 keep[2];
-    float* xch = reinterpret_cast<float*>(smem);            // [wave][b][reg][lane], 8 KB per wave
-    const float ks = h ? -1.f : 1.f;
+    // lane: tile li, channels (r&3)+8(r>>2)+4kh of a 32-channel tile;  acc[j][t] = M[i][j]
+    //   R_i[b] = sum_j M[i][j] A[j][b] :  b=0: M0+M1+M2   b=1: M1-M2-M3          (in registers)
+    //   Y[a][b] = sum_i A^T[a][i] R_i[b]:  a=0: R0+R1+R2   a=1: R1-R2-R3          (across the 4 waves, through LDS)
+    // exchange layout: [i][b][t][register quad][lane] float4 = 64 KB
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float r00 = acc[0][r] + acc[1][r] + acc[2][r], r01 = acc[1][r] - acc[2][r] - acc[3][r];
-        const float r10 = acc[4][r] + acc[5][r] + acc[6][r], r11 = acc[5][r] - acc[6][r] - acc[7][r];
-        // Y[a][b] = sum_i A^T[a][i] R[i][b]:  a=0: R0+R1+R2   a=1: R1-R2-R3
-        //   h=0 (rows 0,1): own parity a=0 gets R0+R1, partner's a=1 gets R1
-        //   h=1 (rows 2,3): own parity a=1 gets -R2-R3, partner's a=0 gets R2
-        keep[0][r] = ks * (r00 + r10);
-        keep[1][r] = ks * (r01 + r11);
-        xch[((wave * 2 + 0) * 16 + r) * 64 + lane] = h ? r00 : r10;
-        xch[((wave * 2 + 1) * 16 + r) * 64 + lane] = h ? r01 : r11;
-    }
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 r0, r1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * rq + k;
+                r0[k] = acc[0][t][r] + acc[1][t][r] + acc[2][t][r];
+                r1[k] = acc[1][t][r] - acc[2][t][r] - acc[3][t][r];
+            }
+            xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * 64 + lane] = r0;
+            xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * 64 + lane] = r1;
+        }
     __syncthreads();
-    const int partner = wave ^ 1;
+    // this wave finishes output row parity oa of second-dimension tile ot
+    const int oa = wave & 1, ot = wave >> 1;
+    const int i0 = oa ? 1 : 0;                              // a=0: +R0 +R1 +R2 ; a=1: +R1 -R2 -R3
+    const float s1 = oa ? -1.f : 1.f, s2 = oa ? -1.f : 1.f;
+    f32x4 keep[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) keep[b][r] += xch[((partner * 2 + b) * 16 + r) * 64 + lane];
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 x0 = xch[((((i0 + 0) * 2 + b) * 2 + ot) * 4 + rq) * 64 + lane];
+            const f32x4 x1 = xch[((((i0 + 1) * 2 + b) * 2 + ot) * 4 + rq) * 64 + lane];
+            const f32x4 x2 = xch[((((i0 + 2) * 2 + b) * 2 + ot) * 4 + rq) * 64 + lane];
+            keep[b][rq] = x0 + x1 * s1 + x2 * s2;
+        }
 
-    // ---- fused epilogue: this wave owns output row parity a = h, columns b = 0,1 ------------------
-    const int oy = oy0 + 4 * mt + 2 * (li >> 4) + h;
+    // ---- fused epilogue: output row parity oa, columns b = 0,1 ---------------------------------------
+    const int nt = (NTN == 2) ? ot : 0, mt = (MTN == 2) ? ot : 0;
+    const int oy = oy0 + 4 * mt + 2 * (li >> 4) + oa;
     if (oy >= a.Ho) return;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
             const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
             f32x4 v;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(keep[b][4 * g + k] + bv[k], a.slopePre);
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(keep[b][g][k] + bv[k], a.slopePre);
             if (vec) {
                 if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
 #pragma unroll
@@ -266,11 +279,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (j0 + k >= a.Cout) break;
-                    float t = v[k];
-                    if (a.res) t += a.res[op * a.ldR + j0 + k];
-                    t = lrelu(t, a.slopePost);
-                    if (a.mask) t *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
-                    a.out[op * a.ldO + j0 + k] = t;
+                    float tv = v[k];
+                    if (a.res) tv += a.res[op * a.ldR + j0 + k];
+                    tv = lrelu(tv, a.slopePost);
+                    if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                    a.out[op * a.ldO + j0 + k] = tv;
                 }
             }
         }
@@ -288,6 +301,15 @@ int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
     a.nchunks = cdiv(a.Ctot, KC);
     a.ncot = cdiv(a.Cout, bn);
     dim3 grid(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<1, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<2, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e1 != hipSuccess || e2 != hipSuccess) { refid_set_error("conv_wino: LDS attribute failed"); return 2; }
+        attr_set = true;
+    }
     if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, a);
     else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_wino");

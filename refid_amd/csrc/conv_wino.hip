@@ -39,7 +39,7 @@ namespace {
 constexpr int TW = 32;                  // output pixels per workgroup row
 constexpr int KC = 8;                   // input channels per chunk
 constexpr int HWD = TW + 2;
-constexpr int LDS_BYTES = 65536;        // 2 raw buffers (13-22 KB) in the K loop; 64 KB row exchange afterwards
+constexpr int LDS_BYTES = 64 * 66 * 16;   // 2 raw buffers (13-22 KB) in the K loop; 66 KB row exchange afterwards
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 
@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     // lane: tile li, channels (r&3)+8(r>>2)+4kh of a 32-channel tile;  acc[j][t] = M[i][j]
     //   R_i[b] = sum_j M[i][j] A[j][b] :  b=0: M0+M1+M2   b=1: M1-M2-M3          (in registers)
     //   Y[a][b] = sum_i A^T[a][i] R_i[b]:  a=0: R0+R1+R2   a=1: R1-R2-R3          (across the 4 waves, through LDS)
-    // exchange layout: [i][b][t][register quad][lane] float4 = 64 KB
+    // exchange layout: [i][b][t][register quad][kh][33] float4 (the 33 spreads the banks for the readers below)
+    constexpr int XL = 66;
     f32x4* xch = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -221,33 +222,32 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
                 r0[k] = acc[0][t][r] + acc[1][t][r] + acc[2][t][r];
                 r1[k] = acc[1][t][r] - acc[2][t][r] - acc[3][t][r];
             }
-            xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * 64 + lane] = r0;
-            xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * 64 + lane] = r1;
+            xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r0;
+            xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r1;
         }
     __syncthreads();
-    // this wave finishes output row parity oa of second-dimension tile ot
-    const int oa = wave & 1, ot = wave >> 1;
-    const int i0 = oa ? 1 : 0;                              // a=0: +R0 +R1 +R2 ; a=1: +R1 -R2 -R3
-    const float s1 = oa ? -1.f : 1.f, s2 = oa ? -1.f : 1.f;
-    f32x4 keep[2][4];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 x0 = xch[((((i0 + 0) * 2 + b) * 2 + ot) * 4 + rq) * 64 + lane];
-            const f32x4 x1 = xch[((((i0 + 1) * 2 + b) * 2 + ot) * 4 + rq) * 64 + lane];
-            const f32x4 x2 = xch[((((i0 + 2) * 2 + b) * 2 + ot) * 4 + rq) * 64 + lane];
-            keep[b][rq] = x0 + x1 * s1 + x2 * s2;
-        }
 
-    // ---- fused epilogue: output row parity oa, columns b = 0,1 ---------------------------------------
-    const int nt = (NTN == 2) ? ot : 0, mt = (MTN == 2) ? ot : 0;
-    const int oy = oy0 + 4 * mt + 2 * (li >> 4) + oa;
-    if (oy >= a.Ho) return;
+    // ---- fused epilogue, COALESCED: thread -> (output pixel, channel quad) in memory order, so bias / residual /
+    // mask loads and the store are contiguous 1 KB per wave instruction (the MFMA D layout would scatter 16-byte
+    // pieces over 64 rows; at 256^2 the store phase was 15 % of the kernel).  The row combination happens here,
+    // on the way out of LDS.
+    constexpr int C4 = BN / 4;                              // float4 per pixel
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int j0 = n0 + nt * 32 + 8 * g + 4 * kh;
-        if (j0 >= a.Cout) continue;
+    for (int it = 0; it < (TH * TW * C4) / 256; ++it) {
+        const int f = it * 256 + tid;
+        const int c4 = f % C4, pr = f / C4;
+        const int row = pr / TW, col = pr % TW;
+        const int c = c4 * 4;
+        const int nt = c >> 5, rq = (c & 31) >> 3, ckh = (c & 7) >> 2;
+        const int mt = row >> 2, oa = row & 1, tile = ((row & 3) >> 1) * 16 + (col >> 1), ob = col & 1;
+        const int t = (NTN == 2) ? nt : mt;
+        const int oy = oy0 + row, ox = ox0 + col;
+        const int j0 = n0 + c;
+        if (oy >= a.Ho || ox >= a.Wo || j0 >= a.Cout) continue;
+        const f32x4* xp = xch + (((oa * 2 + ob) * 2 + t) * 4 + rq) * XL + ckh * 33 + tile;   // row i0 = oa
+        const float sg = oa ? -1.f : 1.f;                   // a=0: R0+R1+R2 ; a=1: R1-R2-R3
+        f32x4 v = xp[0] + (xp[16 * XL] + xp[32 * XL]) * sg;  // rows i0, i0+1, i0+2 (16*XL float4 per row)
+        const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
         const bool vec = a.vecOK && (j0 + 3 < a.Cout);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) {
@@ -258,33 +258,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
                 for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
         }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int ox = ox0 + 2 * (li & 15) + b;
-            if (ox >= a.Wo) continue;
-            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
-            f32x4 v;
+        for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+        if (vec) {
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(keep[b][g][k] + bv[k], a.slopePre);
-            if (vec) {
-                if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+            if (a.mask) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
-                if (a.mask) {
-                    const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+                for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+            }
+            *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+        } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
-                }
-                *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (j0 + k >= a.Cout) break;
-                    float tv = v[k];
-                    if (a.res) tv += a.res[op * a.ldR + j0 + k];
-                    tv = lrelu(tv, a.slopePost);
-                    if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
-                    a.out[op * a.ldO + j0 + k] = tv;
-                }
+            for (int k = 0; k < 4; ++k) {
+                if (j0 + k >= a.Cout) break;
+                float tv = v[k];
+                if (a.res) tv += a.res[op * a.ldR + j0 + k];
+                tv = lrelu(tv, a.slopePost);
+                if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                a.out[op * a.ldO + j0 + k] = tv;
             }
         }
     }

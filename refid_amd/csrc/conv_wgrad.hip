@@ -48,7 +48,7 @@ struct WCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sG4 = reinterpret_cast<f32x4*>(smem);
     f32x4* sX4 = sG4 + C::G_TOTAL;
@@ -152,25 +152,30 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgKArgs a) {
         const bool more = pt + a.nsplit < a.ntiles;
         if (more) load_tile(pt + a.nsplit);
 
+        // All LDS operands of a K step (pixel pair) are read up front, then the MFMAs consume them as they arrive
+        // (the naive "read, wait, 2 MFMAs" order exposed the LDS latency every two MFMAs).
         for (int row = 0; row < C::TH; ++row) {
-#pragma unroll 4
+#pragma unroll 2
             for (int qk = 0; qk < C::TW / 2; ++qk) {
                 const int pcol = 2 * qk + kh;
-                float av[C::SM];
+                float av[C::SM], bv[C::TPW][C::SN];
 #pragma unroll
                 for (int sm = 0; sm < C::SM; ++sm) av[sm] = sG[(row * C::TW + pcol) * C::COT + aoff + sm * 32];
 #pragma unroll
                 for (int tt = 0; tt < C::TPW; ++tt) {
-                    if (C::WT > 1 && !tok[tt]) continue;
                     const int hp = (row * C::S + tdy[tt]) * C::HWD + pcol * C::S + tdx[tt];
-                    float bv[C::SN];
 #pragma unroll
-                    for (int sn = 0; sn < C::SN; ++sn) bv[sn] = sX[hp * C::CIT + boff + sn * 32];
+                    for (int sn = 0; sn < C::SN; ++sn)
+                        bv[tt][sn] = (C::WT > 1 && !tok[tt]) ? 0.f : sX[hp * C::CIT + boff + sn * 32];
+                }
+#pragma unroll
+                for (int tt = 0; tt < C::TPW; ++tt) {
+                    if (C::WT > 1 && !tok[tt]) continue;
 #pragma unroll
                     for (int sm = 0; sm < C::SM; ++sm)
 #pragma unroll
                         for (int sn = 0; sn < C::SN; ++sn)
-                            acc[tt][sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[sn], av[sm],
+                            acc[tt][sm][sn] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[tt][sn], av[sm],
                                                                                   acc[tt][sm][sn], 0, 0, 0);
                 }
             }

@@ -129,31 +129,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         const bool more = pt + a.nsplit < a.ntiles;
         if (more) load_tile(pt + a.nsplit);
 
-        // 16 K steps (tile pairs) per K tile, fully unrolled: every LDS address is base + immediate.
-        // The raw operands of step s+1 are fetched before the 8 MFMAs of step s issue (explicit
-        // software pipelining -- the compiler does not do it across the on-the-fly transforms).
-        const float* xA = sX + (ra * HWD + 2 * kh) * CIT + li;       // + (2*tr*HWD + 4*qk) * CIT
-        const float* xB = sX + (rb * HWD + 2 * kh) * CIT + li;
-        const float* gP = sG + (2 * kh) * COT + li;                  // + (2*tr*TW + 4*qk) * COT
-        float cxa[4], cxb[4], cg[2][4], nxa[4], nxb[4], ng[2][4];
-        auto fetch = [&](int s, float (&pa)[4], float (&pb)[4], float (&pg)[2][4]) {
-            const int tr = s >> 3, qk = s & 7;
-            const int xo = (2 * tr * HWD + 4 * qk) * CIT, go = (2 * tr * TW + 4 * qk) * COT;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { pa[b] = xA[xo + b * CIT]; pb[b] = xB[xo + b * CIT]; }
+        // 16 K steps per K tile, fully unrolled (every LDS address is base + immediate).  A step pairs the two tile
+        // ROWS of one tile column (MFMA K half kh = tile row), so consecutive steps of a lane walk along a row and
+        // the 4-column input window slides by 2: only 2 new columns per row are read per step (12 instead of 16
+        // LDS floats per 8 MFMAs -- LDS bytes and VALU instructions do not hide under MFMAs on gfx950).
+        // The raw operands of step s+1 are fetched before the 8 MFMAs of step s issue.
+        const float* xA = sX + ((2 * kh + ra) * HWD) * CIT + li;     // + (2*s + b) * CIT
+        const float* xB = sX + ((2 * kh + rb) * HWD) * CIT + li;
+        const float* gP = sG + (2 * kh * TW) * COT + li;             // + (2*s) * COT
+        float t0, t1, t2, t3;                                        // T_b = d[ra][b] + sgn d[rb][b], b = window column
+        float cg[2][4], ng[2][4], nt2, nt3;
+        auto fetch_g = [&](int s, float (&pg)[2][4]) {
+            const int go = (2 * s) * COT;
 #pragma unroll
             for (int sm = 0; sm < 2; ++sm) {
                 pg[sm][0] = gP[go + sm * 32];            pg[sm][1] = gP[go + sm * 32 + COT];
                 pg[sm][2] = gP[go + sm * 32 + TW * COT]; pg[sm][3] = gP[go + sm * 32 + TW * COT + COT];
             }
         };
-        fetch(0, cxa, cxb, cg);
+        t0 = xA[0] + sgn * xB[0];             t1 = xA[CIT] + sgn * xB[CIT];
+        t2 = xA[2 * CIT] + sgn * xB[2 * CIT]; t3 = xA[3 * CIT] + sgn * xB[3 * CIT];
+        fetch_g(0, cg);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            if (s + 1 < 16) fetch(s + 1, nxa, nxb, ng);
-            // V row ti:  T_b = d[ra][b] + sgn d[rb][b]
-            const float t0 = cxa[0] + sgn * cxb[0], t1 = cxa[1] + sgn * cxb[1];
-            const float t2 = cxa[2] + sgn * cxb[2], t3 = cxa[3] + sgn * cxb[3];
+            if (s + 1 < 16) {
+                fetch_g(s + 1, ng);
+                nt2 = xA[(2 * s + 4) * CIT] + sgn * xB[(2 * s + 4) * CIT];
+                nt3 = xA[(2 * s + 5) * CIT] + sgn * xB[(2 * s + 5) * CIT];
+            }
             const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
             // Z row ti:  X_b = ca dY[0][b] + cb dY[1][b]
             float z[2][4];
@@ -169,8 +172,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
                 for (int sm = 0; sm < 2; ++sm)
                     acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
             if (s + 1 < 16) {
+                t0 = t2; t1 = t3; t2 = nt2; t3 = nt3;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) { cxa[b] = nxa[b]; cxb[b] = nxb[b]; cg[0][b] = ng[0][b]; cg[1][b] = ng[1][b]; }
+                for (int b = 0; b < 4; ++b) { cg[0][b] = ng[0][b]; cg[1][b] = ng[1][b]; }
             }
         }
         __syncthreads();

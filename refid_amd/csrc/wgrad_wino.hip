@@ -137,8 +137,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         const float* xA = sX + ((2 * kh + ra) * HWD) * CIT + li;     // + (2*s + b) * CIT
         const float* xB = sX + ((2 * kh + rb) * HWD) * CIT + li;
         const float* gP = sG + (2 * kh * TW) * COT + li;             // + (2*s) * COT
-        float t0, t1, t2, t3;                                        // T_b = d[ra][b] + sgn d[rb][b], b = window column
-        float cg[2][4], ng[2][4], nt2, nt3;
+        // T_b = d[ra][b] + sgn d[rb][b] for the 34 window columns of this lane's row pair, consumed two per step; the
+        // step loop is fully unrolled, so tw[] / gbuf[] are plain registers (no copies between steps).
+        float tw[4];
+        float gbuf[2][2][4];
         auto fetch_g = [&](int s, float (&pg)[2][4]) {
             const int go = (2 * s) * COT;
 #pragma unroll
@@ -147,35 +149,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
                 pg[sm][2] = gP[go + sm * 32 + TW * COT]; pg[sm][3] = gP[go + sm * 32 + TW * COT + COT];
             }
         };
-        t0 = xA[0] + sgn * xB[0];             t1 = xA[CIT] + sgn * xB[CIT];
-        t2 = xA[2 * CIT] + sgn * xB[2 * CIT]; t3 = xA[3 * CIT] + sgn * xB[3 * CIT];
-        fetch_g(0, cg);
+#pragma unroll
+        for (int b4 = 0; b4 < 4; ++b4) tw[b4] = xA[b4 * CIT] + sgn * xB[b4 * CIT];
+        fetch_g(0, gbuf[0]);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
+            float n2 = 0.f, n3 = 0.f;
             if (s + 1 < 16) {
-                fetch_g(s + 1, ng);
-                nt2 = xA[(2 * s + 4) * CIT] + sgn * xB[(2 * s + 4) * CIT];
-                nt3 = xA[(2 * s + 5) * CIT] + sgn * xB[(2 * s + 5) * CIT];
+                fetch_g(s + 1, gbuf[(s + 1) & 1]);
+                n2 = xA[(2 * s + 4) * CIT] + sgn * xB[(2 * s + 4) * CIT];
+                n3 = xA[(2 * s + 5) * CIT] + sgn * xB[(2 * s + 5) * CIT];
             }
-            const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
-            // Z row ti:  X_b = ca dY[0][b] + cb dY[1][b]
+            const float (&cg)[2][4] = gbuf[s & 1];
+            // column transform; the 4th operand carries the sign of Z's 4th column (z3 = -x1), so Z needs no negation
+            const float v[4] = {tw[0] - tw[2], tw[1] + tw[2], tw[2] - tw[1], tw[3] - tw[1]};
+            // Z row ti:  X_b = ca dY[0][b] + cb dY[1][b];  z = {x0, x0 + x1, x0 - x1, (-)x1}
             float z[2][4];
 #pragma unroll
             for (int sm = 0; sm < 2; ++sm) {
                 const float x0 = ca * cg[sm][0] + cb * cg[sm][2];
                 const float x1 = ca * cg[sm][1] + cb * cg[sm][3];
-                z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = -x1;
+                z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = x1;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int sm = 0; sm < 2; ++sm)
                     acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
-            if (s + 1 < 16) {
-                t0 = t2; t1 = t3; t2 = nt2; t3 = nt3;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) { cg[0][b] = ng[0][b]; cg[1][b] = ng[1][b]; }
-            }
+            tw[0] = tw[2]; tw[1] = tw[3]; tw[2] = n2; tw[3] = n3;
         }
         __syncthreads();
         if (more) {

@@ -210,9 +210,11 @@ int refid_fac_bwd(const float* g, int ld_g, const float* feat, int ld_feat, cons
 int refid_dwconv_pool_parts(int h, int wd, int c);
 int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
                              float* act, float* pool, int n, int h, int wd, int c, void* stream);
-/* gd = gradient w.r.t. `pre`; gin = input gradient; dw/db accumulate. */
+/* gd = gradient w.r.t. `pre`; gin = input gradient; dw/db accumulate.  parts: scratch of
+ * n * refid_dwconv3x3_bwd_parts(h,wd,c) * 10c floats (deterministic two-stage reduction) or NULL (atomics). */
+int refid_dwconv3x3_bwd_parts(int h, int wd, int c);
 int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
-                        float* dw, float* db, int n, int h, int wd, int c, void* stream);
+                        float* dw, float* db, float* parts, int n, int h, int wd, int c, void* stream);
 /* se_1 (fm:253-260): m = (sum_parts pool)*inv_hw ; z1 = relu(W1 m + b1) ; s = sigmoid(W2 z1 + b2) */
 int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const float* w1, const float* b1, const float* w2,
                  const float* b2, float* m, float* z1, float* s, int n, int c, void* stream);

@@ -95,7 +95,8 @@ def _bind_extra(L):
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
     L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, ll, i, f, vp]
     L.refid_dwconv3x3_gelu_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
-    L.refid_dwconv3x3_bwd.argtypes = [vp, vp, i, vp, vp, vp, vp, i, i, i, i, vp]
+    L.refid_dwconv3x3_bwd.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
+    L.refid_dwconv3x3_bwd_parts.argtypes = [i, i, i]
     L.refid_se_fwd.argtypes = [vp, i, f, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.refid_dwconv_pool_parts.argtypes = [i, i, i]
     L.refid_se_bwd.argtypes = [vp] * 11 + [i, i, vp]

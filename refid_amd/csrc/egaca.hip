@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
 template <int LPP>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ in,
                                                     int ldi, const float* __restrict__ w, float* __restrict__ gin,
-                                                    float* __restrict__ dw, float* __restrict__ db, int H, int W) {
+                                                    float* __restrict__ dw, float* __restrict__ db,
+                                                    float* __restrict__ parts, int H, int W) {
     constexpr int C = LPP * 4, PPB = 256 / LPP;
     __shared__ float sdw[C * 9], sdb[C];
     const int q = threadIdx.x % LPP, n = blockIdx.y;
@@ -198,8 +199,28 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ g
         atomicAdd(&sdb[q * 4 + k], pb[k]);
     }
     __syncthreads();
+    if (parts) {            // per-workgroup partials [block][C*10]; summed in fixed order by dw_bwd_sum_kernel
+        float* dst = parts + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (C * 10);
+        for (int i = threadIdx.x; i < C * 9; i += 256) dst[i] = sdw[i];
+        if (threadIdx.x < C) dst[C * 9 + threadIdx.x] = sdb[threadIdx.x];
+        return;
+    }
     for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(dw + i, sdw[i]);
     if (threadIdx.x < C) atomicAdd(db + threadIdx.x, sdb[threadIdx.x]);
+}
+
+// dw[i] += sum_blocks parts[b][i] ; db likewise.  One wave per column i: lanes stride over the partial rows, then a
+// fixed xor-shuffle tree -- deterministic.
+__global__ __launch_bounds__(256) void dw_bwd_sum_kernel(const float* __restrict__ parts, int nblk, int C,
+                                                        float* __restrict__ dw, float* __restrict__ db) {
+    const int row = C * 10, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= row) return;
+    float a = 0.f;
+    for (int b = lane; b < nblk; b += 64) a += parts[(long long)b * row + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) { if (i < C * 9) dw[i] += a; else db[i - C * 9] += a; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -464,7 +485,7 @@ extern "C" int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, i
 
 extern "C" int refid_dwconv_pool_parts(int h, int wd, int c) {
     if (c != 16 && c != 32 && c != 64 && c != 128) return -1;
-    return blocks_for((long long)h * wd, 256 / (c / 4), 256);
+    return blocks_for((long long)h * wd, 256 / (c / 4), 64);
 }
 
 extern "C" int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
@@ -477,13 +498,25 @@ extern "C" int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float*
     return 0;
 }
 
+extern "C" int refid_dwconv3x3_bwd_parts(int h, int wd, int c) {
+    if (c != 16 && c != 32 && c != 64 && c != 128) return -1;
+    return blocks_for((long long)h * wd, 256 / (c / 4), 64);
+}
+
 extern "C" int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
-                                   float* dw, float* db, int n, int h, int wd, int c, void* stream) {
+                                   float* dw, float* db, float* parts, int n, int h, int wd, int c, void* stream) {
     REFID_CHECK(gd && in && w && gin && dw && db && n > 0, "dwconv3x3_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_bwd_kernel<LPP>, dim3(blocks_for((long long)h * wd, 256 / LPP, 64), n),
-                                       dim3(256), 0, st, gd, in, ld_in, w, gin, dw, db, h, wd));
+    // with a scratch buffer (n * refid_dwconv3x3_bwd_parts() * 10c floats) the parameter gradients are reduced
+    // deterministically in two stages; without one they fall back to fp32 atomics on fewer, longer workgroups
+    const int nb = parts ? refid_dwconv3x3_bwd_parts(h, wd, c) : blocks_for((long long)h * wd, 256 / (c / 4 > 0 ? c / 4 : 1), 64);
+    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_bwd_kernel<LPP>, dim3(nb, n), dim3(256), 0, st, gd, in, ld_in, w, gin, dw, db,
+                                       parts, h, wd));
     REFID_LAUNCH_CHECK("dwconv3x3_bwd");
+    if (parts) {
+        hipLaunchKernelGGL(dw_bwd_sum_kernel, dim3(cdiv(c * 10, 4)), dim3(256), 0, st, parts, nb * n, c, dw, db);
+        REFID_LAUNCH_CHECK("dwconv3x3_bwd/sum");
+    }
     return 0;
 }
 

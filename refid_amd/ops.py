@@ -313,8 +313,12 @@ def dwconv3x3_bwd(gd, x, w, dw, db):
     px, ld = _nhwc(x, "x")
     n, h, wd, c = x.shape
     gin = torch.empty((n, h, wd, c), dtype=torch.float32, device=x.device)
+    nparts = lib().refid_dwconv3x3_bwd_parts(h, wd, c)
+    if nparts <= 0:
+        raise _lib.RefidHipError(f"dwconv3x3_bwd: unsupported channel count {c}")
+    parts = torch.empty((n * nparts, 10 * c), dtype=torch.float32, device=x.device)
     check(lib().refid_dwconv3x3_bwd(_c(gd, "gd"), px, ld, _c(w, "w"), gin.data_ptr(), _c(dw, "dw"), _c(db, "db"),
-                                    n, h, wd, c, _stream()), "refid_dwconv3x3_bwd")
+                                    parts.data_ptr(), n, h, wd, c, _stream()), "refid_dwconv3x3_bwd")
     return gin
 
 

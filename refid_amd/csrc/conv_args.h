@@ -16,6 +16,8 @@ struct ConvKArgs {
     int vecOK;                 // out/res/mask/bias allow 16-byte channel-quad accesses
     int ncot;                  // output-channel tiles (Winograd tile's XCD-aware work mapping)
     int bf16;                  // bf16 MFMA operands (packed weights are bf16), fp32 everything else
+    int ksplit = 1;            // Winograd tile: K (input-channel chunk) ranges per output tile, grid.y (small grids)
+    long long wsStride = 0;    // floats between the partial outputs of two K ranges
 };
 
 

@@ -33,6 +33,7 @@
 //     tile with the fused 16-byte epilogue.
 #include "common.h"
 #include "conv_args.h"
+#include <cstdlib>
 
 namespace {
 
@@ -99,6 +100,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         const int urow = a.coBase + n0 + nt * 32 + li;
         voU[nt] = (urow < a.CoutPad) ? ((ti * 4 * a.CoutPad + urow) * KC + kh * 4) * 4 : OOB;
     }
+    // split-K (small grids only): this workgroup reduces chunks [kc0, kc1) and writes a raw partial output
+    const int kper = ((a.nchunks + a.ksplit - 1) / a.ksplit + 1) & ~1;       // even, so chunk parity == buffer parity
+    const int kc0 = blockIdx.y * kper, kc1 = min(a.nchunks, kc0 + kper);
     const int uStep = a.CoutPad * KC * 4;                  // bytes between xi and xi+1
     const int uChunk = 16 * a.CoutPad * KC * 4;            // bytes per K chunk
 
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 
     // one K chunk: cur = this chunk's U fragments, nxt = register set the next chunk's are prefetched into
     auto phase = [&](int ch, f32x4 (&cur)[4 * NTN], f32x4 (&nxt)[4 * NTN]) {
-        const bool more = ch + 1 < a.nchunks;
+        const bool more = ch + 1 < kc1;
         // Everything still in flight was issued one phase ago and is needed NOW (U(ch) by the MFMAs, raw(ch+1) by
         // store_raw).  Stating that as an explicit vmcnt(0) keeps the compiler's conservative, path-merged counters
         // from draining THIS phase's prefetches inside the MFMA section.  simm16: vmcnt 0, expcnt 7, lgkmcnt 15.
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         if (more) {
             store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
             load_u(ch + 1, nxt);
-            if (ch + 2 < a.nchunks) load_raw(ch + 2);
+            if (ch + 2 < kc1) load_raw(ch + 2);
         }
         // Measured on gfx950 (tools/probes/mfma_valu_overlap.hip): every VALU instruction costs ~2.3 and every
         // ds_read_b128 ~28 cycles of matrix-pipe time, from either wave of the SIMD -- they do not hide under
@@ -193,15 +197,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     };
 
     // prologue: raw(0) -> LDS, U(0) -> regs; raw(1) in flight
-    load_raw(0);
-    load_u(0, ufA);
-    store_raw(0);
-    if (a.nchunks > 1) load_raw(1);
+    if (kc0 < kc1) {
+        load_raw(kc0);
+        load_u(kc0, ufA);
+        store_raw(0);
+        if (kc0 + 1 < kc1) load_raw(kc0 + 1);
+    }
     __syncthreads();
 
-    for (int ch = 0; ch < a.nchunks; ch += 2) {
+    for (int ch = kc0; ch < kc1; ch += 2) {
         phase(ch, ufA, ufB);
-        if (ch + 1 < a.nchunks) phase(ch + 1, ufB, ufA);
+        if (ch + 1 < kc1) phase(ch + 1, ufB, ufA);
     }
 
     // ---- output transform --------------------------------------------------------------------------
@@ -248,6 +254,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         const float sg = oa ? -1.f : 1.f;                   // a=0: R0+R1+R2 ; a=1: R1-R2-R3
         f32x4 v = xp[0] + (xp[16 * XL] + xp[32 * XL]) * sg;  // rows i0, i0+1, i0+2 (16*XL float4 per row)
         const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+        if (a.ksplit > 1) {                                 // raw partial sums; refid_wino_splitk_finish applies the epilogue
+            *reinterpret_cast<f32x4*>(a.out + blockIdx.y * a.wsStride + op * a.ldO + j0) = v;
+            continue;
+        }
         const bool vec = a.vecOK && (j0 + 3 < a.Cout);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
         if (a.bias) {
@@ -283,6 +293,31 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     }
 }
 
+// out = mask( post( pre( sum_s ws[s] + bias ) + res ) ) for the split-K partial outputs (channels padded to 4 in ws)
+__global__ __launch_bounds__(256) void wino_splitk_finish_kernel(const ConvKArgs a, const float* __restrict__ ws, int ldW,
+                                                                long long npix, int C4) {
+    const long long total = npix * C4;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long op = e / C4;
+        const int j0 = (int)(e % C4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + op * ldW + j0);
+        for (int s = 1; s < a.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(ws + s * a.wsStride + op * ldW + j0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (j0 + k >= a.Cout) break;
+            float t = v[k] + (a.bias ? a.bias[a.coBase + j0 + k] : 0.f);
+            t = lrelu(t, a.slopePre);
+            if (a.res) t += a.res[op * a.ldR + j0 + k];
+            t = lrelu(t, a.slopePost);
+            if (a.mask) t *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+            a.out[op * a.ldO + j0 + k] = t;
+        }
+    }
+}
+
+float* g_ws = nullptr;           // split-K workspace (grow-only, per process; launches are stream ordered)
+size_t g_ws_bytes = 0;
+
 }  // namespace
 
 int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
@@ -303,8 +338,52 @@ int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
         if (e1 != hipSuccess || e2 != hipSuccess) { refid_set_error("conv_wino: LDS attribute failed"); return 2; }
         attr_set = true;
     }
-    if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, a);
-    REFID_LAUNCH_CHECK("conv_wino");
+    // Small problems (deep levels, small batches) leave most of the 256 CUs idle with one long K loop per workgroup:
+    // split K over grid.y into a partial-sum workspace and finish with a streaming epilogue kernel.
+    //   REFID_WINO_SPLITK=sample (default): the split depends on the per-sample geometry only, so a sample's result is
+    //       bit-identical whatever the batch size (tests rely on that property);
+    //   REFID_WINO_SPLITK=auto: by total grid size -- best throughput at 1-2 samples per GPU (B=1: 186 -> 156 ms/step);
+    //   REFID_WINO_SPLITK=0: never.
+    static const int split_mode = [] {
+        const char* e = getenv("REFID_WINO_SPLITK");
+        return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1));
+    }();
+    const int nwg = (split_mode == 2) ? (int)grid.x : a.tilesX * a.tilesY * a.ncot * 8;   // "sample": as if N = 8
+    int ks = 1;
+    if (split_mode && nwg <= 256 && a.nchunks >= 16) {
+        ks = 512 / nwg;
+        if (ks > a.nchunks / 8) ks = a.nchunks / 8;
+        if (ks > 8) ks = 8;
+        if (ks < 1) ks = 1;
+    }
+    if (ks == 1) {
+        if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, a);
+        REFID_LAUNCH_CHECK("conv_wino");
+        return 0;
+    }
+    const long long npix = (long long)a.N * a.Ho * a.Wo;
+    const int ldW = round_up(a.Cout, 4);
+    const size_t need = (size_t)ks * npix * ldW * sizeof(float);
+    if (need > g_ws_bytes) {
+        // the old buffer may still be in use by queued launches: release it only after the stream drains
+        if (g_ws) { hipStreamSynchronize(st); hipFree(g_ws); }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_ws), need);
+        if (e != hipSuccess) { g_ws = nullptr; g_ws_bytes = 0; refid_set_error("conv_wino: split-K workspace: %s", hipGetErrorString(e)); return 2; }
+        g_ws_bytes = need;
+    }
+    ConvKArgs p = a;                       // partial pass: raw sums into the workspace
+    p.ksplit = ks; p.wsStride = npix * ldW; p.out = g_ws; p.ldO = ldW;
+    grid.y = ks;
+    if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, p);
+    else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, p);
+    REFID_LAUNCH_CHECK("conv_wino/splitk");
+    ConvKArgs f = a;
+    f.ksplit = ks; f.wsStride = npix * ldW;
+    const long long tot4 = npix * (ldW / 4);
+    int nb = (int)((tot4 + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wino_splitk_finish_kernel, dim3(nb), dim3(256), 0, st, f, g_ws, ldW, npix, ldW / 4);
+    REFID_LAUNCH_CHECK("conv_wino/finish");
     return 0;
 }

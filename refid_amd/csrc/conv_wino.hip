@@ -302,6 +302,21 @@ __global__ __launch_bounds__(256) void wino_splitk_finish_kernel(const ConvKArgs
         const int j0 = (int)(e % C4) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(ws + op * ldW + j0);
         for (int s = 1; s < a.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(ws + s * a.wsStride + op * ldW + j0);
+        if (a.vecOK && j0 + 3 < a.Cout) {
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + a.coBase + j0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePre);
+            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+            if (a.mask) {
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+            }
+            *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (j0 + k >= a.Cout) break;

@@ -20,6 +20,8 @@
 
 namespace {
 
+const bool USE_THIN_WGRAD = !(getenv("REFID_THIN_WGRAD") && getenv("REFID_THIN_WGRAD")[0] == '0');
+
 struct WgKArgs {
     const float* g; int ldG, Co;
     const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
@@ -341,6 +343,194 @@ __global__ __launch_bounds__(256) void wgrad_pw_kernel(const WpArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Thin-input KxK weight gradient (the event head: conv5x5 of 2 -> 32 channels over all B*T frames at once,
+// XXNet_final_attenfusion_arch.py:98-99,149).  With 4 (padded) input channels a 32-column MFMA tile of input
+// channels is 8x waste; here the 32 columns are (8 taps x 4 channels), so a pixel pair costs ceil(K*K/8) MFMAs
+// instead of K*K.  The output gradient streams straight from global memory into MFMA operands (one dword per lane
+// per pixel pair, coalesced 128 B per pixel); only the small input halo goes through LDS (double buffered).
+// Wave w owns row w of a 4x32-pixel tile; a workgroup walks over many tiles and writes one slab per wave.
+struct WtArgs {
+    const float* g; int ldG, Co;
+    const float* x; int ldX;                 // 4 channels per pixel (ldX >= 4)
+    float* slabs; float* bslabs;
+    int N, H, W, pad, K;                      // stride 1, Ho = H, Wo = W
+    int tilesX, tilesY, ntiles, nsplit, accum;
+};
+constexpr int WT_TH = 4, WT_TW = 32, WT_MAXG = 4;           // up to 32 taps (5x5 = 25)
+
+__global__ __launch_bounds__(256) void wgrad_thin_kernel(const WtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int K = a.K, HWD = WT_TW + K - 1, HP = (WT_TH + K - 1) * HWD;
+    f32x4* sX4 = reinterpret_cast<f32x4*>(smem);            // 2 x HP pixels x 4 channels
+    const float* sX = reinterpret_cast<const float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int ntaps = K * K, ngrp = (ntaps + 7) / 8;
+    // B operand column li = (tap t = li >> 2 of the group, channel li & 3): per-lane LDS offset per group
+    int boff[WT_MAXG];
+    float bmask[WT_MAXG];                               // columns beyond the last tap contribute zeros (branch-free)
+#pragma unroll
+    for (int gidx = 0; gidx < WT_MAXG; ++gidx) {
+        const int tap = gidx * 8 + (li >> 2);
+        const bool ok = tap < ntaps;
+        boff[gidx] = ok ? ((tap / K) * HWD + (tap % K)) * 4 + (li & 3) : 0;
+        bmask[gidx] = ok ? 1.f : 0.f;
+    }
+    const long long gmax = (long long)a.N * a.H * a.W * a.ldG * 4;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.g), 0, (int)min(gmax, 0x7fffffffLL), 0x00020000);
+    const bool cok = li < a.Co;
+
+    f32x16 acc[WT_MAXG];
+#pragma unroll
+    for (int gidx = 0; gidx < WT_MAXG; ++gidx)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[gidx][r] = 0.f;
+    float bsum = 0.f;
+
+    auto tile_origin = [&](int pt, int& n, int& oy0, int& ox0) {
+        int t = pt;
+        const int tx = t % a.tilesX; t /= a.tilesX;
+        const int ty = t % a.tilesY;
+        n = t / a.tilesY; oy0 = ty * WT_TH; ox0 = tx * WT_TW;
+    };
+    f32x4 rx[2];
+    auto load_x = [&](int pt) {
+        int n, oy0, ox0; tile_origin(pt, n, oy0, ox0);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int hp = tid + it * 256;
+            const int iy = oy0 - a.pad + hp / HWD, ix = ox0 - a.pad + hp % HWD;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const f32x4*>(a.x + ((long long)(n * a.H + iy) * a.W + ix) * a.ldX);
+            rx[it] = v;
+        }
+    };
+    auto store_x = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int hp = tid + it * 256;
+            if (hp < HP) sX4[buf * HP + hp] = rx[it];
+        }
+    };
+    // this wave's row of the tile: 16 pixel pairs of the output gradient, prefetched one tile ahead into the OTHER
+    // register set (two explicit sets and a loop unrolled by two: indexing a register array with a runtime buffer
+    // index makes the compiler select element by element and wait after every single load)
+    float gvA[16], gvB[16];
+    // per-lane byte offset inside a tile row (pixel kh of a pair, channel li); the pair index and the tile origin go
+    // into the SCALAR offset of the buffer load: no per-load vector address math, no divergent branches (those made
+    // the compiler recycle in-flight destination registers and wait after every load)
+    const int voG = cok ? (kh * a.ldG + li) * 4 : -1;
+    auto load_g = [&](int pt, float (&dst)[16]) {
+        int n, oy0, ox0; tile_origin(pt, n, oy0, ox0);
+        const int oy = oy0 + wave;                                  // wave-uniform
+        const int rowbase = (oy < a.H) ? (int)((((long long)(n * a.H + oy) * a.W + ox0) * a.ldG) * 4) : 0;
+        const int rowok = (oy < a.H) ? 0 : -1;                      // all-ones -> out-of-range offset -> zeros
+        const int wleft = a.W - ox0;                                 // valid columns in this tile row
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int colbad = (2 * j + kh < wleft) ? 0 : -1;
+            dst[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsG, voG | rowok | colbad,
+                                                                                     rowbase + 2 * j * a.ldG * 4, 0));
+        }
+    };
+    auto tile = [&](int pt, int buf, const float (&cur)[16], float (&nxt)[16]) {
+        const bool more = pt + a.nsplit < a.ntiles;
+        if (more) { load_x(pt + a.nsplit); load_g(pt + a.nsplit, nxt); }
+        const float* xb = sX + (buf * HP + wave * HWD + kh) * 4;          // + (2j) * 4 + boff
+        float bva[WT_MAXG], bvb[WT_MAXG];                 // LDS operands of pair j+1 are fetched before the MFMAs of pair j
+#pragma unroll
+        for (int gidx = 0; gidx < WT_MAXG; ++gidx) bva[gidx] = xb[boff[gidx]];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float gq = cur[j];
+            bsum += gq;
+            float (&bc)[WT_MAXG] = (j & 1) ? bvb : bva;
+            float (&bn)[WT_MAXG] = (j & 1) ? bva : bvb;
+            if (j + 1 < 16) {
+#pragma unroll
+                for (int gidx = 0; gidx < WT_MAXG; ++gidx) bn[gidx] = xb[2 * (j + 1) * 4 + boff[gidx]];
+            }
+#pragma unroll
+            for (int gidx = 0; gidx < WT_MAXG; ++gidx) {
+                if (gidx >= ngrp) break;
+                acc[gidx] = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[gidx] * bmask[gidx], gq, acc[gidx], 0, 0, 0);
+            }
+        }
+        if (more) store_x(buf ^ 1);
+        __syncthreads();
+    };
+
+    int pt = blockIdx.x;
+    if (pt < a.ntiles) { load_x(pt); store_x(0); load_g(pt, gvA); }
+    __syncthreads();
+    for (; pt < a.ntiles; pt += 2 * a.nsplit) {
+        tile(pt, 0, gvA, gvB);
+        if (pt + a.nsplit < a.ntiles) tile(pt + a.nsplit, 1, gvB, gvA);
+    }
+    // slab [split*4 + wave][group][co 32][col 32]; D[col][co]: lane li = co, register quad = 4 consecutive columns
+    float* sl = a.slabs + ((long long)(blockIdx.x * 4 + wave) * WT_MAXG) * 1024;
+#pragma unroll
+    for (int gidx = 0; gidx < WT_MAXG; ++gidx) {
+        if (gidx >= ngrp) break;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = acc[gidx][4 * qd + k];
+            f32x4* dst = reinterpret_cast<f32x4*>(sl + gidx * 1024 + li * 32 + 8 * qd + 4 * kh);
+            if (a.accum) v += *dst;
+            *dst = v;
+        }
+    }
+    if (a.bslabs) {
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (kh == 0) {
+            float* dst = a.bslabs + (long long)(blockIdx.x * 4 + wave) * 32 + li;
+            *dst = a.accum ? *dst + bsum : bsum;
+        }
+    }
+}
+
+// dw[co][ci][tap] += sum_slabs D[grp][co][(t, ci)],  db[co] += sum_slabs; one wave per output element, fixed order
+__global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __restrict__ slabs, const float* __restrict__ bslabs,
+                                                               int nslab, int Co, int Ci, int iTotal, int ntaps,
+                                                               float* __restrict__ dw, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int total = Co * Ci * ntaps;
+    if (e >= total + Co) return;
+    float s = 0.f;
+    if (e < total) {
+        const int tap = e % ntaps, ci = (e / ntaps) % Ci, co = e / (ntaps * Ci);
+        const long long off = (long long)(tap >> 3) * 1024 + co * 32 + (tap & 7) * 4 + ci;
+        for (int k = lane; k < nslab; k += 64) s += slabs[(long long)k * WT_MAXG * 1024 + off];
+    } else if (db != nullptr) {
+        for (int k = lane; k < nslab; k += 64) s += bslabs[(long long)k * 32 + (e - total)];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) {
+        if (e < total) {
+            const int tap = e % ntaps, ci = (e / ntaps) % Ci, co = e / (ntaps * Ci);
+            dw[((long long)co * iTotal + ci) * ntaps + tap] += s;
+        } else if (db != nullptr) db[e - total] += s;
+    }
+}
+
+bool thin_ok(const refid_wgrad_desc* d) {
+    return USE_THIN_WGRAD && d->algo == 0 && d->kh == d->kw && d->kh * d->kw <= 32 && d->kh >= 3 && d->stride == 1 &&
+           d->c_a == 4 && d->c_b == 0 && d->c_o <= 32 && d->i_base == 0 && d->i_total <= 4 && 2 * d->pad == d->kh - 1 &&
+           (long long)d->n * d->h * d->w * d->ld_g * 4 < 0x7fffffffLL;
+}
+int thin_nsplit(const refid_wgrad_desc* d) {
+    const int ntiles = cdiv(d->w, WT_TW) * cdiv(d->h, WT_TH) * d->n;
+    return ntiles < 768 ? ntiles : 768;        // 3 resident workgroups per CU: one round
+}
+
 struct RedArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
@@ -478,6 +668,7 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st);
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
     if (d->algo == 1) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
+    if (thin_ok(d)) return (size_t)thin_nsplit(d) * 4 * (WT_MAXG * 1024 + 32) * sizeof(float);
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     if (!p.ok) return 0;
     const Geo g = geo_of(d, p);
@@ -503,6 +694,27 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     REFID_CHECK(d->algo == 0 || (d->algo == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1),
                 "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
     if (d->algo == 1) return refid_wgrad_wino_launch(d, st);
+    if (thin_ok(d)) {
+        REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
+        const int ns = thin_nsplit(d), nslab = ns * 4;
+        WtArgs t;
+        t.g = d->g; t.ldG = d->ld_g; t.Co = d->c_o; t.x = d->in_a; t.ldX = d->ld_a;
+        t.slabs = d->slabs; t.bslabs = d->db ? d->slabs + (size_t)nslab * WT_MAXG * 1024 : nullptr;
+        t.N = d->n; t.H = d->h; t.W = d->w; t.pad = d->pad; t.K = d->kh;
+        t.tilesX = cdiv(d->w, WT_TW); t.tilesY = cdiv(d->h, WT_TH); t.ntiles = t.tilesX * t.tilesY * d->n;
+        t.nsplit = ns; t.accum = (d->phase == 2);
+        if (d->phase != 3) {
+            const int lds = 2 * (WT_TH + d->kh - 1) * (WT_TW + d->kh - 1) * 16;
+            hipLaunchKernelGGL(wgrad_thin_kernel, dim3(ns), dim3(256), lds, st, t);
+            REFID_LAUNCH_CHECK("wgrad_thin");
+        }
+        if (d->phase == 1 || d->phase == 2) return 0;
+        const int ci = d->i_total, total = d->o_real * ci * d->kh * d->kw + d->o_real;
+        hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3(cdiv(total, 4)), dim3(256), 0, st, t.slabs, t.bslabs, nslab,
+                           d->o_real, ci, d->i_total, d->kh * d->kw, d->dw, d->db);
+        REFID_LAUNCH_CHECK("wgrad_thin_reduce");
+        return 0;
+    }
     const Geo g = geo_of(d, p);
     WgKArgs a;
     a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;

@@ -498,3 +498,32 @@ def test_pointwise_tile(cfg):
         o2 = torch.empty(N, H, W, Cb, device="cuda")
         ops.conv2d(nhwc(g), wd, o2, kh=1, kw=1, cout=Cb, cout_pad=-(-Ci // 32) * 32, co_base=Ca, algo=3)
         np.testing.assert_allclose(nchw(o2).numpy(), xg.grad[:, Ca:].numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", [(3, 16, 40, 2, 32, 5), (2, 9, 33, 2, 8, 5), (1, 8, 32, 3, 16, 3), (5, 12, 64, 4, 32, 5)])
+def test_thin_input_wgrad(cfg):
+    """Event-head style weight gradient: <= 4 (zero padded) input channels, K x K taps packed 8 per MFMA column tile;
+    one-shot and persistent-slab phases."""
+    ops = _ops()
+    N, H, W, Ci, Co, k = cfg
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, k // 2)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    x4 = torch.zeros(N, H, W, 4, device="cuda")
+    x4[..., :Ci] = nhwc(x)
+    gd = nhwc(g)
+    dw = torch.zeros(Co, Ci, k, k, device="cuda"); db = torch.zeros(Co, device="cuda")
+    for _ in range(2):
+        ops.conv2d_wgrad(gd, x4, dw, kh=k, kw=k, stride=1, pad=k // 2, db=db, i_total=Ci)
+    scale = max(1.0, float(w.grad.abs().max()))
+    np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+    np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+    dw2 = torch.zeros_like(dw); db2 = torch.zeros_like(db)
+    sl = ops.conv2d_wgrad(gd, x4, dw2, kh=k, kw=k, stride=1, pad=k // 2, db=db2, i_total=Ci, phase=1)
+    ops.conv2d_wgrad(gd, x4, dw2, kh=k, kw=k, stride=1, pad=k // 2, db=db2, i_total=Ci, phase=2, slabs=sl)
+    ops.conv2d_wgrad(gd, x4, dw2, kh=k, kw=k, stride=1, pad=k // 2, db=db2, i_total=Ci, phase=3, slabs=sl)
+    np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+    np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)

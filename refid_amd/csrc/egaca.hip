@@ -110,19 +110,23 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
     for (int p = blockIdx.x * PPB + threadIdx.x / LPP; p < HW; p += gridDim.x * PPB) {
         const int y = p / W, x = p % W;
         f32x4 a = bv;
+        // 9 loads from clamped coordinates issued together, masked afterwards (a conditional load per tap is a
+        // branch + load + full wait: 9 serialised latencies per pixel); same summation order as before
+        f32x4 nb[9];
+        float mk[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const int yy = y + dy - 1;
-            if (yy < 0 || yy >= H) continue;
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int xx = x + dx - 1;
-                if (xx < 0 || xx >= W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((long long)(n * H + yy) * W + xx) * ldi + q * 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a[k] += v[k] * wr[k][dy * 3 + dx];
+                const int yy = y + dy - 1, xx = x + dx - 1;
+                mk[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? 1.f : 0.f;
+                const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                nb[dy * 3 + dx] = *reinterpret_cast<const f32x4*>(in + ((long long)(n * H + yc) * W + xc) * ldi + q * 4);
             }
-        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += (mk[t] != 0.f ? nb[t][k] : 0.f) * wr[k][t];
         f32x4 gl;
 #pragma unroll
         for (int k = 0; k < 4; ++k) gl[k] = gelu_f(a[k]);
@@ -169,26 +173,31 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ g
         const int y = p / W, x = p % W;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gd + ((long long)n * HW + p) * C + q * 4);
         f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        // all 18 neighbour loads are issued up front from CLAMPED coordinates and masked afterwards: a conditional
+        // load per tap compiles to a branch + load + full wait, i.e. 18 serialised memory latencies per pixel
+        f32x4 gn[9], in9[9];
+        float mg[9], mi[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                // dgrad: gin[y][x] += gd[y - dy + 1][x - dx + 1] * w[dy][dx]
-                const int gy = y - dy + 1, gxx = x - dx + 1;
-                if (gy >= 0 && gy < H && gxx >= 0 && gxx < W) {
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(gd + ((long long)(n * H + gy) * W + gxx) * C + q * 4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) a[k] += gv[k] * wr[k][dy * 3 + dx];
-                }
-                // wgrad: dw[dy][dx] += gd[y][x] * in[y + dy - 1][x + dx - 1]
-                const int iy = y + dy - 1, ix = x + dx - 1;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                    const f32x4 iv = *reinterpret_cast<const f32x4*>(in + ((long long)(n * H + iy) * W + ix) * ldi + q * 4);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) pw[k][dy * 3 + dx] += g0[k] * iv[k];
-                }
+                const int t = dy * 3 + dx;
+                const int gy = y - dy + 1, gxx = x - dx + 1;           // dgrad: gin[y][x] += gd[y-dy+1][x-dx+1] * w[dy][dx]
+                const int iy = y + dy - 1, ix = x + dx - 1;            // wgrad: dw[dy][dx] += gd[y][x] * in[y+dy-1][x+dx-1]
+                mg[t] = (gy >= 0 && gy < H && gxx >= 0 && gxx < W) ? 1.f : 0.f;
+                mi[t] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? 1.f : 0.f;
+                const int gyc = min(max(gy, 0), H - 1), gxc = min(max(gxx, 0), W - 1);
+                const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+                gn[t] = *reinterpret_cast<const f32x4*>(gd + ((long long)(n * H + gyc) * W + gxc) * C + q * 4);
+                in9[t] = *reinterpret_cast<const f32x4*>(in + ((long long)(n * H + iyc) * W + ixc) * ldi + q * 4);
             }
-        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a[k] += (mg[t] != 0.f ? gn[t][k] : 0.f) * wr[k][t];
+                pw[k][t] += g0[k] * (mi[t] != 0.f ? in9[t][k] : 0.f);
+            }
         *reinterpret_cast<f32x4*>(gin + ((long long)n * HW + p) * C + q * 4) = a;
         pb += g0;
     }

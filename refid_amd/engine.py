@@ -721,6 +721,7 @@ class Engine:
         c = self.ctx
         if c is None:
             raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
+        WGRAD_STREAM.pending.clear()          # leftovers of a backward that raised must never be launched
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
         dev = gout.device

@@ -237,6 +237,7 @@ class EvhinetEngine:
         c = self.ctx
         if c is None:
             raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
+        WGRAD_STREAM.pending.clear()          # leftovers of a backward that raised must never be launched
         Bn, H, W = c["shape"]
         gout = gout.to(self.device, torch.float32).contiguous()
         g4 = ops.nchw_to_nhwc(gout, _pad4(self.in_chn))

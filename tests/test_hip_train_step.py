@@ -95,3 +95,33 @@ def test_unsupported_training_options_raise():
     o["train"]["pixel_opt"] = None
     with pytest.raises(ValueError):
         TwoImageEventRecurrentRestorationModel(o)
+
+
+def test_six_steps_track_the_oracle_loss_curve():
+    """Longer horizon than the two-step parity above: six fused HIP steps and six oracle steps on the same tiny problem
+    keep the same loss curve (tools/train_drift.py prints 30 steps: |diff| <= 3e-8, parameters within 0.5 % of their
+    displacement)."""
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    opt = {"name": "t", "is_train": True, "num_gpu": 1,
+           "network_g": dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2, num_encoders=3,
+                             base_num_channels=8, num_block=1, num_residual_blocks=2),
+           "path": {"pretrain_network_g": None},
+           "train": {"optim_g": dict(type="AdamW", lr=2e-4, weight_decay=1e-4, betas=[0.9, 0.99]),
+                     "scheduler": dict(type="TrueCosineAnnealingLR", T_max=200, eta_min=1e-7),
+                     "pixel_opt": dict(type="CharbonnierLoss", loss_weight=1, reduction="mean")}, "val": {}}
+    model = TwoImageEventRecurrentRestorationModel(opt)
+    P0 = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    model.net_g.load_state_dict(P0)
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    P = {k: v.clone() for k, v in P0.items()}
+    st = O.TrainState(P)
+    for it in range(1, 7):
+        model.update_learning_rate(it)
+        model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+        model.optimize_parameters(it)
+        loss, _, _, _ = O.train_step(P, st, x, ev, gt, lr=O.cosine_lr(2e-4, it - 1, 200, 1e-7), weight_decay=1e-4)
+        assert abs(model.get_current_log()["l_pix"] - float(loss)) < 2e-6, it
+    sd = model.net_g.state_dict()
+    for k in sd:
+        disp = (P[k].double() - P0[k].double()).abs().max().item()
+        assert (sd[k].double().cpu() - P[k].double()).abs().max().item() <= 0.03 * disp + 1e-9, k

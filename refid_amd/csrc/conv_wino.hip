@@ -231,6 +231,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
             xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r0;
             xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r1;
         }
+    // residual / mask of this thread's 8 output pieces are requested NOW, so their latency hides behind the exchange
+    // barrier and the LDS reads below (the accumulators are dead: registers are plentiful here)
+    constexpr int NIT = (TH * TW * (BN / 4)) / 256;
+    const bool pre = a.vecOK && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
+    f32x4 pres[NIT], pmask[NIT];
+    if (pre) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int f = it * 256 + tid;
+            const int c4 = f % (BN / 4), pr = f / (BN / 4);
+            const int oy = oy0 + pr / TW, ox = ox0 + pr % TW, j0 = n0 + c4 * 4;
+            const bool ok = oy < a.Ho && ox < a.Wo && j0 + 3 < a.Cout;
+            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+            pres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pmask[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+            if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+        }
+    }
     __syncthreads();
 
     // ---- fused epilogue, COALESCED: thread -> (output pixel, channel quad) in memory order, so bias / residual /
@@ -270,11 +289,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
         if (vec) {
-            if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+            if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
             if (a.mask) {
-                const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+                const f32x4 mv = pre ? pmask[it] : *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
             }

@@ -4,18 +4,36 @@
 BASELINE.json metric: "interpolated frames/sec (train step) GoPro 256x256 11+1"; workload =
 configs[1]: GoPro 11+1 blur-VFI, batch 8 per GPU, 256x256, T=23, img_chn=26, fp32, full
 step (zero_grad -> forward -> Charbonnier -> BPTT -> clip 0.01 -> AdamW), synthetic inputs
-already resident in HBM.  One process per GPU; N>1 is launched by torch.distributed.run and
-uses RCCL (backend 'nccl') for the gradient all-reduce; per-GPU batch is fixed (weak scaling).
+already resident in HBM.
+
+One process per GPU (the reference launches `torch.distributed.launch --nproc_per_node=N`,
+/root/reference/README.md:138, basicsr/utils/dist_util.py:11-30):
+  * under a launcher (WORLD_SIZE set, e.g. `python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N`) this process is one rank; WORLD_SIZE must equal --gpus;
+  * without one, `python bench.py --gpus N` (N > 1) re-executes itself under torch.distributed.run with
+    N ranks on 127.0.0.1; fewer visible devices than ranks is an error, never a silent 1-rank run.
+N > 1 uses RCCL (backend 'nccl') for the gradient all-reduce.
+
+--scaling weak (default): --batch samples PER GPU whatever N is;
+--scaling strong: --batch is the GLOBAL batch, sharded (batch/N per GPU: config 2's batch 8 -> B=1 per GPU at
+  8 GPUs, the reference recipe's `batch_size_per_gpu: 1`).
+With N > 1 the weak run also times the strong-scaling shard of the same global batch afterwards and reports
+it as `"strong": {...}` in the same JSON line.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
   roofline      the dominant kernel's achieved fp32 TFLOP/s (algorithmic FLOPs / HIP-event time
                 of its launches in one instrumented step) against the 157.3 TFLOP/s fp32 MFMA peak;
   cpu_baseline  the CPU oracle (oracle/refid_oracle.py, kind "port") timed on this box's host
-                cores for ONE train step at B=1 of the same workload (rank 0, N=1 only).
+                cores for train steps at B=1 of the same workload (rank 0, N=1 only).
+
+--dry-run --backend gloo: launcher / rendezvous / gradient-sync / timing protocol only, on CPU tensors (no
+model step; `value` is null).  Used by tests/test_bench_launcher.py; never a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+METRIC = "interpolated frames/sec (train step) GoPro 256x256 11+1"
 
 
 def synthetic_batch(B, T, H, W, img_chn, seed, device):
@@ -58,100 +77,235 @@ def options(args):
     }
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args):
-    """One oracle train step on the host cores, B=1 of the same workload (bounded sample)."""
+    """SURVEY.md 8(d) 'CPU baseline timing': the oracle's S2 train step (fwd + bwd + clip + AdamW) on the host
+    cores, fp32, B=1, warm-up at size, 3 timed steps, median.  The thread count is swept first (one step each)
+    because the oracle's small per-step convolutions oversubscribe a many-core host: the best count is the one
+    reported.  Bounded sample: the first Tc of the T frames (cost is linear in frames: 2 recurrent steps per
+    frame + one image branch per sample)."""
     from oracle import refid_oracle as O
     torch.manual_seed(0)
     P = O.make_params(args.img_chn, mode="init", seed=0)
     for k in P:
         if k.endswith((".beta", ".gamma")):
             P[k] = torch.randn_like(P[k]) * 0.1
-    st = O.TrainState(P)
-    xw, ew, gw = O.make_inputs(1, 2, 32, 32, args.img_chn, mode="rng")          # thread-pool warm-up
-    O.train_step({k: v.clone() for k, v in P.items()}, O.TrainState(P), xw, ew, gw)
-    # bounded sample: B=1 and the first Tc of the T frames (cost is linear in frames: 2T recurrent
-    # steps + one image branch), so frames/s is directly comparable
-    Tc = min(args.T, args.cpu_frames)
+    Tc = max(1, min(args.T, args.cpu_frames))
     x, ev, gt = O.make_inputs(1, Tc, args.size, args.size, args.img_chn, seed=1, mode="rng")
-    t0 = time.perf_counter()
-    O.train_step(P, st, x, ev, gt)
-    dt = time.perf_counter() - t0
-    return {"value": round(Tc / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 oracle train step (fwd+bwd+clip+AdamW), B=1, {Tc} of T={args.T} frames, "
-                      f"{args.size}x{args.size}, fp32, {dt:.1f} s"}
+
+    def one():
+        Pc = {k: v.clone() for k, v in P.items()}
+        t0 = time.perf_counter()
+        O.train_step(Pc, O.TrainState(Pc), x, ev, gt)
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    cands = sorted({n for n in (8, 16, 32, 64, 128) if n <= ncpu} | {min(ncpu, 8)})
+    t_begin = time.perf_counter()
+    torch.set_num_threads(cands[0])
+    one()                                                    # warm-up at size (allocator, thread pool)
+    sweep = {}
+    for n in cands:
+        torch.set_num_threads(n)
+        sweep[n] = one()
+        if time.perf_counter() - t_begin > args.cpu_budget * 0.5:
+            break
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    times = []
+    for _ in range(3):
+        times.append(one())
+        if time.perf_counter() - t_begin > args.cpu_budget and times:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(Tc / med, 4), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": f"oracle train step (fwd+bwd+clip+AdamW), B=1, {Tc} of T={args.T} frames, "
+                      f"{args.size}x{args.size}, fp32; warm-up + thread sweep "
+                      f"{ {n: round(Tc / t, 3) for n, t in sweep.items()} } frames/s, then median of "
+                      f"{len(times)} timed steps at {best} threads ({med:.2f} s/step); host: {ncpu} logical CPUs, "
+                      f"{_cpu_model()}"}
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU (weak) / global batch (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--T", type=int, default=23)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--img-chn", dest="img_chn", type=int, default=26)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", dest="cpu_frames", type=int, default=5, help="frames in the CPU-baseline sample")
+    ap.add_argument("--cpu-frames", dest="cpu_frames", type=int, default=3, help="frames in the CPU-baseline sample")
+    ap.add_argument("--cpu-budget", dest="cpu_budget", type=float, default=60.0,
+                    help="soft wall-clock bound (s) of the CPU-baseline leg")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak runs: skip the extra strong-scaling timing")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the step from captured hipGraphs (auto: when the per-GPU batch is <= 2)")
     ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE configs[1] (headline); bf16 = config-3 style compute (bf16 MFMA operands)")
-    args = ap.parse_args()
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: --dry-run only")
+    ap.add_argument("--dry-run", dest="dry_run", action="store_true",
+                    help="launcher / collective / timing protocol only (CPU tensors, no model step, value=null)")
+    args = ap.parse_args(argv)
+    if args.backend == "gloo" and not args.dry_run:
+        ap.error("--backend gloo is only meaningful with --dry-run (the HIP path has no CPU fallback)")
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.scaling == "strong" and args.batch % args.gpus:
+        ap.error(f"--scaling strong: global batch {args.batch} is not divisible by --gpus {args.gpus}")
+    return args
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) of this same script."""
+    if not args.dry_run:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible: "
+                             "refusing to run fewer ranks than requested")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+class _DryModel:
+    """Stand-in step for --dry-run: the product's GradSync plan over a CPU arena of the real parameter inventory."""
+
+    def __init__(self, args):
+        from refid_amd.dist import GradSync
+        from refid_amd.engine import ParamArena, param_shapes
+        self.arena = ParamArena(param_shapes(args.img_chn), torch.device("cpu"))
+        self.sync = GradSync(self.arena.flat_g, self.arena.offsets) if torch.distributed.is_initialized() else None
+
+    def feed_data(self, data):
+        pass
+
+    def update_learning_rate(self, it):
+        pass
+
+    def optimize_parameters(self, it):
+        self.arena.flat_g.fill_(1.0)
+        if self.sync is not None:
+            self.sync("early")
+            self.sync("late")
+            world = torch.distributed.get_world_size()
+            if float(self.arena.flat_g[0]) != float(world) or float(self.arena.flat_g[-1]) != float(world):
+                raise RuntimeError("dry-run gradient all-reduce returned a wrong sum")
+
+    def get_current_log(self):
+        return {"l_pix": 0.0}
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, argv))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); "
+                         "they must match (one process per GPU)")
+    if args.dry_run:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"bench.py: local rank {local_rank} has no device ({torch.cuda.device_count()} visible): "
+                             "one GPU per rank is required")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("REFID_FORCE_GRADSYNC") == "1"    # 1-rank RCCL dry run of the N>1 path
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-
-    from refid_amd import ops
-    from refid_amd.train import TwoImageEventRecurrentRestorationModel
-
-    torch.manual_seed(1234)                        # same init on every rank (then broadcast anyway)
-    model = TwoImageEventRecurrentRestorationModel(options(args))
-    with torch.no_grad():                          # released-checkpoint-like: beta/gamma ~ N(0, 0.1^2)
-        for k, p in model.net_g.named_parameters():
-            if k.endswith((".beta", ".gamma")):
-                p.normal_(0.0, 0.1)
-    model.net_g.notify_params_changed()
-    x, ev, gt = synthetic_batch(args.batch, args.T, args.size, args.size, args.img_chn, 100 + rank, dev)
-    model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     def sync():
         if use_dist:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    if args.dry_run:
+        model = _DryModel(args)
+    else:
+        from refid_amd import ops
+        from refid_amd.train import TwoImageEventRecurrentRestorationModel
+        torch.manual_seed(1234)                        # same init on every rank (then broadcast anyway)
+        model = TwoImageEventRecurrentRestorationModel(options(args))
+        with torch.no_grad():                          # released-checkpoint-like: beta/gamma ~ N(0, 0.1^2)
+            for k, p in model.net_g.named_parameters():
+                if k.endswith((".beta", ".gamma")):
+                    p.normal_(0.0, 0.1)
+        model.net_g.notify_params_changed()
 
     it = 0
-    for _ in range(args.warmup):
-        it += 1
-        model.update_learning_rate(it)
-        model.optimize_parameters(it)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        it += 1
-        model.update_learning_rate(it)
-        model.optimize_parameters(it)
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+
+    def timed(per_gpu_batch, steps, warmup):
+        """W warm-up steps, then K steps bracketed by barrier + device sync; MAX over ranks."""
+        nonlocal it
+        if not args.dry_run:
+            x, ev, gt = synthetic_batch(per_gpu_batch, args.T, args.size, args.size, args.img_chn, 100 + rank, dev)
+            model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+            use_graph = args.graph == "on" or (args.graph == "auto" and per_gpu_batch <= 2)
+            if hasattr(model, "set_graph_mode"):
+                model.set_graph_mode(use_graph)
+        for _ in range(warmup):
+            it += 1
+            model.update_learning_rate(it)
+            model.optimize_parameters(it)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            it += 1
+            model.update_learning_rate(it)
+            model.optimize_parameters(it)
+        sync()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    per_gpu = args.batch if args.scaling == "weak" else args.batch // world
+    dt = timed(per_gpu, args.steps, args.warmup)
     loss = model.get_current_log()["l_pix"]
 
     roof = None
-    if not args.no_roofline:
+    if not args.no_roofline and not args.dry_run:
         # one extra, instrumented step (every rank runs it: the step contains collectives; only rank 0
         # records): HIP events around every conv-tile / wgrad launch on the launch stream; the dominant
         # kernel = the kernel with the largest accumulated time
@@ -160,6 +314,8 @@ def main():
         # every kernel alone on one stream (same as REFID_OVERLAP_WGRAD=0).
         from refid_amd import engine as _engine
         overlap, _engine.OVERLAP_WGRAD = _engine.OVERLAP_WGRAD, False
+        if hasattr(model, "set_graph_mode"):
+            model.set_graph_mode(False)
         if rank == 0:
             ops.PROFILE = []
         it += 1
@@ -167,61 +323,78 @@ def main():
         model.optimize_parameters(it)
         torch.cuda.synchronize()
         _engine.OVERLAP_WGRAD = overlap
-    if not args.no_roofline and rank == 0:
-        prof, ops.PROFILE = ops.PROFILE, None
-        agg = {}
-        for name, fl, e0, e1, _shape, nb in prof:
-            a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
-            a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1; a[3] += nb
-        name, (fl, sec, cnt, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
-        # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-        # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
-        traffic = None
-        import glob
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-            try:
-                rec = json.load(open(path)).get(name)
-            except (OSError, ValueError):
-                rec = None
-            if rec:
-                traffic = rec["hbm_bytes_per_launch"]
-                break
-        # Winograd F(2x2,3x3) executes 16/36 of the direct convolution's multiplies on the matrix
-        # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
-        # the SURVEY 8(d) direct-convolution figure beside it.
-        executed = fl * (16.0 / 36.0) if "wino" in name else fl
-        peak = FP32_MFMA_PEAK_TFLOPS
-        if args.dtype == "bf16" and "wino" not in name and "wgrad" not in name:
-            peak = 2500.0                  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-        ach = executed / sec / 1e12
-        conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
-        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
-                "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
-                "avg_launch_us": round(sec / cnt * 1e6, 2),
-                "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
-                "note": "per-kernel timing from one extra single-stream step (kernels run alone; the timed steps "
-                        "overlap wgrad kernels on a side stream); rocprof counterpart: profiles/*_nooverlap_kernel_stats.csv",
-                "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
-                                     "share_of_step": round(conv_t / (dt / args.steps), 3)}}
+        if rank == 0:
+            prof, ops.PROFILE = ops.PROFILE, None
+            agg = {}
+            for name, fl, e0, e1, _shape, nb in prof:
+                a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
+                a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1; a[3] += nb
+            name, (fl, sec, cnt, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
+            # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+            # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
+            traffic = None
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                try:
+                    rec = json.load(open(path)).get(name)
+                except (OSError, ValueError):
+                    rec = None
+                if rec:
+                    traffic = rec["hbm_bytes_per_launch"]
+                    break
+            # Winograd F(2x2,3x3) executes 16/36 of the direct convolution's multiplies on the matrix
+            # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
+            # the SURVEY 8(d) direct-convolution figure beside it.
+            executed = fl * (16.0 / 36.0) if "wino" in name else fl
+            peak = FP32_MFMA_PEAK_TFLOPS
+            if args.dtype == "bf16" and "bf16" in name:
+                peak = 2500.0                  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+            ach = executed / sec / 1e12
+            conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
+                    "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
+                    "avg_launch_us": round(sec / cnt * 1e6, 2),
+                    "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
+                    "note": "per-kernel timing from one extra single-stream step (kernels run alone; the timed steps "
+                            "overlap wgrad kernels on a side stream); rocprof counterpart: "
+                            "profiles/*_nooverlap_kernel_stats.csv",
+                    "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
+                                         "share_of_step": round(conv_t / (dt / args.steps), 3)}}
+
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong_leg and args.batch % world == 0 and not args.dry_run:
+        # the same GLOBAL batch as the 1-GPU configuration, sharded over the ranks (B = batch/N per GPU)
+        sdt = timed(args.batch // world, args.steps, args.warmup)
+        strong = {"global_batch": args.batch, "per_gpu_batch": args.batch // world,
+                  "value": round(args.batch * args.T * args.steps / sdt, 3), "unit": "frames/s",
+                  "ms_per_step": round(sdt / args.steps * 1e3, 2)}
     if use_dist:
         torch.distributed.barrier()
 
     if rank == 0:
-        frames = args.batch * args.T * world * args.steps
+        gbatch = per_gpu * world
+        frames = gbatch * args.T * args.steps
         out = {
-            "metric": "interpolated frames/sec (train step) GoPro 256x256 11+1", "value": round(frames / dt, 3),
+            "metric": METRIC, "value": None if args.dry_run else round(frames / dt, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": f"GoPro 11+1 blur-VFI train step, batch {args.batch}/GPU, {args.size}x{args.size}, "
-                                   f"T={args.T}, img_chn={args.img_chn}, {args.dtype}" +
-                                   (" (BASELINE configs[1])" if args.dtype == "fp32" and args.T == 23 else ""),
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "loss": round(loss, 6)},
+            "rccl_ranks": world if (use_dist and args.backend == "nccl") else (0 if not use_dist else None),
+            "config": {"workload": f"GoPro 11+1 blur-VFI train step, batch {per_gpu}/GPU"
+                                   f"{' (global batch ' + str(gbatch) + ' sharded)' if args.scaling == 'strong' else ''}, "
+                                   f"{args.size}x{args.size}, T={args.T}, img_chn={args.img_chn}, {args.dtype}" +
+                                   (" (BASELINE configs[1])" if args.dtype == "fp32" and args.T == 23 and gbatch == 8 * (world if args.scaling == "weak" else 1) else ""),
+                       "global_batch": gbatch, "parallelism": f"dp{world}", "loss": round(loss, 6)},
         }
+        if args.dry_run:
+            out["dry_run"] = True
+            out["backend"] = args.backend
         if roof is not None:
             out["roofline"] = roof
-        if not args.no_cpu_baseline and world == 1:
+        if strong is not None:
+            out["strong"] = strong
+        if not args.no_cpu_baseline and world == 1 and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if use_dist:

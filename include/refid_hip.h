@@ -15,7 +15,9 @@
  *    slices of wider buffers can be addressed; base pointers and pitches are multiples
  *    of 4 floats (16 B).
  *  - every function is asynchronous on the caller's `stream` (a hipStream_t passed as
- *    void*), allocates nothing, keeps no global mutable state and is re-entrant.
+ *    void*), allocates nothing, never synchronises, keeps no global mutable state and is
+ *    re-entrant: scratch memory is always the CALLER's (refid_conv_workspace_bytes,
+ *    refid_wgrad_workspace_bytes), so launches on different streams use different buffers.
  *  - return value: 0 = ok, non-zero = error; refid_last_error() returns a thread-local
  *    message for the last failing call on this thread.
  */
@@ -29,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 1
+#define REFID_ABI_VERSION 2
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -89,8 +91,17 @@ typedef struct refid_conv_desc {
                                                    2 = direct tile with bf16 MFMA operands (fp32
                                                    accumulate/epilogue/tensors; w_packed from
                                                    refid_pack_conv_weights_bf16 with kc doubled)   */
+    int wino_split;                             /* algo 1 only: split K over the grid for small problems into `ws`
+                                                   partial sums + a finishing pass: 0 = never; 1 = by per-sample
+                                                   geometry (a sample's bits do not depend on the batch size);
+                                                   2 = by total grid size (best at 1-2 samples per GPU)        */
+    float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
+                                                   aligned, private to this stream until the call's work has run;
+                                                   NULL: never split                                            */
 } refid_conv_desc;
 
+/* Scratch bytes refid_conv2d(d) wants in d->ws (0 = none); depends on the geometry fields and wino_split only. */
+size_t refid_conv_workspace_bytes(const refid_conv_desc* d);
 int refid_conv2d(const refid_conv_desc* d, void* stream);
 
 /* Channel-chunk width (KC) and row padding (BN) the conv tile for this geometry wants
@@ -164,11 +175,12 @@ int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* p
 int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* packed_bf16, int role, int o, int i,
                                  int kh, int kw, int kc, int bn, void* stream);
 int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
-/* After BPTT, turn the gradients accumulated for the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r])
- * back into gradients of (W, b, scale):  dscale[r] += <W[r,:],G[r,:]> + b[r]*gb[r];
- * G[r,:] *= scale[r]; gb[r] *= scale[r]. */
-int refid_fold_back(const float* w, const float* b, const float* scale, float* gw, float* gb,
-                    float* dscale, int rows, int k, void* stream);
+/* After BPTT, turn the gradient of the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r]) of THIS backward pass
+ * (gw_folded, gb_folded: private buffers, zero before BPTT) into gradients of (W, b, scale) and ACCUMULATE them:
+ *   dscale[r] += <W[r,:],Gf[r,:]> + b[r]*gbf[r];  gw[r,:] += scale[r]*Gf[r,:];  gb[r] += scale[r]*gbf[r].
+ * (gw/gb may already hold gradients of earlier backward passes: gradient accumulation stays exact.) */
+int refid_fold_back(const float* w, const float* b, const float* scale, const float* gw_folded,
+                    const float* gb_folded, float* gw, float* gb, float* dscale, int rows, int k, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * EGACA non-GEMM pieces (fusion_modules.py:290-333) and LayerNorm2d (fusion_modules.py:97-134).
@@ -258,6 +270,11 @@ int refid_clip_adamw(float* p, const float* g, float* m, float* v, const double*
  * einops.rearrange calls at XXNet_final_attenfusion_arch.py:140-143 (layout change only). */
 int refid_nchw_to_nhwc(const float* src, long long src_batch_stride, float* dst, int n, int c, int h, int w,
                        int c_pad, void* stream);
+/* The same conversion of sum_t src[:, t]: src is (n, t_count, c, h, w) with the given batch / time strides (floats).
+ * Gradient of a tensor every time step reads (`head` in `pred(z_t + head)`, XXNet_final_attenfusion_arch.py:215):
+ * autograd sums the T per-step gradients. */
+int refid_nchw_tsum_to_nhwc(const float* src, long long src_batch_stride, long long t_stride, int t_count, float* dst,
+                            int n, int c, int h, int w, int c_pad, void* stream);
 /* NHWC (n,h,w,ld) first c channels -> NCHW (n,c,h,w) with an output batch stride (so a
  * (B,T,3,H,W) stack is written in place: XXNet_final_attenfusion_arch.py:218). */
 int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch_stride,

@@ -215,11 +215,66 @@ def run_evhinet(losses, name, wf, B, H, W, seed, train, out_dir, sub=1):
     print(name, "out mean", float(out[0].mean()), "loss", float(rec.get("loss", np.nan)))
 
 
+def run_host_logic(arch, out_dir):
+    """Host-side contracts pinned to the reference's own code:
+    (1) A11 initialisation (recurrent_sub_modules.py:752-753,776-804 default_init_weights on ResidualBlockNoBN, torch
+        defaults elsewhere, LN 1/0, beta/gamma 0): per-parameter moments of the reference ctor at torch seed 0;
+    (2) learning-rate sequences of the schedulers base_model.py:77-108 can build (models/lr_scheduler.py + torch
+        CosineAnnealingLR), stepped the way base_model.py:158-180 does (step() from iteration 2, linear warm-up that
+        overwrites the group's lr with initial_lr / warmup_iter * iter)."""
+    torch.manual_seed(0)
+    net = build_ref(arch, 26, 32)
+    keys, mom = [], []
+    for k, p in net.state_dict().items():
+        v = p.double().flatten()
+        keys.append(k)
+        mom.append([v.numel(), float(v.mean()), float(v.std(unbiased=False)), float(v.abs().max()), float(v.min()),
+                    float(v.max())])
+    rec = {"init_keys": np.array(keys), "init_moments": np.array(mom, dtype=np.float64)}
+    lrs = importlib.import_module("basicsr.models.lr_scheduler")
+    cases = {
+        "TrueCosineAnnealingLR": (dict(T_max=30, eta_min=1e-7), -1, None),
+        "TrueCosineAnnealingLR_warm": (dict(T_max=30, eta_min=1e-7), 6, None),
+        "MultiStepLR": (dict(milestones=[5, 5, 12, 20], gamma=0.5), -1, None),
+        "MultiStepRestartLR_warm": (dict(milestones=[8, 16, 30], gamma=0.5, restarts=[0, 20], restart_weights=[1, 0.5]), 4, None),
+        "CosineAnnealingRestartLR": (dict(periods=[10, 10, 20], restart_weights=[1, 0.5, 0.25], eta_min=1e-7), -1, None),
+        "LinearLR": ({}, -1, 40),
+    }
+    for name, (cfg, warm, total) in cases.items():
+        kind = name.split("_")[0]
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=2e-4)
+        if kind == "TrueCosineAnnealingLR":
+            sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, **cfg)
+        elif kind in ("MultiStepLR", "MultiStepRestartLR"):
+            sch = lrs.MultiStepRestartLR(opt, **cfg)
+        elif kind == "CosineAnnealingRestartLR":
+            sch = lrs.CosineAnnealingRestartLR(opt, **cfg)
+        else:
+            sch = lrs.LinearLR(opt, total)
+        seq = []
+        for it in range(1, 40):
+            if it > 1:                                   # base_model.py:166-168
+                opt.step()
+                sch.step()
+            if it < warm:                                # base_model.py:170-180
+                for g in opt.param_groups:
+                    g["lr"] = g["initial_lr"] / warm * it
+            seq.append(opt.param_groups[0]["lr"])
+        rec["lr/" + name] = np.array(seq, dtype=np.float64)
+        rec["lrcfg/" + name] = np.array(repr((kind, cfg, warm, total)))
+    np.savez_compressed(os.path.join(out_dir, "host_logic.npz"), **rec)
+    print("host_logic: init moments of", len(keys), "tensors;", len(cases), "lr sequences")
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
     arch, losses = import_reference()
+    run_host_logic(arch, out_dir)
+    if os.environ.get("ONLY") == "host":
+        return
     if os.environ.get("ONLY") != "refid":
         run_evhinet(losses, "evhinet_tiny_train", 8, 2, 32, 32, 1, True, out_dir)
         run_evhinet(losses, "evhinet_odd_train", 16, 1, 40, 24, 2, True, out_dir)

@@ -30,6 +30,8 @@ class ConvDesc(C.Structure):
         ("mode", C.c_int),
         ("slope_pre", C.c_float), ("slope_post", C.c_float), ("slope_mask", C.c_float),
         ("algo", C.c_int),
+        ("wino_split", C.c_int),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
     ]
 
 
@@ -47,6 +49,7 @@ class WgradDesc(C.Structure):
     ]
 
 
+ABI_VERSION = 2          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 
@@ -64,6 +67,8 @@ def lib():
     L.refid_abi_version.restype = C.c_int
     L.refid_device_cu_count.restype = C.c_int
     L.refid_conv2d.argtypes = [C.POINTER(ConvDesc), C.c_void_p]
+    L.refid_conv_workspace_bytes.argtypes = [C.POINTER(ConvDesc)]
+    L.refid_conv_workspace_bytes.restype = C.c_size_t
     L.refid_conv_kc.argtypes = [C.c_int] * 4
     L.refid_conv_bn.argtypes = [C.c_int] * 5
     L.refid_conv_tile_name.argtypes = [C.c_int] * 5
@@ -75,11 +80,13 @@ def lib():
     L.refid_packed_weight_floats.restype = C.c_size_t
     L.refid_pack_conv_weights.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     L.refid_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+    L.refid_nchw_tsum_to_nhwc.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p] + [C.c_int] * 5 + \
+        [C.c_void_p]
     L.refid_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong] + [C.c_int] * 4 + [C.c_void_p]
     L.refid_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     L.refid_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_longlong, C.c_void_p]
     _bind_extra(L)
-    if L.refid_abi_version() != 1:
+    if L.refid_abi_version() != ABI_VERSION:
         raise RefidHipError("librefid_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -91,7 +98,7 @@ def _bind_extra(L):
     L.refid_pack_conv_weights_scaled.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
     L.refid_pack_conv_weights_bf16.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
-    L.refid_fold_back.argtypes = [vp] * 6 + [i, i, vp]
+    L.refid_fold_back.argtypes = [vp] * 8 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
     L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, ll, i, f, vp]
     L.refid_dwconv3x3_gelu_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]

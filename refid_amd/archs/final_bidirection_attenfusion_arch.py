@@ -5,12 +5,14 @@ Mirrors the reference class of the same name
 constructor keywords, the same 183 state-dict keys/shapes (so released ``['params']``
 checkpoints load with ``strict=True``), called as ``net_g(x=lq, event=voxel)``
 (twoImage_event_recurrent_model.py:276,324), returns a new (B,T,out_chn,H,W) tensor that is
-attached to autograd in grad mode.  All arithmetic runs in librefid_hip.so; there is no
-torch/CPU fallback -- calling it without the built extension or off-GPU raises.
+attached to autograd in grad mode (``refid_amd/autograd.py``: parameter gradients are delivered through
+autograd, so ``DistributedDataParallel`` -- base_model.py:66-72 -- wraps it like any module).  All arithmetic
+runs in librefid_hip.so; there is no torch/CPU fallback -- calling it without the built extension or off-GPU raises.
 """
 import torch
 from torch import nn
 
+from .. import autograd as hip_autograd
 from ..engine import Engine, param_shapes
 from .._lib import RefidHipError
 
@@ -20,18 +22,6 @@ class _Node(nn.Module):
 
     def extra_repr(self):
         return ""
-
-
-class _HipForward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, event, anchor, net):
-        ctx.net = net
-        return net._engine.forward(x, event, save=net._save_for_backward)
-
-    @staticmethod
-    def backward(ctx, gout):
-        ctx.net._backward(gout)
-        return None, None, None, None
 
 
 class FinalBidirectionAttenfusion(nn.Module):
@@ -69,8 +59,7 @@ class FinalBidirectionAttenfusion(nn.Module):
         self.base_num_channels, self.num_residual_blocks = base_num_channels, num_residual_blocks
         self._shapes = param_shapes(img_chn, ev_chn, out_chn, base_num_channels, num_residual_blocks)
         self._engine = None
-        self._save_for_backward = False
-        self._grad_sync = None                 # callable(flat_grad, phase) installed by refid_amd.dist
+        self._grad_sync = None                 # optional callable(phase) run inside BPTT (refid_amd.dist.GradSync)
         self._params = {}
         for key, shape in self._shapes.items():
             node = self
@@ -162,19 +151,8 @@ class FinalBidirectionAttenfusion(nn.Module):
             eng.mark_params_changed()
             self._seen_version = ver
         grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values())
-        self._save_for_backward = grad_mode
         if not grad_mode:
             return eng.forward(x, event, save=False)
-        anchor = self._params["pred.conv2d.bias"]
-        return _HipForward.apply(x, event, anchor, self)
-
-    def _backward(self, gout):
-        eng = self.engine
-        fresh = any(p.grad is None or p.grad.data_ptr() != eng.arena.g(k).data_ptr()
-                    for k, p in self._params.items())
-        if fresh:
-            eng.zero_grad()
-        eng.backward(gout, grad_sync=self._grad_sync)
-        for k, p in self._params.items():
-            if p.requires_grad:
-                p.grad = eng.arena.g(k)
+        # every parameter is an input of the autograd node and receives its gradient through autograd
+        # (hooks, DistributedDataParallel, gradient accumulation all behave as for any nn.Module)
+        return hip_autograd.apply(self, x, event)

@@ -10,6 +10,7 @@ import math
 import torch
 from torch import nn
 
+from .. import autograd as hip_autograd
 from .._lib import RefidHipError
 from ..evhinet import EvhinetEngine, param_shapes
 
@@ -17,18 +18,6 @@ from ..evhinet import EvhinetEngine, param_shapes
 class _Node(nn.Module):
     def extra_repr(self):
         return ""
-
-
-class _HipForward(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, event, anchor, net):
-        ctx.net = net
-        return net._engine.forward(x, event, save=True)
-
-    @staticmethod
-    def backward(ctx, gout):
-        ctx.net._backward(gout)
-        return None, None, None, None
 
 
 class SingleMultiConnectEVHINet(nn.Module):
@@ -140,14 +129,4 @@ class SingleMultiConnectEVHINet(nn.Module):
         grad_mode = torch.is_grad_enabled() and any(p.requires_grad for p in self._params.values())
         if not grad_mode:
             return [eng.forward(x, event, save=False)]
-        return [_HipForward.apply(x, event, self._params["sam12.conv2.bias"], self)]
-
-    def _backward(self, gout):
-        eng = self.engine
-        fresh = any(p.grad is None or p.grad.data_ptr() != eng.arena.g(k).data_ptr() for k, p in self._params.items())
-        if fresh:
-            eng.zero_grad()
-        eng.backward(gout, grad_sync=self._grad_sync)
-        for k, p in self._params.items():
-            if p.requires_grad:
-                p.grad = eng.arena.g(k)
+        return [hip_autograd.apply(self, x, event)]

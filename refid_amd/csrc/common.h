@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 #include "../../include/refid_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -32,3 +33,16 @@ __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? 
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+// One-time per-DEVICE set-up of a kernel's dynamic-LDS limit (the attribute belongs to the device's copy of the
+// code object).  hipFuncSetAttribute is idempotent, so a benign race between host threads costs one extra call.
+template <class K>
+static inline int refid_lds_attr_once(std::atomic<unsigned long long>& done, K kernel, int bytes, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) { refid_set_error("%s: hipGetDevice failed", what); return 2; }
+    if ((done.load(std::memory_order_relaxed) >> dev) & 1ull) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { refid_set_error("%s: LDS attribute: %s", what, hipGetErrorString(e)); return 2; }
+    done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    return 0;
+}

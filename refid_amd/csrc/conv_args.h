@@ -22,6 +22,8 @@ struct ConvKArgs {
 
 
 // conv_wino.hip
-int refid_launch_wino3x3(const ConvKArgs& a, hipStream_t st);
+// ws / ws_bytes: caller-provided split-K workspace (refid_wino3x3_workspace_bytes; NULL = never split)
+size_t refid_wino3x3_workspace_bytes(const ConvKArgs& a, int split_mode);
+int refid_launch_wino3x3(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, hipStream_t st);
 // conv_pw.hip
 int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st);

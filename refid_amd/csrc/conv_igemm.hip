@@ -294,13 +294,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 
 template <class C, bool BF>
 int launch_t(const ConvKArgs& ka, int ncls, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<C, BF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) { refid_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return 2; }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = refid_lds_attr_once(attr_done, &conv_igemm_kernel<C, BF>, C::LDS_BYTES, "conv")) return rc;
     ConvKArgs a = ka;
     a.tilesX = cdiv(a.Wo, C::TW);
     a.tilesY = cdiv(a.Ho, C::TH);
@@ -383,6 +378,15 @@ extern "C" const char* refid_conv_tile_name(int kh, int kw, int stride, int mode
     }
 }
 
+extern "C" size_t refid_conv_workspace_bytes(const refid_conv_desc* d) {
+    if (!d || d->algo != 1 || d->wino_split == 0) return 0;       // only the Winograd tile's split-K uses one
+    ConvKArgs a;
+    a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
+    a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
+    a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
+    return refid_wino3x3_workspace_bytes(a, d->wino_split);
+}
+
 extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     REFID_CHECK(d != nullptr, "conv2d: null descriptor");
@@ -447,7 +451,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
                         (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
                     "conv2d: tensor too large for the Winograd tile's 32-bit offsets (use algo 0)");
-        return refid_launch_wino3x3(a, st);
+        return refid_launch_wino3x3(a, d->ws, d->ws_bytes, d->wino_split, st);
     }
     switch (f) {
         case F_3x3:

@@ -646,13 +646,8 @@ Geo geo_of(const refid_wgrad_desc* d, const Plan& p) {
 
 template <class C>
 int launch_w(const WgKArgs& a, const Geo& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<C>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        if (e != hipSuccess) { refid_set_error("wgrad: LDS attribute: %s", hipGetErrorString(e)); return 2; }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = refid_lds_attr_once(attr_done, &wgrad_kernel<C>, C::LDS_BYTES, "wgrad")) return rc;
     dim3 grid(g.nsplit, g.nciT, g.ncoT);
     hipLaunchKernelGGL(wgrad_kernel<C>, grid, dim3(256), C::LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("wgrad");

@@ -33,7 +33,6 @@
 //     tile with the fused 16-byte epilogue.
 #include "common.h"
 #include "conv_args.h"
-#include <cstdlib>
 
 namespace {
 
@@ -349,40 +348,27 @@ __global__ __launch_bounds__(256) void wino_splitk_finish_kernel(const ConvKArgs
     }
 }
 
-float* g_ws = nullptr;           // split-K workspace (grow-only, per process; launches are stream ordered)
-size_t g_ws_bytes = 0;
-
 }  // namespace
 
-int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
-    ConvKArgs a = ka;
+namespace {
+// Small problems (deep levels, small batches) leave most of the 256 CUs idle with one long K loop per workgroup:
+// split K over grid.y into a partial-sum workspace and finish with a streaming epilogue kernel.
+//   split_mode 1 ("sample"): the split depends on the per-sample geometry only, so a sample's result is bit-identical
+//       whatever the batch size (tests rely on that property);
+//   split_mode 2 ("auto"): by total grid size -- best throughput at 1-2 samples per GPU;
+//   split_mode 0: never.
+struct WinoPlan { int th, bn, ks; dim3 grid; };
+
+WinoPlan wino_plan(ConvKArgs& a, int split_mode) {
+    WinoPlan p;
     const bool narrow = a.Cout <= 32;           // 32-channel layers: split pixels instead of channels
-    const int th = narrow ? 8 : 4, bn = narrow ? 32 : 64;
+    p.th = narrow ? 8 : 4; p.bn = narrow ? 32 : 64;
     a.tilesX = cdiv(a.Wo, TW);
-    a.tilesY = cdiv(a.Ho, th);
+    a.tilesY = cdiv(a.Ho, p.th);
     a.nchunks = cdiv(a.Ctot, KC);
-    a.ncot = cdiv(a.Cout, bn);
-    dim3 grid(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<1, 2>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<2, 1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e1 != hipSuccess || e2 != hipSuccess) { refid_set_error("conv_wino: LDS attribute failed"); return 2; }
-        attr_set = true;
-    }
-    // Small problems (deep levels, small batches) leave most of the 256 CUs idle with one long K loop per workgroup:
-    // split K over grid.y into a partial-sum workspace and finish with a streaming epilogue kernel.
-    //   REFID_WINO_SPLITK=sample (default): the split depends on the per-sample geometry only, so a sample's result is
-    //       bit-identical whatever the batch size (tests rely on that property);
-    //   REFID_WINO_SPLITK=auto: by total grid size -- best throughput at 1-2 samples per GPU (B=1: 186 -> 156 ms/step);
-    //   REFID_WINO_SPLITK=0: never.
-    static const int split_mode = [] {
-        const char* e = getenv("REFID_WINO_SPLITK");
-        return !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'a' ? 2 : 1));
-    }();
-    const int nwg = (split_mode == 2) ? (int)grid.x : a.tilesX * a.tilesY * a.ncot * 8;   // "sample": as if N = 8
+    a.ncot = cdiv(a.Cout, p.bn);
+    p.grid = dim3(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
+    const int nwg = (split_mode == 2) ? (int)p.grid.x : a.tilesX * a.tilesY * a.ncot * 8;   // "sample": as if N = 8
     int ks = 1;
     if (split_mode && nwg <= 256 && a.nchunks >= 16) {
         ks = 512 / nwg;
@@ -390,6 +376,28 @@ int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
         if (ks > 8) ks = 8;
         if (ks < 1) ks = 1;
     }
+    p.ks = ks;
+    return p;
+}
+}  // namespace
+
+size_t refid_wino3x3_workspace_bytes(const ConvKArgs& ka, int split_mode) {
+    ConvKArgs a = ka;
+    const WinoPlan p = wino_plan(a, split_mode);
+    if (p.ks == 1) return 0;
+    return (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float);
+}
+
+int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, hipStream_t st) {
+    ConvKArgs a = ka;
+    // no workspace from the caller = no split (still correct, one K loop per workgroup)
+    const WinoPlan pl = wino_plan(a, ws ? split_mode : 0);
+    const bool narrow = a.Cout <= 32;
+    dim3 grid = pl.grid;
+    static std::atomic<unsigned long long> done12{0}, done21{0};
+    if (int rc = refid_lds_attr_once(done12, &conv_wino_kernel<1, 2>, LDS_BYTES, "conv_wino")) return rc;
+    if (int rc = refid_lds_attr_once(done21, &conv_wino_kernel<2, 1>, LDS_BYTES, "conv_wino")) return rc;
+    const int ks = pl.ks;
     if (ks == 1) {
         if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, a);
         else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, a);
@@ -399,15 +407,13 @@ int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
     const long long npix = (long long)a.N * a.Ho * a.Wo;
     const int ldW = round_up(a.Cout, 4);
     const size_t need = (size_t)ks * npix * ldW * sizeof(float);
-    if (need > g_ws_bytes) {
-        // the old buffer may still be in use by queued launches: release it only after the stream drains
-        if (g_ws) { hipStreamSynchronize(st); hipFree(g_ws); }
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_ws), need);
-        if (e != hipSuccess) { g_ws = nullptr; g_ws_bytes = 0; refid_set_error("conv_wino: split-K workspace: %s", hipGetErrorString(e)); return 2; }
-        g_ws_bytes = need;
+    if (need > ws_bytes || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+        refid_set_error("conv_wino: split-K workspace too small or misaligned (%zu bytes given, %zu needed: "
+                        "refid_conv_workspace_bytes)", ws_bytes, need);
+        return 1;
     }
     ConvKArgs p = a;                       // partial pass: raw sums into the workspace
-    p.ksplit = ks; p.wsStride = npix * ldW; p.out = g_ws; p.ldO = ldW;
+    p.ksplit = ks; p.wsStride = npix * ldW; p.out = ws; p.ldO = ldW;
     grid.y = ks;
     if (narrow) hipLaunchKernelGGL((conv_wino_kernel<1, 2>), grid, dim3(256), LDS_BYTES, st, p);
     else hipLaunchKernelGGL((conv_wino_kernel<2, 1>), grid, dim3(256), LDS_BYTES, st, p);
@@ -417,7 +423,7 @@ int refid_launch_wino3x3(const ConvKArgs& ka, hipStream_t st) {
     const long long tot4 = npix * (ldW / 4);
     int nb = (int)((tot4 + 255) / 256);
     if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(wino_splitk_finish_kernel, dim3(nb), dim3(256), 0, st, f, g_ws, ldW, npix, ldW / 4);
+    hipLaunchKernelGGL(wino_splitk_finish_kernel, dim3(nb), dim3(256), 0, st, f, ws, ldW, npix, ldW / 4);
     REFID_LAUNCH_CHECK("conv_wino/finish");
     return 0;
 }

@@ -432,21 +432,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(db + i, sb[i]);
 }
 
-// beta/gamma fold-back (see refid_hip.h): per row r:
-//   dscale[r] += sum_k W[r][k]*G[r][k] + b[r]*gb[r] ;  G[r][:] *= scale[r] ; gb[r] *= scale[r]
+// beta/gamma fold-back (see refid_hip.h): per row r, Gf / gbf = gradient of the FOLDED weights of this backward:
+//   dscale[r] += sum_k W[r][k]*Gf[r][k] + b[r]*gbf[r] ;  G[r][:] += scale[r]*Gf[r][:] ; gb[r] += scale[r]*gbf[r]
 __global__ __launch_bounds__(64) void fold_back_kernel(const float* __restrict__ W, const float* __restrict__ b,
-                                                      const float* __restrict__ scale, float* __restrict__ G,
+                                                      const float* __restrict__ scale, const float* __restrict__ Gf,
+                                                      const float* __restrict__ gbf, float* __restrict__ G,
                                                       float* __restrict__ gb, float* __restrict__ dscale, int K) {
     const int r = blockIdx.x;
+    const float sc = scale[r];
     float a = 0.f;
-    for (int k = threadIdx.x; k < K; k += 64) a += W[(long long)r * K + k] * G[(long long)r * K + k];
+    for (int k = threadIdx.x; k < K; k += 64) {
+        const float gf = Gf[(long long)r * K + k];
+        a += W[(long long)r * K + k] * gf;
+        G[(long long)r * K + k] += sc * gf;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    const float sc = scale[r];
-    for (int k = threadIdx.x; k < K; k += 64) G[(long long)r * K + k] *= sc;
     if (threadIdx.x == 0) {
-        dscale[r] += a + b[r] * gb[r];
-        gb[r] *= sc;
+        dscale[r] += a + b[r] * gbf[r];
+        gb[r] += sc * gbf[r];
     }
 }
 
@@ -610,10 +614,14 @@ extern "C" int refid_colsum(const float* g, int ld_g, float* db, long long npix,
     return 0;
 }
 
-extern "C" int refid_fold_back(const float* w, const float* b, const float* scale, float* gw, float* gb,
-                               float* dscale, int rows, int k, void* stream) {
-    REFID_CHECK(w && b && scale && gw && gb && dscale && rows > 0 && k > 0, "fold_back: bad arguments");
-    hipLaunchKernelGGL(fold_back_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, w, b, scale, gw, gb, dscale, k);
+extern "C" int refid_fold_back(const float* w, const float* b, const float* scale, const float* gw_folded,
+                               const float* gb_folded, float* gw, float* gb, float* dscale, int rows, int k,
+                               void* stream) {
+    REFID_CHECK(w && b && scale && gw_folded && gb_folded && gw && gb && dscale && rows > 0 && k > 0,
+                "fold_back: bad arguments");
+    REFID_CHECK(gw_folded != gw && gb_folded != gb, "fold_back: the folded gradient must not alias the accumulated one");
+    hipLaunchKernelGGL(fold_back_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, w, b, scale, gw_folded, gb_folded,
+                       gw, gb, dscale, k);
     REFID_LAUNCH_CHECK("fold_back");
     return 0;
 }

@@ -25,10 +25,12 @@ extern "C" int refid_device_cu_count(void) {
 namespace {
 
 // ---- NCHW -> NHWC (padded) : one block transposes a 32-pixel x C strip through LDS ----------
+// (tCount > 1: the source is (n, tCount, C, HW) and the tCount slices are summed on the way -- the gradient of a tensor
+// every time step reads, e.g. `head` in `pred(z_t + head)`, XXNet_final_attenfusion_arch.py:215)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
                                                           long long srcBatchStride,
                                                           float* __restrict__ dst, int C, int HW,
-                                                          int Cpad) {
+                                                          int Cpad, int tCount, long long tStride) {
     // grid.x = pixel blocks of 64, grid.y = n
     __shared__ float tile[64][65];
     const int n = blockIdx.y;
@@ -38,7 +40,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         // read: coalesced along pixels
         for (int cc = ty; cc < 64; cc += 4) {
             const int c = c0 + cc, p = p0 + tx;
-            tile[cc][tx] = (c < C && p < HW) ? src[(long long)n * srcBatchStride + (long long)c * HW + p] : 0.f;
+            float v = 0.f;
+            if (c < C && p < HW) {
+                const float* sp = src + (long long)n * srcBatchStride + (long long)c * HW + p;
+                for (int t = 0; t < tCount; ++t) v += sp[t * tStride];
+            }
+            tile[cc][tx] = v;
         }
         __syncthreads();
         // write: coalesced along channels
@@ -239,8 +246,19 @@ extern "C" int refid_nchw_to_nhwc(const float* src, long long src_batch_stride, 
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc: bad arguments");
     dim3 grid(cdiv(h * w, 64), n);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
-                       h * w, c_pad);
+                       h * w, c_pad, 1, 0ll);
     REFID_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int refid_nchw_tsum_to_nhwc(const float* src, long long src_batch_stride, long long t_stride, int t_count,
+                                       float* dst, int n, int c, int h, int w, int c_pad, void* stream) {
+    REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c && t_count > 0,
+                "nchw_tsum_to_nhwc: bad arguments");
+    dim3 grid(cdiv(h * w, 64), n);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
+                       h * w, c_pad, t_count, t_stride);
+    REFID_LAUNCH_CHECK("nchw_tsum_to_nhwc");
     return 0;
 }
 

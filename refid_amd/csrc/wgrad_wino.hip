@@ -298,13 +298,8 @@ size_t refid_wgrad_wino_workspace_bytes(const refid_wgrad_desc* d) {
 }
 
 int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e != hipSuccess) { refid_set_error("wgrad_wino: LDS attribute: %s", hipGetErrorString(e)); return 2; }
-        attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino_kernel, LDS_BYTES, "wgrad_wino")) return rc;
     const Geo g = geo_of(d);
     WwArgs a;
     a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;

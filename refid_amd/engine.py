@@ -192,6 +192,11 @@ class ConvOp:
         self.gb = arena.g(name + ".bias") if self.has_bias else None
         self.scale = arena.p(scale_name).view(-1) if scale_name else None
         self.scale_name = scale_name
+        # a conv whose packed weights carry a folded per-row scale (EGACA's beta / gamma) accumulates the gradient of
+        # the FOLDED weights; it must never be mixed with what the arena already holds (gradient accumulation over
+        # several backward calls), so it goes to a private buffer that Engine.backward zeroes and refid_fold_back
+        # un-folds into the arena (Engine._bind_fold_scratch)
+        self.gw_arena, self.gb_arena = self.gw, self.gb
         s = self.w.shape
         if kind == "convT":
             self.ci, self.co, self.k = s[0], s[1], 2
@@ -483,6 +488,18 @@ class Engine:
         self.packed_version = -1
         self.param_version = 0
         self.ctx = None
+        self._bind_fold_scratch()
+
+    def _bind_fold_scratch(self):
+        self.folded_ops = [o for o in self.all_ops if o.scale is not None]
+        n = sum((o.gw_arena.numel() + 3) // 4 * 4 + (o.gb_arena.numel() + 3) // 4 * 4 for o in self.folded_ops)
+        self.fold_scratch = torch.zeros(max(n, 4), dtype=torch.float32, device=self.device)
+        off = 0
+        for o in self.folded_ops:
+            for attr, ref in (("gw", o.gw_arena), ("gb", o.gb_arena)):
+                k = ref.numel()
+                setattr(o, attr, self.fold_scratch[off:off + k].view(ref.shape))
+                off += (k + 3) // 4 * 4
 
     # -------------------------------------------------------------------------------------------
     def mark_params_changed(self):
@@ -567,7 +584,8 @@ class Engine:
 
     def _egaca_fold_back(self, A):
         for conv, nm in ((A.conv3, "beta"), (A.conv5, "gamma")):
-            ops.fold_back(conv.w, conv.b, conv.scale, conv.gw, conv.gb, A.g(nm).view(-1))
+            ops.fold_back(conv.w, conv.b, conv.scale, conv.gw, conv.gb, conv.gw_arena, conv.gb_arena,
+                          A.g(nm).view(-1))
 
     # -------------------------------------------------------------------------------------------
     # trunk = EvR hidden-state update (rsm:659-678, 719-726, 755-758)
@@ -722,6 +740,9 @@ class Engine:
         if c is None:
             raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
         WGRAD_STREAM.pending.clear()          # leftovers of a backward that raised must never be launched
+        for o in self.all_ops:                # ... nor may its half-filled slabs be added to (phase 2) or reduced
+            o.w_calls, o.w_last = 0, None
+        self.fold_scratch.zero_()             # folded-weight gradients of THIS backward only (see ConvOp.__init__)
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
         dev = gout.device
@@ -729,7 +750,7 @@ class Engine:
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]
         zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)  # noqa: E731
         # pred has no activation (arch:215), so head's share sum_t dgrad(g_t) is dgrad(sum_t g_t): one launch
-        g_head = self.pred.dgrad(ops.nchw_to_nhwc(gout.sum(dim=1), _pad4(self.out_chn)))
+        g_head = self.pred.dgrad(ops.nchw_tsum_to_nhwc(gout, _pad4(self.out_chn)))
         g_xb = [zeros(t) for t in xb]
         g_Sb = [None, None, None]
         g_e = torch.empty_like(e_all)

@@ -5,6 +5,7 @@ pitch may exceed C (channel-slice views of wider buffers).  torch is used here o
 for device memory and streams; all arithmetic happens in librefid_hip.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -13,6 +14,9 @@ from ._lib import ConvDesc, WgradDesc, check, lib
 
 ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_FWD, ROLE_WINO_DGRAD = range(7)
 
+
+# Winograd split-K policy (refid_conv_desc.wino_split): REFID_WINO_SPLITK = sample (default) | auto | 0
+WINO_SPLIT = {"0": 0, "a": 2}.get(os.environ.get("REFID_WINO_SPLITK", "sample")[:1], 1)
 
 # bench.py's roofline leg: when PROFILE is a list, conv2d()/conv2d_wgrad() bracket each launch with
 # events on the launch stream and append (kernel, algorithmic_flops, start_event, end_event).
@@ -124,6 +128,12 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.kh, d.kw, d.stride, d.pad, d.mode = kh, kw, stride, pad, mode
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
     d.algo = algo
+    if algo == 1 and WINO_SPLIT:
+        d.wino_split = WINO_SPLIT
+        need = lib().refid_conv_workspace_bytes(C.byref(d))
+        if need:
+            ws = _workspace(need, in_a.device, "conv")
+            d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
     if PROFILE is None:
         check(lib().refid_conv2d(C.byref(d), _stream()), "refid_conv2d")
         return out
@@ -150,9 +160,10 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
 _ws_cache = {}
 
 
-def _workspace(nbytes, device):
-    """Grow-only scratch buffer per device (split-K slabs).  Stream-ordered re-use."""
-    key = (device.index, torch.cuda.current_stream().cuda_stream)
+def _workspace(nbytes, device, kind="wgrad"):
+    """Grow-only scratch buffer per (device, stream, kind): the C ABI never allocates, the caller lends it
+    scratch that is private to the launching stream (stream-ordered re-use)."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, kind)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
@@ -193,10 +204,12 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     if phase == 0:
         ws = _workspace(nbytes, g.device)
     else:
-        if slabs is None:
+        if slabs is None or (phase == 1 and slabs.numel() * 4 < nbytes):
+            # phase 1 overwrites: a larger batch / crop than the first step's simply gets a larger buffer
             slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
         elif slabs.numel() * 4 < nbytes:
-            raise _lib.RefidHipError("wgrad: persistent slab buffer too small for this geometry")
+            raise _lib.RefidHipError("wgrad: persistent slab buffer too small for this geometry (phase 2/3 must "
+                                     "see the geometry of the phase-1 call)")
         ws = slabs
     d.slabs = ws.data_ptr()
     if PROFILE is None or phase == 3:
@@ -222,6 +235,18 @@ def nchw_to_nhwc(src, c_pad=None, out=None):
     dst = out if out is not None else torch.empty((n, h, w, c_pad), dtype=torch.float32, device=src.device)
     check(lib().refid_nchw_to_nhwc(src.data_ptr(), src.stride(0) if n > 1 else c * h * w, dst.data_ptr(), n, c, h, w,
                                    c_pad, _stream()), "refid_nchw_to_nhwc")
+    return dst
+
+
+def nchw_tsum_to_nhwc(src, c_pad=None):
+    """(N,T,C,H,W) contiguous -> sum over T as (N,H,W,c_pad)."""
+    n, t, c, h, w = src.shape
+    if not src.is_contiguous():
+        raise _lib.RefidHipError("nchw_tsum_to_nhwc: contiguous (N,T,C,H,W) tensor required")
+    c_pad = c_pad or ((c + 3) // 4) * 4
+    dst = torch.empty((n, h, w, c_pad), dtype=torch.float32, device=src.device)
+    check(lib().refid_nchw_tsum_to_nhwc(src.data_ptr(), t * c * h * w, c * h * w, t, dst.data_ptr(), n, c, h, w, c_pad,
+                                        _stream()), "refid_nchw_tsum_to_nhwc")
     return dst
 
 
@@ -395,11 +420,14 @@ def mul_vec(a, b, out=None):
     return out
 
 
-def fold_back(w, b, scale, gw, gb, dscale):
+def fold_back(w, b, scale, gw_folded, gb_folded, gw, gb, dscale):
+    """Un-fold the gradient of (scale[r]*W[r,:], scale[r]*b[r]) accumulated in gw_folded/gb_folded:
+    dscale[r] += <W[r,:],Gf[r,:]> + b[r]*gbf[r];  gw[r,:] += scale[r]*Gf[r,:];  gb[r] += scale[r]*gbf[r]."""
     rows = scale.numel()
     k = w.numel() // rows
-    check(lib().refid_fold_back(_c(w, "w"), _c(b, "b"), _c(scale, "scale"), _c(gw, "gw"), _c(gb, "gb"),
-                                _c(dscale, "dscale"), rows, k, _stream()), "refid_fold_back")
+    check(lib().refid_fold_back(_c(w, "w"), _c(b, "b"), _c(scale, "scale"), _c(gw_folded, "gw_folded"),
+                                _c(gb_folded, "gb_folded"), _c(gw, "gw"), _c(gb, "gb"), _c(dscale, "dscale"), rows, k,
+                                _stream()), "refid_fold_back")
 
 
 def charbonnier(pred, gt, grad=None, eps=1e-12, grad_scale=None):

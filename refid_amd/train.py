@@ -22,6 +22,40 @@ from .archs import define_network
 from .dist import GradSync, get_dist_info
 
 
+def scheduler_lr(kind, cfg, epoch, base_lr, prev_lr, total_iter=None):
+    """Learning rate after `epoch` scheduler steps -- the schedulers base_model.py:77-108 can build
+    (models/lr_scheduler.py:6-177 + torch CosineAnnealingLR), restated per step for ONE param group.
+    prev_lr: the current lr (the multi-step scheme is recursive on it)."""
+    if kind == "none":
+        return base_lr
+    if kind == "TrueCosineAnnealingLR":
+        # torch.optim.lr_scheduler.CosineAnnealingLR.get_lr: RECURSIVE on the group's current lr (so a warm-up that
+        # overwrote the lr carries over, exactly as in the reference); equals the closed form otherwise
+        eta, tm = cfg["eta_min"], cfg["T_max"]
+        if (epoch - 1 - tm) % (2 * tm) == 0:
+            return prev_lr + (base_lr - eta) * (1 - math.cos(math.pi / tm)) / 2
+        return (1 + math.cos(math.pi * epoch / tm)) / (1 + math.cos(math.pi * (epoch - 1) / tm)) * (prev_lr - eta) + eta
+    if kind in ("MultiStepLR", "MultiStepRestartLR"):     # lr_scheduler.py:6-46
+        restarts, weights = list(cfg.get("restarts", (0,))), list(cfg.get("restart_weights", (1,)))
+        if epoch in restarts:
+            return base_lr * weights[restarts.index(epoch)]
+        n = list(cfg["milestones"]).count(epoch)
+        return prev_lr * cfg.get("gamma", 0.1) ** n if n else prev_lr
+    if kind == "CosineAnnealingRestartLR":                # lr_scheduler.py:117-177
+        periods, weights = list(cfg["periods"]), list(cfg.get("restart_weights", (1,)))
+        cum = [sum(periods[:i + 1]) for i in range(len(periods))]
+        idx = next(i for i, c in enumerate(cum) if epoch <= c)
+        near = 0 if idx == 0 else cum[idx - 1]
+        eta = cfg.get("eta_min", 0)
+        return eta + weights[idx] * 0.5 * (base_lr - eta) * (1 + math.cos(math.pi * (epoch - near) / periods[idx]))
+    if kind == "LinearLR":                                # lr_scheduler.py:48-67
+        return (1 - epoch / total_iter) * base_lr
+    raise NotImplementedError(f"Scheduler {kind} is not implemented yet.")
+
+
+SCHEDULERS = ("TrueCosineAnnealingLR", "MultiStepLR", "MultiStepRestartLR", "CosineAnnealingRestartLR", "LinearLR")
+
+
 class TwoImageEventRecurrentRestorationModel:
     PIXEL_LOSSES = ("CharbonnierLoss",)            # the only one the reference's configs for this model use
 
@@ -59,11 +93,14 @@ class TwoImageEventRecurrentRestorationModel:
         self.betas = tuple(og.get("betas", (0.9, 0.999)))
         self.adam_eps = float(og.get("eps", 1e-8))
         sch = dict(train_opt.get("scheduler", {"type": "none"}))
-        self.sched_type = sch.get("type", "none")
-        if self.sched_type in ("CosineAnnealingLR", "TrueCosineAnnealingLR"):
-            self.t_max, self.eta_min = int(sch["T_max"]), float(sch.get("eta_min", 0.0))
-        elif self.sched_type != "none":
-            raise NotImplementedError(f"Scheduler {self.sched_type} is not implemented yet.")
+        self.sched_type = sch.pop("type", "none")
+        if self.sched_type == "TrueCosineAnnealingLR":
+            sch = dict(T_max=int(sch["T_max"]), eta_min=float(sch.get("eta_min", 0.0)))
+        elif self.sched_type not in SCHEDULERS + ("none",):
+            # base_model.py:77-108 also knows VibrateLR (unused by any options/*.yml); everything else raises there too
+            raise NotImplementedError(f"Scheduler {self.sched_type} is not implemented yet. (supported: {SCHEDULERS})")
+        self.sched_cfg = sch
+        self.total_iter = train_opt.get("total_iter")
         self.use_grad_clip = train_opt.get("use_grad_clip", True)
         eng = self.net_g.engine
         self.exp_avg = torch.zeros_like(eng.arena.flat_p)
@@ -82,15 +119,14 @@ class TwoImageEventRecurrentRestorationModel:
             eng.mark_params_changed()
 
     def update_learning_rate(self, current_iter, warmup_iter=-1):
-        """base_model.py:158-180: scheduler.step() from the second iteration on (+ linear warm-up)."""
+        """base_model.py:158-180: scheduler.step() from the second iteration on; during warm-up the lr is the
+        INITIAL lr scaled linearly (init_lr / warmup_iter * current_iter), not the scheduled one."""
         if current_iter > 1:
             self.sched_epoch += 1
-        lr = self.base_lr
-        if self.sched_type != "none":
-            lr = self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * self.sched_epoch / self.t_max)) / 2
+            self.cur_lr = scheduler_lr(self.sched_type, self.sched_cfg, self.sched_epoch, self.base_lr, self.cur_lr,
+                                       self.total_iter)
         if current_iter < warmup_iter:
-            lr = lr / warmup_iter * current_iter
-        self.cur_lr = lr
+            self.cur_lr = self.base_lr / warmup_iter * current_iter
 
     def get_current_learning_rate(self):
         return [self.cur_lr]
@@ -119,6 +155,10 @@ class TwoImageEventRecurrentRestorationModel:
                        step=self.step_count, grad_scale=1.0 / self.world)     # optimizer_g.step()
         eng.mark_params_changed()
         self.output = pred
+        # reduce_loss_dict (base_model.py:325-350) runs inside optimize_parameters on EVERY rank (a loop that only
+        # logs on rank 0 must not desynchronise the collectives); only the .item() is deferred to get_current_log
+        if self.dist_on:
+            torch.distributed.all_reduce(loss_sum)          # 8 bytes; every rank ends up with the mean, not only rank 0
         self._loss_sum, self._loss_n = loss_sum, n
         self.log_dict = None
 
@@ -130,13 +170,13 @@ class TwoImageEventRecurrentRestorationModel:
         return gpred, loss_sum, n
 
     def get_current_log(self):
-        """reduce_loss_dict (base_model.py:325-350): mean over ranks, evaluated lazily (one sync)."""
+        """The loss of the last step, averaged over ranks (reduce_loss_dict).  No collective here -- it ran inside
+        optimize_parameters -- just one device sync for the .item()."""
         if self.log_dict is None:
-            l = self._loss_sum.clone()
+            l = float(self._loss_sum.item())
             if self.dist_on:
-                torch.distributed.all_reduce(l)
                 l /= self.world
-            self.log_dict = OrderedDict(l_pix=float(l.item()) * self.loss_weight / self._loss_n)
+            self.log_dict = OrderedDict(l_pix=l * self.loss_weight / self._loss_n)
         return self.log_dict
 
     def grad_norm(self):
@@ -157,11 +197,48 @@ class TwoImageEventRecurrentRestorationModel:
         self.net_g.train()
 
     # ---- checkpoints (state-dict key names are a compatibility contract) ------
-    def save_network(self, net, save_path, param_key="params"):
-        sd = OrderedDict((k.replace("module.", "", 1) if k.startswith("module.") else k, v.detach().cpu().clone())
+    def save_network(self, net, net_label, current_iter, param_key="params"):
+        """base_model.py:188-219: {opt['path']['models']}/{net_label}_{iter|latest}.pth holding {param_key: state_dict}
+        with any 'module.' prefix removed; rank 0 only (@master_only)."""
+        if self.rank != 0:
+            return None
+        if current_iter == -1:
+            current_iter = "latest"
+        save_path = os.path.join(self.opt["path"]["models"], f"{net_label}_{current_iter}.pth")
+        net = getattr(net, "module", net) if isinstance(net, (torch.nn.DataParallel,
+                                                               torch.nn.parallel.DistributedDataParallel)) else net
+        sd = OrderedDict((k[7:] if k.startswith("module.") else k, v.detach().cpu().clone())
                          for k, v in net.state_dict().items())
-        if self.rank == 0:
-            torch.save({param_key: sd}, save_path)
+        torch.save({param_key: sd}, save_path)
+        return save_path
+
+    def save(self, epoch, current_iter):
+        """twoImage_event_recurrent_model.py:552-554."""
+        self.save_network(self.net_g, "net_g", current_iter)
+        self.save_training_state(epoch, current_iter)
+
+    def save_training_state(self, epoch, current_iter):
+        """base_model.py:283-306: {opt['path']['training_states']}/{iter}.state with one optimizer / scheduler entry
+        (the fused AdamW's state lives in two flat arenas: they are stored as such)."""
+        if self.rank != 0 or current_iter == -1:
+            return None
+        state = {"epoch": epoch, "iter": current_iter,
+                 "optimizers": [{"type": "refid_amd.fused_adamw", "step": self.step_count,
+                                 "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()}],
+                 "schedulers": [{"type": self.sched_type, "last_epoch": self.sched_epoch, "lr": self.cur_lr}]}
+        save_path = os.path.join(self.opt["path"]["training_states"], f"{current_iter}.state")
+        torch.save(state, save_path)
+        return save_path
+
+    def resume_training(self, resume_state):
+        """base_model.py:308-323."""
+        assert len(resume_state["optimizers"]) == 1, "Wrong lengths of optimizers"
+        assert len(resume_state["schedulers"]) == 1, "Wrong lengths of schedulers"
+        o, sc = resume_state["optimizers"][0], resume_state["schedulers"][0]
+        self.step_count = int(o["step"])
+        self.exp_avg.copy_(o["exp_avg"])
+        self.exp_avg_sq.copy_(o["exp_avg_sq"])
+        self.sched_epoch, self.cur_lr = int(sc["last_epoch"]), float(sc["lr"])
 
     def load_network(self, net, load_path, strict=True, param_key="params"):
         load_net = torch.load(load_path, map_location="cpu")

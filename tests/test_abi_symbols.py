@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(libpath):
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in refid_hip.h but not exported: {missing}"
     lib.refid_abi_version.restype = ctypes.c_int
-    assert lib.refid_abi_version() == 1
+    assert lib.refid_abi_version() == 2
 
 
 def test_python_binding_loads_and_host_queries_work(libpath):
@@ -62,7 +62,7 @@ def test_struct_layouts_match_the_header():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            names = re.sub(r"^(const\s+)?(float|int)\s*\*?", "", stmt)
+            names = re.sub(r"^(const\s+)?(float|int|size_t)\s*\*?", "", stmt)
             out += [n.strip().lstrip("*").strip() for n in names.split(",")]
         return out
 

@@ -527,3 +527,50 @@ def test_thin_input_wgrad(cfg):
     ops.conv2d_wgrad(gd, x4, dw2, kh=k, kw=k, stride=1, pad=k // 2, db=db2, i_total=Ci, phase=3, slabs=sl)
     np.testing.assert_allclose(dw2.cpu().numpy(), dw.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
     np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+
+
+def test_winograd_splitk_two_streams_have_private_workspaces():
+    """the C ABI owns no scratch -- refid_conv2d takes the caller's workspace
+    (refid_conv_workspace_bytes), so split-K Winograd launches issued concurrently from two streams cannot share
+    partial sums.  Results == the serial launches, bit for bit; no workspace = no split, same values within rounding."""
+    import ctypes as C
+    from refid_amd import _lib
+    ops = _ops()
+    N, H, W, Ci, Co = 1, 16, 32, 256, 128            # 1x2 pixel tiles x 2 channel tiles, 32 chunks -> splits 4-way
+    probs = []
+    for s in range(2):
+        x = nhwc(rnd(N, Ci, H, W, seed=10 + s))
+        w = rnd(Co, Ci, 3, 3, seed=20 + s, scale=0.05).float().cuda()
+        wp = ops.pack_conv_weights(w, ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+        probs.append((x, wp))
+    d = _lib.ConvDesc()
+    d.n, d.h, d.w, d.ho, d.wo, d.c_a, d.cout, d.cout_pad, d.algo, d.wino_split = N, H, W, H, W, Ci, Co, 128, 1, 1
+    assert _lib.lib().refid_conv_workspace_bytes(C.byref(d)) == 4 * N * H * W * Co * 4
+    d.wino_split = 0
+    assert _lib.lib().refid_conv_workspace_bytes(C.byref(d)) == 0
+
+    def run(x, wp, reps):
+        out = torch.empty(N, H, W, Co, device="cuda")
+        for _ in range(reps):
+            ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=128, algo=1)
+        return out
+
+    serial = [run(x, wp, 1).clone() for x, wp in probs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None, None]
+    for _ in range(3):                                 # interleave many launches so the two streams really overlap
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i] = run(*probs[i], reps=20)
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(outs[i], serial[i]), f"stream {i}: concurrent split-K result differs from the serial one"
+    keys = [k for k in ops._ws_cache if k[2] == "conv"]
+    assert len({k[1] for k in keys}) >= 3              # default stream + the two side streams: one buffer each
+    old, ops.WINO_SPLIT = ops.WINO_SPLIT, 0
+    try:
+        nosplit = run(*probs[0], reps=1)
+    finally:
+        ops.WINO_SPLIT = old
+    np.testing.assert_allclose(nosplit.cpu().numpy(), serial[0].cpu().numpy(), rtol=1e-4, atol=1e-5)

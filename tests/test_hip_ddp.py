@@ -55,6 +55,59 @@ def _worker(rank, world, port, ret, backend="gloo"):
     dist.destroy_process_group()
 
 
+def _ddp_worker(rank, world, port, ret):
+    """The reference's model_to_device (base_model.py:57-75, opt['dist'] branch) applied to the drop-in module, then the
+    reference's optimize_parameters sequence (twoImage_event_recurrent_model.py:273-310) with torch's own AdamW."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from refid_amd.archs import define_network
+    from refid_amd.dist import shard_batch
+    torch.cuda.set_device(0)
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2, num_encoders=3,
+                              base_num_channels=8, num_block=1, num_residual_blocks=2))
+    net.load_state_dict(O.make_params(26, base_num_channels=8, mode="hash", seed=5 + rank))   # ranks start different
+    net = net.to("cuda")
+    net = DistributedDataParallel(net, device_ids=[torch.cuda.current_device()], find_unused_parameters=False)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-4, weight_decay=1e-4, betas=(0.9, 0.99))
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    mine = shard_batch(2, rank, world)
+    for _ in range(2):
+        opt.zero_grad()
+        pred = net(x=x[mine].cuda(), event=ev[mine].cuda())
+        l_total = torch.sqrt((pred - gt[mine].cuda()) ** 2 + 1e-12).mean()
+        l_total = l_total + 0 * sum(p.sum() for p in net.parameters())
+        l_total.backward()
+        gn = torch.nn.utils.clip_grad_norm_(net.parameters(), 0.01)
+        opt.step()
+    ret[rank] = (float(gn), {k: v.cpu() for k, v in net.module.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def test_distributed_data_parallel_wraps_the_drop_in_module():
+    """`DistributedDataParallel(net_g)` exactly as base_model.py:66-72 does it.  Two ranks (gloo, sharing
+    the GPU) x B=1 with torch's clip + AdamW == the oracle's two train steps on the B=2 batch."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, port, ret), nprocs=2, join=True)
+    (gn0, sd0), (gn1, sd1) = ret[0], ret[1]
+    assert gn0 == gn1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k                  # rank-0 broadcast + averaged gradients: replicas agree
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    Pc = {k: v.clone() for k, v in P.items()}
+    st = O.TrainState(Pc)
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    for _ in range(2):
+        _, gnorm_ref, _, _ = O.train_step(Pc, st, x, ev, gt, lr=2e-4)
+    assert abs(gn0 - float(gnorm_ref)) < 2e-3 * float(gnorm_ref)
+    for k in P:
+        disp = (Pc[k].double() - P[k].double()).abs().max().item()
+        assert (sd0[k].double() - Pc[k].double()).abs().max().item() <= 0.03 * disp + 1e-9, k
+
+
 def test_two_rank_step_equals_single_rank_on_the_full_batch():
     from refid_amd.train import TwoImageEventRecurrentRestorationModel
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()

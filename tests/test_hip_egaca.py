@@ -150,11 +150,14 @@ def test_fold_back_and_scaled_pack():
                res=dev(r.permute(0, 2, 3, 1)))
     close(out, y.detach().permute(0, 2, 3, 1))
     # gradients of the folded conv, then fold back
-    gw = torch.zeros(Co, Ci, 1, 1, device="cuda"); gb = torch.zeros(Co, device="cuda")
-    ops.conv2d_wgrad(dev(g.permute(0, 2, 3, 1)), dev(x.permute(0, 2, 3, 1)), gw, kh=1, kw=1, db=gb)
-    dbeta = torch.zeros(Co, device="cuda")
-    ops.fold_back(dev(Wt.detach()), dev(b.detach()), dev(beta.detach()), gw, gb, dbeta)
-    close(gw, Wt.grad, atol=1e-4); close(gb, b.grad, atol=1e-4); close(dbeta, beta.grad, atol=1e-4)
+    gwf = torch.zeros(Co, Ci, 1, 1, device="cuda"); gbf = torch.zeros(Co, device="cuda")
+    ops.conv2d_wgrad(dev(g.permute(0, 2, 3, 1)), dev(x.permute(0, 2, 3, 1)), gwf, kh=1, kw=1, db=gbf)
+    # the accumulated gradients already hold something (gradient accumulation): it must be added to,
+    # never rescaled
+    gw = torch.full((Co, Ci, 1, 1), 0.5, device="cuda"); gb = torch.full((Co,), -0.25, device="cuda")
+    dbeta = torch.full((Co,), 2.0, device="cuda")
+    ops.fold_back(dev(Wt.detach()), dev(b.detach()), dev(beta.detach()), gwf, gbf, gw, gb, dbeta)
+    close(gw, Wt.grad + 0.5, atol=1e-4); close(gb, b.grad - 0.25, atol=1e-4); close(dbeta, beta.grad + 2.0, atol=1e-4)
 
 
 def test_charbonnier_norm_adamw():

@@ -141,3 +141,63 @@ def test_bf16_compute_path_psnr_parity(golden_dir):
     big = ref_gn > 1e-3 * ref_gn.max()
     np.testing.assert_allclose(gn[big], ref_gn[big], rtol=0.05)
     assert int((gn == 0).sum()) == 13
+
+
+def test_gradient_accumulation_over_two_backward_calls(golden_dir):
+    """gradients delivered through autograd ACCUMULATE like any module's -- including the EGACA
+    convs whose beta/gamma are folded into the packed weights (their un-fold must never rescale what is already
+    accumulated).  Two different batches, no zero_grad in between == the oracle's sum of the two gradients; and the
+    engine-level contract 'backward accumulates into the arena' holds as well."""
+    z, P, x, ev, gt, img_chn, base = load(golden_dir, "tiny26_train")
+    assert float(P["encoders_forward.1.atten_fuse.beta"].abs().max()) > 0        # fold is really active
+    x2, ev2, gt2 = O.make_inputs(x.shape[0], ev.shape[1], x.shape[2], x.shape[3], img_chn, seed=77, mode="hash")
+    refs = []
+    for a, b, c in ((x, ev, gt), (x2, ev2, gt2)):
+        Pc = {k: v.clone() for k, v in P.items()}
+        refs.append(O.train_step(Pc, O.TrainState(Pc), a, b, c)[2])
+    want = {k: refs[0][k].double() + refs[1][k].double() for k in P}
+    net = build(img_chn, base, P)
+    for a, b, c in ((x, ev, gt), (x2, ev2, gt2)):
+        pred = net(x=a.cuda(), event=b.cuda())
+        torch.sqrt((pred - c.cuda()) ** 2 + 1e-12).mean().backward()
+    _grad_check(net, P, want)
+    # engine level: two backward() calls on the same saved batch without zero_grad() == 2x one call
+    eng = net.engine
+    gpred = torch.full_like(pred, 1e-3)
+    eng.zero_grad()
+    eng.forward(x.cuda(), ev.cuda(), save=True)
+    eng.backward(gpred)
+    one = eng.arena.flat_g.clone()
+    eng.forward(x.cuda(), ev.cuda(), save=True)
+    eng.backward(gpred)
+    two = eng.arena.flat_g
+    scale = float(one.abs().max())
+    assert float((two - 2 * one).abs().max()) <= 1e-5 * scale
+    for k in ("encoders_forward.1.atten_fuse.beta", "encoders_backward.1.atten_fuse.gamma",
+              "encoders_forward.1.atten_fuse.conv3.weight", "encoders_backward.1.atten_fuse.conv5.bias"):
+        o, n = eng.arena.offsets[k]
+        assert float(one[o:o + n].abs().max()) > 0, k
+        np.testing.assert_allclose(two[o:o + n].cpu().numpy(), 2 * one[o:o + n].cpu().numpy(), rtol=1e-4,
+                                   atol=1e-6 * scale, err_msg=k)
+
+
+def test_parameter_hooks_fire_and_grads_do_not_alias_the_arena(golden_dir):
+    """Parameter gradients arrive through autograd (refid_amd/autograd.py): per-parameter hooks fire -- which is what
+    DistributedDataParallel's reducer hangs on -- and p.grad never aliases the engine's arena (the next backward
+    overwrites the arena)."""
+    z, P, x, ev, gt, img_chn, base = load(golden_dir, "tiny6_train")
+    net = build(img_chn, base, P)
+    fired = []
+    for k, p in net.named_parameters():
+        p.register_hook(lambda g, k=k: fired.append(k))
+    pred = net(x=x.cuda(), event=ev.cuda())
+    pred.mean().backward()
+    assert sorted(fired) == sorted(k for k, _ in net.named_parameters())
+    lo = net.engine.arena.flat_g.data_ptr()
+    hi = lo + net.engine.arena.flat_g.numel() * 4
+    assert all(not (lo <= p.grad.data_ptr() < hi) for p in net.parameters())
+    net.requires_grad_(False)
+    net.pred.conv2d.weight.requires_grad_(True)
+    net.zero_grad(set_to_none=True)
+    net(x=x.cuda(), event=ev.cuda()).mean().backward()
+    assert [k for k, p in net.named_parameters() if p.grad is not None] == ["pred.conv2d.weight"]

@@ -64,7 +64,9 @@ def test_three_train_steps_match_oracle():
 
 def test_eval_step_chunks_and_checkpoint_roundtrip(tmp_path):
     from refid_amd.train import TwoImageEventRecurrentRestorationModel
-    model = TwoImageEventRecurrentRestorationModel(_opt(6, 8))
+    opt = _opt(6, 8)
+    opt["path"].update(models=str(tmp_path), training_states=str(tmp_path))
+    model = TwoImageEventRecurrentRestorationModel(opt)
     P = O.make_params(6, base_num_channels=8, mode="hash", seed=2)
     model.net_g.load_state_dict(P)
     x, ev, gt = O.make_inputs(3, 2, 16, 24, 6, seed=3)
@@ -73,8 +75,9 @@ def test_eval_step_chunks_and_checkpoint_roundtrip(tmp_path):
     with torch.no_grad():
         ref = O.forward(P, x, ev)
     np.testing.assert_allclose(model.output.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
-    path = os.path.join(tmp_path, "net_g_1.pth")
-    model.save_network(model.net_g, path)
+    path = model.save_network(model.net_g, "net_g", 1)         # base_model.py:188-219 signature / file name
+    assert path == os.path.join(tmp_path, "net_g_1.pth")
+    assert model.save_network(model.net_g, "net_g", -1).endswith("net_g_latest.pth")
     ck = torch.load(path)
     assert list(ck.keys()) == ["params"] and list(ck["params"].keys()) == list(P.keys())
     m2 = TwoImageEventRecurrentRestorationModel({**_opt(6, 8), "path": {"pretrain_network_g": path, "strict_load_g": True}})
@@ -83,6 +86,37 @@ def test_eval_step_chunks_and_checkpoint_roundtrip(tmp_path):
     torch.save({"params": {"module." + k: v for k, v in ck["params"].items()}}, path)
     m3 = TwoImageEventRecurrentRestorationModel({**_opt(6, 8), "path": {"pretrain_network_g": path}})
     assert torch.equal(m3.net_g.state_dict()["pred.conv2d.weight"].cpu(), P["pred.conv2d.weight"])
+
+
+def test_save_and_resume_training_state(tmp_path):
+    """save(epoch, iter) (twoImage_event_recurrent_model.py:552-554) + resume_training (base_model.py:308-323): a run
+    resumed from the saved network + state continues bit-identically."""
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    opt = _opt(6, 8)
+    opt["path"].update(models=str(tmp_path), training_states=str(tmp_path))
+    P = O.make_params(6, base_num_channels=8, mode="hash", seed=9)
+    x, ev, gt = O.make_inputs(1, 2, 16, 16, 6, seed=4, mode="hash")
+    a = TwoImageEventRecurrentRestorationModel(opt)
+    a.net_g.load_state_dict(P)
+    a.feed_data({"lq": x, "voxel": ev, "gt": gt})
+    for it in (1, 2):
+        a.update_learning_rate(it)
+        a.optimize_parameters(it)
+    a.save(0, 2)
+    for it in (3, 4):
+        a.update_learning_rate(it)
+        a.optimize_parameters(it)
+    o2 = _opt(6, 8)
+    o2["path"].update(pretrain_network_g=os.path.join(tmp_path, "net_g_2.pth"))
+    b = TwoImageEventRecurrentRestorationModel(o2)
+    b.resume_training(torch.load(os.path.join(tmp_path, "2.state")))
+    b.feed_data({"lq": x, "voxel": ev, "gt": gt})
+    for it in (3, 4):
+        b.update_learning_rate(it)
+        b.optimize_parameters(it)
+    assert b.get_current_learning_rate() == a.get_current_learning_rate()
+    for (k, va), vb in zip(a.net_g.state_dict().items(), b.net_g.state_dict().values()):
+        assert torch.equal(va, vb), k
 
 
 def test_unsupported_training_options_raise():

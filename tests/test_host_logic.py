@@ -3,6 +3,7 @@ layout, schedules, bucket planning, and that the product path refuses to run wit
 import os
 import textwrap
 
+import numpy as np
 import pytest
 import torch
 
@@ -177,3 +178,66 @@ def test_evhinet_module_mirrors_reference_state_dict_on_cpu():
     assert all(tuple(sd[k].shape) == tuple(want[k]) for k in want)
     with pytest.raises(RefidHipError):
         net(x=torch.zeros(1, 3, 16, 16), event=torch.zeros(1, 6, 16, 16))
+
+
+def test_init_matches_reference_moments(golden_dir):
+    """A11: reset_parameters() against the reference ctor's own initialisation
+    (recurrent_sub_modules.py:752-753,776-804: ResidualBlockNoBN convs Kaiming-normal x0.1 with zero bias; torch
+    defaults elsewhere; LayerNorm2d 1/0; beta/gamma 0) -- per-parameter moments stored by oracle/make_golden.py."""
+    import math
+    from refid_amd.archs import define_network
+    z = np.load(os.path.join(golden_dir, "host_logic.npz"))
+    keys, mom = [str(k) for k in z["init_keys"]], z["init_moments"]
+    torch.manual_seed(123)                                   # a DIFFERENT seed: only the distributions must agree
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2, num_encoders=3,
+                              base_num_channels=32, num_block=1, num_residual_blocks=2))
+    sd = net.state_dict()
+    assert list(sd.keys()) == keys
+    n_kaiming = 0
+    for k, (numel, mean, std, amax, lo, hi) in zip(keys, mom):
+        v = sd[k].double().flatten()
+        assert v.numel() == numel, k
+        if std == 0.0:                                       # constants: LN weight 1 / bias 0, beta, gamma, resblock biases
+            assert float(v.min()) == lo and float(v.max()) == hi, k
+            continue
+        my_std = float(v.std(unbiased=False))
+        if ".main.2.0.conv" in k:                            # Kaiming normal (fan_in, gain sqrt(2)) x 0.1
+            n_kaiming += 1
+            assert k.endswith("weight")
+            fan_in = sd[k].shape[1] * 9
+            want = 0.1 * math.sqrt(2.0 / fan_in)
+            assert abs(std - want) < 0.02 * want, (k, std, want)          # the reference itself
+            assert abs(my_std - want) < 0.02 * want, (k, my_std, want)
+            assert float(v.abs().max()) > 3.0 * want                      # normal tails, not a uniform
+        else:                                                # torch default: U(-1/sqrt(fan_in), 1/sqrt(fan_in))
+            w = sd[k[:-4] + "weight"] if k.endswith("bias") else sd[k]
+            bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
+            assert amax <= bound * (1 + 1e-6) and float(v.abs().max()) <= bound * (1 + 1e-6), k
+            tol = 0.02 if numel >= 10000 else (0.1 if numel >= 512 else 0.45)
+            assert abs(my_std - bound / math.sqrt(3)) < tol * bound, (k, my_std, bound)
+            assert abs(std - bound / math.sqrt(3)) < tol * bound, (k, std, bound)
+            if numel >= 512:
+                assert float(v.abs().max()) > 0.9 * bound, k
+    assert n_kaiming == 2 * (6 + 3)                          # conv1/conv2 of 6 EvR trunks + 3 decoder trunks
+
+
+def test_schedulers_match_reference_sequences(golden_dir):
+    """base_model.py:77-108,158-180: every scheduler type the reference can build, stepped from iteration 2,
+    with the linear warm-up that scales the INITIAL lr; sequences recorded from the reference's own scheduler classes."""
+    import ast
+    from refid_amd import train
+    z = np.load(os.path.join(golden_dir, "host_logic.npz"))
+    names = [k[3:] for k in z.files if k.startswith("lr/")]
+    assert len(names) == 6
+    for name in names:
+        kind, cfg, warm, total = ast.literal_eval(str(z["lrcfg/" + name]))
+        m = train.TwoImageEventRecurrentRestorationModel.__new__(train.TwoImageEventRecurrentRestorationModel)
+        m.base_lr = m.cur_lr = 2e-4
+        m.sched_type, m.sched_cfg, m.sched_epoch, m.total_iter = kind, cfg, 0, total
+        seq = []
+        for it in range(1, 40):
+            m.update_learning_rate(it, warmup_iter=warm)
+            seq.append(m.get_current_learning_rate()[0])
+        np.testing.assert_allclose(np.array(seq), z["lr/" + name], rtol=1e-9, atol=1e-15, err_msg=name)
+    with pytest.raises(NotImplementedError):
+        train.scheduler_lr("CosineAnnealingLR", {}, 1, 2e-4, 2e-4)     # the reference rejects this spelling too

@@ -43,6 +43,19 @@ constexpr int LDS_BYTES = 64 * 66 * 16;   // 2 raw buffers (13-22 KB) in the K l
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 
+// tools/probes/wino_trace.py builds this file with -DREFID_WINO_TRACE: every workgroup records wall-clock stamps
+// (100 MHz) at its phase boundaries + the CU it ran on, to see where a tile's time goes.  Never in the product build.
+#ifdef REFID_WINO_TRACE
+__device__ unsigned long long* g_wino_trace = nullptr;
+#define WINO_STAMP(slot)                                                                                     \
+    do {                                                                                                     \
+        if (g_wino_trace && threadIdx.x == 0)                                                                \
+            g_wino_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64();        \
+    } while (0)
+#else
+#define WINO_STAMP(slot) do {} while (0)
+#endif
+
 // <NTN, MTN>: a wave's second dimension is either two 32-channel column tiles (NTN = 2: workgroup tile
 // 4x32 pixels x 64 channels) or two 4-row pixel tiles (MTN = 2: 8x32 pixels x 32 channels, 32-channel layers).
 template <int NTN, int MTN>
@@ -60,6 +73,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int ti = wave;                                   // transform row i owned by this wave (xi = 4i .. 4i+3)
+    WINO_STAMP(0);
+#ifdef REFID_WINO_TRACE
+    if (g_wino_trace && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wino_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
 
     // XCD-aware work mapping: workgroup b runs on XCD b % 8 (observed dispatch order; used for L2
     // affinity only).  The ncot channel tiles of one pixel tile are consecutive on the SAME XCD, so
@@ -203,11 +225,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         if (kc0 + 1 < kc1) load_raw(kc0 + 1);
     }
     __syncthreads();
+    WINO_STAMP(1);
 
     for (int ch = kc0; ch < kc1; ch += 2) {
         phase(ch, ufA, ufB);
         if (ch + 1 < kc1) phase(ch + 1, ufB, ufA);
     }
+    WINO_STAMP(2);
 
     // ---- output transform --------------------------------------------------------------------------
     // lane: tile li, channels (r&3)+8(r>>2)+4kh of a 32-channel tile;  acc[j][t] = M[i][j]
@@ -250,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
         }
     }
     __syncthreads();
+    WINO_STAMP(3);
 
     // ---- fused epilogue, COALESCED: thread -> (output pixel, channel quad) in memory order, so bias / residual /
     // mask loads and the store are contiguous 1 KB per wave instruction (the MFMA D layout would scatter 16-byte
@@ -309,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
             }
         }
     }
+    WINO_STAMP(4);
 }
 
 // out = mask( post( pre( sum_s ws[s] + bias ) + res ) ) for the split-K partial outputs (channels padded to 4 in ws)
@@ -380,6 +406,12 @@ WinoPlan wino_plan(ConvKArgs& a, int split_mode) {
     return p;
 }
 }  // namespace
+
+#ifdef REFID_WINO_TRACE
+extern "C" int refid_wino_trace_set(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 size_t refid_wino3x3_workspace_bytes(const ConvKArgs& ka, int split_mode) {
     ConvKArgs a = ka;

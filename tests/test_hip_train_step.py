@@ -90,7 +90,8 @@ def test_eval_step_chunks_and_checkpoint_roundtrip(tmp_path):
 
 def test_save_and_resume_training_state(tmp_path):
     """save(epoch, iter) (twoImage_event_recurrent_model.py:552-554) + resume_training (base_model.py:308-323): a run
-    resumed from the saved network + state continues bit-identically."""
+    resumed from the saved network + state continues on the same trajectory (the LayerNorm / depthwise parameter
+    gradients are accumulated with atomics, so two runs agree to rounding, not bit for bit)."""
     from refid_amd.train import TwoImageEventRecurrentRestorationModel
     opt = _opt(6, 8)
     opt["path"].update(models=str(tmp_path), training_states=str(tmp_path))
@@ -115,8 +116,19 @@ def test_save_and_resume_training_state(tmp_path):
         b.update_learning_rate(it)
         b.optimize_parameters(it)
     assert b.get_current_learning_rate() == a.get_current_learning_rate()
+    assert b.step_count == a.step_count == 4
     for (k, va), vb in zip(a.net_g.state_dict().items(), b.net_g.state_dict().values()):
-        assert torch.equal(va, vb), k
+        disp = (va.double().cpu() - P[k].double()).abs().max().item()
+        assert (va.double() - vb.double()).abs().max().item() <= 0.02 * disp + 1e-9, k
+    # a resume that forgets the optimizer state is NOT on that trajectory (the check above has teeth)
+    c = TwoImageEventRecurrentRestorationModel(o2)
+    c.feed_data({"lq": x, "voxel": ev, "gt": gt})
+    for it in (3, 4):
+        c.update_learning_rate(it)
+        c.optimize_parameters(it)
+    k = "pred.conv2d.weight"
+    assert (c.net_g.state_dict()[k] - a.net_g.state_dict()[k]).abs().max().item() > \
+        10 * (b.net_g.state_dict()[k] - a.net_g.state_dict()[k]).abs().max().item() + 1e-9
 
 
 def test_unsupported_training_options_raise():

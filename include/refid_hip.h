@@ -95,6 +95,10 @@ typedef struct refid_conv_desc {
                                                    partial sums + a finishing pass: 0 = never; 1 = by per-sample
                                                    geometry (a sample's bits do not depend on the batch size);
                                                    2 = by total grid size (best at 1-2 samples per GPU)        */
+    int wino_tile;                              /* algo 1 only: 0 = tile chosen by problem size (default); 1 = the
+                                                   2-waves-per-SIMD tile (4x32 px x 64 ch workgroups); 2 = the persistent
+                                                   one-wave-per-SIMD tile (8x32 px x 64 ch, 256 workgroups walking the
+                                                   tiles) whenever the geometry allows.  Same results bit for bit.  */
     float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
                                                    aligned, private to this stream until the call's work has run;
                                                    NULL: never split                                            */

@@ -18,12 +18,16 @@ struct ConvKArgs {
     int bf16;                  // bf16 MFMA operands (packed weights are bf16), fp32 everything else
     int ksplit = 1;            // Winograd tile: K (input-channel chunk) ranges per output tile, grid.y (small grids)
     long long wsStride = 0;    // floats between the partial outputs of two K ranges
+    int gridTiles = 0;         // persistent Winograd tile: number of virtual blocks (XCD-aware tile enumeration)
 };
 
 
 // conv_wino.hip
 // ws / ws_bytes: caller-provided split-K workspace (refid_wino3x3_workspace_bytes; NULL = never split)
 size_t refid_wino3x3_workspace_bytes(const ConvKArgs& a, int split_mode);
-int refid_launch_wino3x3(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, hipStream_t st);
+int refid_launch_wino3x3(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st);
+// conv_wino2.hip: persistent one-wave-per-SIMD variant for problems with >= 2 tiles per CU
+bool refid_wino3x3_p_eligible(const ConvKArgs& a, int cus);
+int refid_launch_wino3x3_p(const ConvKArgs& a, int cus, hipStream_t st);
 // conv_pw.hip
 int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st);

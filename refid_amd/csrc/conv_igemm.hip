@@ -451,7 +451,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
                         (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
                     "conv2d: tensor too large for the Winograd tile's 32-bit offsets (use algo 0)");
-        return refid_launch_wino3x3(a, d->ws, d->ws_bytes, d->wino_split, st);
+        return refid_launch_wino3x3(a, d->ws, d->ws_bytes, d->wino_split, d->wino_tile, st);
     }
     switch (f) {
         case F_3x3:

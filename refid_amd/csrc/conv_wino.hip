@@ -33,6 +33,7 @@
 //     tile with the fused 16-byte epilogue.
 #include "common.h"
 #include "conv_args.h"
+#include <cstdlib>
 
 namespace {
 
@@ -52,8 +53,17 @@ __device__ unsigned long long* g_wino_trace = nullptr;
         if (g_wino_trace && threadIdx.x == 0)                                                                \
             g_wino_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64();        \
     } while (0)
+// fine-grained: shader-clock stamps of the K-loop phases of waves 0 and 3 of ONE workgroup (g_wino_ktrace_wg)
+__device__ unsigned long long* g_wino_ktrace = nullptr;
+__device__ int g_wino_ktrace_wg = -1;
+#define WINO_KSTAMP(ch, slot)                                                                                  \
+    do {                                                                                                       \
+        if (ktrace && (threadIdx.x & 63) == 0)                                                                 \
+            g_wino_ktrace[(((threadIdx.x >> 6) * 64 + ((ch) & 63)) * 8) + (slot)] = clock64();                  \
+    } while (0)
 #else
 #define WINO_STAMP(slot) do {} while (0)
+#define WINO_KSTAMP(ch, slot) do {} while (0)
 #endif
 
 // <NTN, MTN>: a wave's second dimension is either two 32-channel column tiles (NTN = 2: workgroup tile
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 
     f32x4 rr[R_ITEMS], ufA[4 * NTN], ufB[4 * NTN];
 
-    auto load_raw = [&](int ch) {
+    auto load_raw = [&](int ch, f32x4 (&rr)[R_ITEMS]) {
         const int c0 = ch * KC;                            // chunk-uniform: Ca % 8 == 0 for two sources
         const bool fromA = c0 < a.Ca;
         const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
             rr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
         }
     };
-    auto store_raw = [&](int buf) {
+    auto store_raw = [&](int buf, const f32x4 (&rr)[R_ITEMS]) {
 #pragma unroll
         for (int it = 0; it < R_ITEMS; ++it) {
             const int hp = (tid >> 1) + it * 128;
@@ -178,17 +188,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
     const int offP = hp0 + rowP * HWD, offM = hp0 + rowM * HWD;
 
     // one K chunk: cur = this chunk's U fragments, nxt = register set the next chunk's are prefetched into
+#ifdef REFID_WINO_TRACE
+    const bool ktrace = g_wino_ktrace && (int)blockIdx.x == g_wino_ktrace_wg;
+#endif
     auto phase = [&](int ch, f32x4 (&cur)[4 * NTN], f32x4 (&nxt)[4 * NTN]) {
         const bool more = ch + 1 < kc1;
+        WINO_KSTAMP(ch, 0);
         // Everything still in flight was issued one phase ago and is needed NOW (U(ch) by the MFMAs, raw(ch+1) by
         // store_raw).  Stating that as an explicit vmcnt(0) keeps the compiler's conservative, path-merged counters
         // from draining THIS phase's prefetches inside the MFMA section.  simm16: vmcnt 0, expcnt 7, lgkmcnt 15.
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        WINO_KSTAMP(ch, 1);
         if (more) {
-            store_raw((ch + 1) & 1);                 // raw(ch+1): loaded one phase ago
+            store_raw((ch + 1) & 1, rr);             // raw(ch+1): loaded one phase ago
             load_u(ch + 1, nxt);
-            if (ch + 2 < kc1) load_raw(ch + 2);
+            if (ch + 2 < kc1) load_raw(ch + 2, rr);
         }
+        WINO_KSTAMP(ch, 2);
         // Measured on gfx950 (tools/probes/mfma_valu_overlap.hip): every VALU instruction costs ~2.3 and every
         // ds_read_b128 ~28 cycles of matrix-pipe time, from either wave of the SIMD -- they do not hide under
         // MFMAs.  So a wave transforms only ITS row of B^T d B (8 reads, 32 VALU per pixel tile) and reuses it for
@@ -214,15 +230,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
                             cur[j * NTN + nt][kk], v[j][kk], acc[j][NTN == 2 ? nt : mt], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
+        WINO_KSTAMP(ch, 3);
         __syncthreads();                             // raw(ch) consumed by every wave; raw(ch+1) visible
+        WINO_KSTAMP(ch, 4);
     };
 
-    // prologue: raw(0) -> LDS, U(0) -> regs; raw(1) in flight
+    // prologue: raw(0) -> LDS, U(0) -> regs; raw(1) in flight.  All three requests go out back to back (ONE memory
+    // latency up front instead of two: the accumulators are not live yet, a second staging set costs nothing here)
     if (kc0 < kc1) {
-        load_raw(kc0);
+        f32x4 rr0[R_ITEMS];
+        load_raw(kc0, rr0);
+        if (kc0 + 1 < kc1) load_raw(kc0 + 1, rr);
         load_u(kc0, ufA);
-        store_raw(0);
-        if (kc0 + 1 < kc1) load_raw(kc0 + 1);
+        store_raw(0, rr0);
     }
     __syncthreads();
     WINO_STAMP(1);
@@ -411,6 +431,10 @@ WinoPlan wino_plan(ConvKArgs& a, int split_mode) {
 extern "C" int refid_wino_trace_set(unsigned long long* buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_wino_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }
+extern "C" int refid_wino_ktrace_set(unsigned long long* buf, int wg) {
+    return (hipMemcpyToSymbol(HIP_SYMBOL(g_wino_ktrace), &buf, sizeof(buf)) == hipSuccess &&
+            hipMemcpyToSymbol(HIP_SYMBOL(g_wino_ktrace_wg), &wg, sizeof(wg)) == hipSuccess) ? 0 : 1;
+}
 #endif
 
 size_t refid_wino3x3_workspace_bytes(const ConvKArgs& ka, int split_mode) {
@@ -420,8 +444,29 @@ size_t refid_wino3x3_workspace_bytes(const ConvKArgs& ka, int split_mode) {
     return (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float);
 }
 
-int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, hipStream_t st) {
+namespace {
+// CU count per device (persistent-tile grid size); 0 = query failed -> the persistent tile is not used
+int device_cus() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 0;
+    int c = cus[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) c = -1;
+        cus[dev].store(c, std::memory_order_relaxed);
+    }
+    return c > 0 ? c : 0;
+}
+}  // namespace
+
+int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
     ConvKArgs a = ka;
+    // tile_hint (refid_conv_desc.wino_tile): 0 = choose by problem size, 1 = the 2-waves-per-SIMD tile, 2 = the
+    // persistent one-wave-per-SIMD tile whenever the geometry allows it (both produce the same bits)
+    if (tile_hint != 1 && a.vecOK && a.Cout % 4 == 0) {
+        const int cus = device_cus();
+        if (cus > 0 && refid_wino3x3_p_eligible(a, tile_hint == 2 ? 0 : cus)) return refid_launch_wino3x3_p(a, cus, st);
+    }
     // no workspace from the caller = no split (still correct, one K loop per workgroup)
     const WinoPlan pl = wino_plan(a, ws ? split_mode : 0);
     const bool narrow = a.Cout <= 32;

@@ -18,6 +18,9 @@ ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_F
 # Winograd split-K policy (refid_conv_desc.wino_split): REFID_WINO_SPLITK = sample (default) | auto | 0
 WINO_SPLIT = {"0": 0, "a": 2}.get(os.environ.get("REFID_WINO_SPLITK", "sample")[:1], 1)
 
+# Winograd tile selection (refid_conv_desc.wino_tile): 0 = by problem size, 1 = 2-waves tile, 2 = persistent tile
+WINO_TILE = int(os.environ.get("REFID_WINO_TILE", "0"))
+
 # bench.py's roofline leg: when PROFILE is a list, conv2d()/conv2d_wgrad() bracket each launch with
 # events on the launch stream and append (kernel, algorithmic_flops, start_event, end_event).
 PROFILE = None
@@ -128,6 +131,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.kh, d.kw, d.stride, d.pad, d.mode = kh, kw, stride, pad, mode
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
     d.algo = algo
+    d.wino_tile = WINO_TILE
     if algo == 1 and WINO_SPLIT:
         d.wino_split = WINO_SPLIT
         need = lib().refid_conv_workspace_bytes(C.byref(d))

@@ -24,11 +24,15 @@ def build():
     from refid_amd.build import FLAGS, HIPCC, build as build_main
     build_main()
     os.makedirs(BIN, exist_ok=True)
-    obj = os.path.join(BIN, "conv_wino_trace.o")
-    subprocess.check_call([HIPCC] + FLAGS + ["-DREFID_WINO_TRACE", "-I", os.path.join(ROOT, "refid_amd", "csrc"),
-                                             "-c", KERNEL, "-o", obj])
-    objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "refid_amd", "csrc", "*.o"))) if not o.endswith("conv_wino.o")]
-    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, obj] + objs)
+    traced = []
+    for src in ("conv_wino", "conv_wino2"):
+        obj = os.path.join(BIN, src + "_trace.o")
+        subprocess.check_call([HIPCC] + FLAGS + ["-DREFID_WINO_TRACE", "-I", os.path.join(ROOT, "refid_amd", "csrc"),
+                                                 "-c", os.path.join(ROOT, "refid_amd", "csrc", src + ".hip"), "-o", obj])
+        traced.append(obj)
+    objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "refid_amd", "csrc", "*.o")))
+            if os.path.basename(o) not in ("conv_wino.o", "conv_wino2.o")]
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + traced + objs)
     print("built", LIB)
 
 
@@ -38,6 +42,7 @@ def main():
     from refid_amd import _lib
     _lib.LIB_PATH = LIB
     from refid_amd import ops
+    ops.WINO_TILE = 1                       # the traced kernel is the 2-waves tile
     L = _lib.lib()
     L.refid_wino_trace_set.argtypes = [C.c_void_p]
     B = int(os.environ.get("B", 8))
@@ -98,10 +103,78 @@ def main():
         print(f"  CU busy time split by #workgroups in their K loop: 0: {in_loop[0] / busy:.2f}  1: {in_loop[1] / busy:.2f}  "
               f"2: {in_loop[2] / busy:.2f};  end -> next start on the CU: {np.mean(gaps):.2f} us (p90 {np.percentile(gaps, 90):.2f})")
         print(f"  kernel span by stamps: {us(float(t[:, 4].max() - t0)):.1f} us")
+        # fine-grained: K-loop phases of one mid-kernel workgroup (shader cycles)
+        nchunks = Ci // 8
+        kb = torch.zeros(4 * 64 * 8, dtype=torch.int64, device="cuda")
+        L.refid_wino_ktrace_set.argtypes = [C.c_void_p, C.c_int]
+        for wg in (len(t) // 2 + 3, len(t) // 2 + 700):
+            kb.zero_()
+            L.refid_wino_ktrace_set(C.c_void_p(kb.data_ptr()), wg)
+            run()
+            torch.cuda.synchronize()
+            k = kb.view(4, 64, 8).cpu().numpy()
+            L.refid_wino_ktrace_set(None, -1)
+            for w in (0, 3):
+                rows = k[w, :min(nchunks, 64)]
+                wait = rows[:, 1] - rows[:, 0]; issue = rows[:, 2] - rows[:, 1]; mfma = rows[:, 3] - rows[:, 2]; bar = rows[:, 4] - rows[:, 3]
+                gap = rows[1:, 0] - rows[:-1, 4]
+                print(f"  wg {wg} wave {w}: per chunk cycles  vmcnt-wait {wait.mean():.0f}  issue(ds_write+loads) {issue.mean():.0f}  "
+                      f"lds+valu+mfma {mfma.mean():.0f}  barrier {bar.mean():.0f}  between-phases {gap.mean():.0f}  | chunk total "
+                      f"{(rows[-1, 4] - rows[0, 0]) / len(rows):.0f}  (32 MFMAs = 2048)")
+                print("     first chunks (wait, issue, mfma, barrier): " + "  ".join(
+                    f"({a},{b},{c},{d})" for a, b, c, d in zip(wait[:6], issue[:6], mfma[:6], bar[:6])))
+
+
+def persistent():
+    """K-loop phase accounting of the persistent one-wave-per-SIMD tile (exact: the wave is alone on its SIMD)."""
+    import numpy as np
+    import torch
+    from refid_amd import _lib
+    _lib.LIB_PATH = LIB
+    from refid_amd import ops
+    ops.WINO_TILE = 2
+    L = _lib.lib()
+    L.refid_wino2_ktrace_set.argtypes = [C.c_void_p, C.c_int]
+    B = 8
+    for name, H, Ca, Cb, Co in [("L0 res 64->64 @256", 256, 64, 0, 64), ("L1 res 128->128 @128", 128, 128, 0, 128),
+                                ("L2 main.0 512->256 @64", 64, 256, 256, 256)]:
+        Ci = Ca + Cb
+        a = torch.randn(B, H, H, Ca, device="cuda")
+        b = torch.randn(B, H, H, Cb, device="cuda") if Cb else None
+        w = torch.randn(Co, Ci, 3, 3, device="cuda") * 0.05
+        res = torch.randn(B, H, H, Co, device="cuda")
+        out = torch.empty(B, H, H, Co, device="cuda")
+        bias = torch.randn(Co, device="cuda")
+        ww = ops.pack_conv_weights(w, ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+        run = lambda: ops.conv2d(a, ww, out, kh=3, kw=3, pad=1, cout=Co, cout_pad=-(-Co // 64) * 64, in_b=b, bias=bias,  # noqa: E731
+                                 res=res, slope_pre=0.1, algo=1)
+        for _ in range(3):
+            run()
+        kb = torch.zeros(4 * 64 * 8, dtype=torch.int64, device="cuda")
+        nchunks = min(Ci // 8, 64)
+        print(f"\n{name} (persistent tile, second tile of the workgroup; clock64 ticks)")
+        for wg in (17, 130):
+            kb.zero_()
+            L.refid_wino2_ktrace_set(C.c_void_p(kb.data_ptr()), wg)
+            run()
+            torch.cuda.synchronize()
+            L.refid_wino2_ktrace_set(None, -1)
+            k = kb.view(4, 64, 8).cpu().numpy()
+            for wv in (0, 3):
+                r = k[wv, :nchunks]
+                names = ("vmcnt-wait", "ds_write+load issue", "block0 (32 MFMA + reads/V of block1)", "barrier",
+                         "block1 (32 MFMA + reads/V of next chunk)")
+                d = [r[:, i + 1] - r[:, i] for i in range(5)]
+                gap = r[1:, 0] - r[:-1, 5]
+                tot = (r[-1, 5] - r[0, 0]) / len(r)
+                print(f"  wg {wg} wave {wv}: " + "  ".join(f"{n} {x[1:-1].mean():.0f}" for n, x in zip(names, d)) +
+                      f"  between {gap.mean():.0f}  | chunk {tot:.0f} ticks (64 MFMAs = 4096 cycles)")
 
 
 if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
+    elif "--persistent" in sys.argv:
+        persistent()
     else:
         main()

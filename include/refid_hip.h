@@ -267,6 +267,13 @@ int refid_clip_adamw(float* p, const float* g, float* m, float* v, const double*
                      float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay,
                      int step, long long count, void* stream);
 
+/* The same step with the per-iteration scalars in DEVICE memory: hyper[0] = lr, hyper[1] = 1 - beta1^t,
+ * hyper[2] = sqrt(1 - beta2^t).  A train step captured in a hipGraph is replayed with different lr / t every
+ * iteration; kernel arguments are frozen at capture time, device memory is not. */
+int refid_clip_adamw_dev(float* p, const float* g, float* m, float* v, const double* sqnorm, float max_norm,
+                         float grad_scale, const float* hyper, float beta1, float beta2, float eps,
+                         float weight_decay, long long count, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Layout / elementwise helpers on the boundary.
  * ---------------------------------------------------------------------------------- */

@@ -116,6 +116,7 @@ def _bind_extra(L):
     L.refid_charbonnier.argtypes = [vp, vp, vp, vp, ll, f, f, vp]
     L.refid_grad_sqnorm.argtypes = [vp, vp, ll, vp]
     L.refid_clip_adamw.argtypes = [vp, vp, vp, vp, vp, f, f, f, f, f, f, f, i, ll, vp]
+    L.refid_clip_adamw_dev.argtypes = [vp, vp, vp, vp, vp, f, f, vp, f, f, f, f, ll, vp]
     d = C.c_double
     L.refid_events_to_voxel.argtypes = [vp, vp, vp, vp, ll, i, i, i, d, d, vp, vp]
     L.refid_sqerr_u8.argtypes = [vp, vp, i, ll, vp, vp]

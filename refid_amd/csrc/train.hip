@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256) void clip_adamw_kernel(f32x4* __restrict__ p, 
                                                         f32x4* __restrict__ m, f32x4* __restrict__ v,
                                                         const double* __restrict__ sqnorm, float max_norm,
                                                         float gscale, float lr, float b1, float b2, float eps,
-                                                        float wd, float bc1, float bc2_sqrt, long long n4) {
+                                                        float wd, float bc1, float bc2_sqrt, long long n4,
+                                                        const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }     // per-step scalars of a replayed hipGraph
     float coef = 1.f;
     if (max_norm > 0.f) {
         const float norm = (float)sqrt(*sqnorm) * gscale;
@@ -133,7 +135,19 @@ extern "C" int refid_clip_adamw(float* p, const float* g, float* m, float* v, co
     const double bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblocks(count / 4)), dim3(256), 0, (hipStream_t)stream, (f32x4*)p,
                        (const f32x4*)g, (f32x4*)m, (f32x4*)v, sqnorm, max_norm, grad_scale, lr, beta1, beta2, eps,
-                       weight_decay, (float)bc1, (float)sqrt(bc2), count / 4);
+                       weight_decay, (float)bc1, (float)sqrt(bc2), count / 4, (const float*)nullptr);
     REFID_LAUNCH_CHECK("clip_adamw");
+    return 0;
+}
+
+extern "C" int refid_clip_adamw_dev(float* p, const float* g, float* m, float* v, const double* sqnorm, float max_norm,
+                                    float grad_scale, const float* hyper, float beta1, float beta2, float eps,
+                                    float weight_decay, long long count, void* stream) {
+    REFID_CHECK(p && g && m && v && hyper && count > 0 && count % 4 == 0, "clip_adamw_dev: bad arguments");
+    REFID_CHECK(max_norm <= 0.f || sqnorm != nullptr, "clip_adamw_dev: clipping needs the squared norm");
+    hipLaunchKernelGGL(clip_adamw_kernel, dim3(nblocks(count / 4)), dim3(256), 0, (hipStream_t)stream, (f32x4*)p,
+                       (const f32x4*)g, (f32x4*)m, (f32x4*)v, sqnorm, max_norm, grad_scale, 0.f, beta1, beta2, eps,
+                       weight_decay, 1.f, 1.f, count / 4, hyper);
+    REFID_LAUNCH_CHECK("clip_adamw_dev");
     return 0;
 }

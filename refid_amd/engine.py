@@ -736,6 +736,18 @@ class Engine:
         Parameter gradients are ACCUMULATED into the arena (call zero_grad() first).
         grad_sync(phase): optional hook, called with "early" once the forward-sweep / decoder /
         bottleneck / pred gradients are final (overlaps the rest of BPTT) and with "late" at the end."""
+        st = self.backward_early(gout)
+        if grad_sync is not None:
+            grad_sync("early")
+        self.backward_late(st)
+        if grad_sync is not None:
+            grad_sync("late")
+
+    def backward_early(self, gout):
+        """First half of BPTT (the forward sweep, walked t = T-1 .. 0): afterwards the gradients of the forward-sweep
+        encoders, bottleneck, decoders and pred are final.  Returns the state backward_late() continues from.  (Two
+        halves so that a data-parallel job can start its first all-reduce in between -- and so that each half can be
+        captured in its own hipGraph with the collective issued eagerly between the replays.)"""
         c = self.ctx
         if c is None:
             raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
@@ -808,9 +820,12 @@ class Engine:
             o.finish_wgrad()
         WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_f[1].att)
-        if grad_sync is not None:
-            grad_sync("early")
+        return dict(c=c, B=B, dev=dev, g_xb=g_xb, g_Sb=g_Sb, g_e=g_e, g_head=g_head)
 
+    def backward_late(self, state):
+        """Second half of BPTT: the backward sweep (walked t = 0 .. T-1), event head and image branch."""
+        c, B, dev, g_xb, g_Sb, g_e, g_head = (state[k] for k in ("c", "B", "dev", "g_xb", "g_Sb", "g_e", "g_head"))
+        xb, head, e_all = c["xb"], c["head"], c["e_all"]
         # ---------------- backward sweep (executed t = T-1..0), BPTT in reverse: t = 0 .. T-1 ----
         g_hb = [None, None, None]
         for t, sts in reversed(c["steps_b"]):
@@ -851,8 +866,6 @@ class Engine:
             o.finish_wgrad()
         WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_b[1].att)
-        if grad_sync is not None:
-            grad_sync("late")
 
     def _evr_first_bwd(self, L, g_s, st, g_h, g_xb, g_e, t, B, ip, g_skip, first_writer):
         """Trunk + first op of an EvR level; returns the gradient w.r.t. the level's input

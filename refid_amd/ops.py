@@ -465,6 +465,14 @@ def clip_adamw(p, g, m, v, sqnorm, *, max_norm, lr, betas, eps, weight_decay, st
           "refid_clip_adamw")
 
 
+def clip_adamw_dev(p, g, m, v, sqnorm, hyper, *, max_norm, betas, eps, weight_decay, grad_scale=1.0):
+    """clip_adamw with (lr, 1 - beta1^t, sqrt(1 - beta2^t)) read from the 3-float device tensor `hyper`."""
+    check(lib().refid_clip_adamw_dev(_c(p, "p"), _c(g, "g"), _c(m, "m"), _c(v, "v"),
+                                     sqnorm.data_ptr() if sqnorm is not None else None, max_norm, grad_scale,
+                                     _c(hyper, "hyper"), betas[0], betas[1], eps, weight_decay, p.numel(), _stream()),
+          "refid_clip_adamw_dev")
+
+
 # ---------------------------------------------------------------------------------------------
 # SingleMultiConnectEVHINet non-GEMM pieces (csrc/evhinet.hip)
 # ---------------------------------------------------------------------------------------------

@@ -139,7 +139,119 @@ class TwoImageEventRecurrentRestorationModel:
             self.gt = data["gt"].to(self.device, non_blocking=True)
 
     # ---- S2: one optimisation step ----------------------------------------------------------------
+    # ---- hipGraph replay of the step (MI355X: ~5000 kernel launches per step; at 1-2 samples per GPU the Python /
+    # ctypes enqueue is as long as the GPU work, and 8 ranks contend for the host cores) -----------------------------
+    def set_graph_mode(self, on):
+        """on: capture the whole train step (zero_grad .. AdamW) into hipGraphs at the next optimize_parameters() and
+        replay it afterwards -- one graph on a single GPU; three graphs (forward + forward-sweep BPTT | backward-sweep
+        BPTT | clip + AdamW) with the two RCCL all-reduce phases issued eagerly in between when data-parallel.  The
+        captured step is re-captured when the input shapes change.  off: eager launches (the default)."""
+        on = bool(on)
+        if on and not hasattr(self.net_g.engine, "backward_early"):
+            raise NotImplementedError("graph mode is implemented for FinalBidirectionAttenfusion's engine only")
+        if on != getattr(self, "graph_on", False) or not on:
+            self._graph = None                     # drops the captured graphs and their private memory pool
+        self.graph_on = on
+
+    def _graph_capture(self):
+        eng = self.net_g.engine
+        dev = self.device
+        g = dict(key=(tuple(self.lq.shape), tuple(self.voxel.shape), tuple(self.gt.shape)))
+        g["lq"], g["voxel"], g["gt"] = (torch.empty_like(t, device=dev).copy_(t) for t in (self.lq, self.voxel, self.gt))
+        g["hyper"] = torch.zeros(4, dtype=torch.float32, device=dev)
+        # per-step scalars travel through a small ring of pinned buffers (the host may run several replays ahead of the
+        # GPU; a slot is rewritten only after the copy that last read it has executed)
+        g["hyper_host"] = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(8)]
+        g["hyper_evt"] = [None] * 8
+        max_norm = 0.01 if self.use_grad_clip else 0.0
+        # warm-up WITHOUT a parameter update: every lazily created resource (kernel attributes, split-K / weight-
+        # gradient slabs, side stream) exists before capture; nothing may allocate with hipMalloc or synchronise inside
+        eng.zero_grad()
+        pred = eng.forward(g["lq"], g["voxel"], save=True)
+        saved, self.gt = self.gt, g["gt"]
+        try:
+            gpred, _, _ = self._loss_and_grad(pred)
+            eng.backward(gpred)
+            torch.cuda.synchronize()
+            del pred, gpred
+            graphs = []
+
+            def seg(fn, pool):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, pool=pool):
+                    out = fn()
+                graphs.append(gr)
+                return out
+
+            def part1():
+                eng.mark_params_changed()                        # the weights change every step: repack is part of the graph
+                eng.zero_grad()
+                pred = eng.forward(g["lq"], g["voxel"], save=True)
+                gpred, loss_sum, n = self._loss_and_grad(pred)
+                return pred, loss_sum, n, eng.backward_early(gpred)
+
+            def part3():
+                if max_norm > 0:
+                    ops.grad_sqnorm(eng.arena.flat_g, out=self.sqnorm)
+                ops.clip_adamw_dev(eng.arena.flat_p, eng.arena.flat_g, self.exp_avg, self.exp_avg_sq, self.sqnorm,
+                                   g["hyper"], max_norm=max_norm, betas=self.betas, eps=self.adam_eps,
+                                   weight_decay=self.weight_decay, grad_scale=1.0 / self.world)
+
+            if self.dist_on:
+                g["pred"], g["loss_sum"], g["n"], state = seg(part1, None)
+                pool = graphs[0].pool()
+                seg(lambda: eng.backward_late(state), pool)
+                seg(part3, pool)
+            else:
+                def whole():
+                    pred, loss_sum, n, state = part1()
+                    eng.backward_late(state)
+                    part3()
+                    return pred, loss_sum, n
+                g["pred"], g["loss_sum"], g["n"] = seg(whole, None)
+            state = None
+        finally:
+            self.gt = saved
+        g["graphs"] = graphs
+        return g
+
+    def _step_graph(self):
+        g = getattr(self, "_graph", None)
+        key = (tuple(self.lq.shape), tuple(self.voxel.shape), tuple(self.gt.shape))
+        if g is None or g["key"] != key:
+            self._graph = None
+            g = self._graph = self._graph_capture()
+        else:
+            g["lq"].copy_(self.lq, non_blocking=True)
+            g["voxel"].copy_(self.voxel, non_blocking=True)
+            g["gt"].copy_(self.gt, non_blocking=True)
+        self.step_count += 1
+        slot = self.step_count % len(g["hyper_host"])
+        if g["hyper_evt"][slot] is not None:
+            g["hyper_evt"][slot].synchronize()
+        h = g["hyper_host"][slot]
+        h[0] = self.cur_lr
+        h[1] = 1.0 - self.betas[0] ** self.step_count
+        h[2] = math.sqrt(1.0 - self.betas[1] ** self.step_count)
+        g["hyper"].copy_(h, non_blocking=True)
+        g["hyper_evt"][slot] = torch.cuda.Event()
+        g["hyper_evt"][slot].record()
+        gr = g["graphs"]
+        gr[0].replay()
+        if self.dist_on:
+            self.grad_sync("early")
+            gr[1].replay()
+            self.grad_sync("late")
+            gr[2].replay()
+            torch.distributed.all_reduce(g["loss_sum"])
+        self.net_g.engine.mark_params_changed()
+        self.output = g["pred"]
+        self._loss_sum, self._loss_n = g["loss_sum"], g["n"]
+        self.log_dict = None
+
     def optimize_parameters(self, current_iter):
+        if getattr(self, "graph_on", False):
+            return self._step_graph()
         eng = self.net_g.engine
         eng.zero_grad()                                          # optimizer_g.zero_grad()
         pred = eng.forward(self.lq, self.voxel, save=True)       # net_g(x=lq, event=voxel)

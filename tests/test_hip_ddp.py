@@ -29,7 +29,7 @@ def _opt(img_chn, base):
     }
 
 
-def _worker(rank, world, port, ret, backend="gloo"):
+def _worker(rank, world, port, ret, backend="gloo", graph=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     if backend == "nccl":
@@ -44,6 +44,7 @@ def _worker(rank, world, port, ret, backend="gloo"):
     model.net_g.load_state_dict(P)
     torch.distributed.broadcast(model.net_g.engine.arena.flat_p, src=0)        # ... rank 0 wins (DDP semantics)
     model.net_g.notify_params_changed()
+    model.set_graph_mode(graph)
     x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
     mine = shard_batch(2, rank, world)
     for it in (1, 2):
@@ -137,6 +138,28 @@ def test_two_rank_step_equals_single_rank_on_the_full_batch():
         a, b = sd[k].double().cpu(), sd0[k].double()
         disp = (a - P[k].double()).abs().max().item()
         assert (a - b).abs().max().item() <= 0.02 * disp + 1e-9, k
+
+
+def test_graph_mode_two_ranks_three_segments():
+    """Data-parallel graph mode: forward + forward-sweep BPTT | backward-sweep BPTT | clip + AdamW are three hipGraphs
+    sharing one memory pool, the early / late all-reduces run eagerly between the replays.  Two gloo ranks sharing the
+    GPU == the eager two-rank run."""
+    rets = []
+    for graph in (False, True):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        ret = ctx.Manager().dict()
+        mp.spawn(_worker, args=(2, port, ret, "gloo", graph), nprocs=2, join=True)
+        rets.append((ret[0], ret[1]))
+    (e0, e1), (g0, g1) = rets
+    assert g0[0] == g1[0] and g0[1] == g1[1]
+    for k in g0[2]:
+        assert torch.equal(g0[2][k], g1[2][k]), k              # replicas agree bit for bit in graph mode too
+    assert abs(g0[0] - e0[0]) < 1e-6 and abs(g0[1] - e0[1]) < 1e-4 * e0[1]
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    for k in g0[2]:
+        disp = (e0[2][k].double() - P[k].double()).abs().max().item()
+        assert (g0[2][k].double() - e0[2][k].double()).abs().max().item() <= 0.02 * disp + 1e-9, k
 
 
 def test_one_rank_rccl_group_runs_the_same_collectives():

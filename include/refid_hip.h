@@ -91,20 +91,21 @@ typedef struct refid_conv_desc {
                                                    2 = direct tile with bf16 MFMA operands (fp32
                                                    accumulate/epilogue/tensors; w_packed from
                                                    refid_pack_conv_weights_bf16 with kc doubled)   */
-    int wino_split;                             /* algo 1 only: split K over the grid for small problems into `ws`
-                                                   partial sums + a finishing pass: 0 = never; 1 = by per-sample
-                                                   geometry (a sample's bits do not depend on the batch size);
-                                                   2 = by total grid size (best at 1-2 samples per GPU)        */
-    int wino_tile;                              /* algo 1 only: 0 = tile chosen by problem size (default); 1 = the
-                                                   2-waves-per-SIMD tile (4x32 px x 64 ch workgroups); 2 = the persistent
-                                                   one-wave-per-SIMD tile (8x32 px x 64 ch, 256 workgroups walking the
-                                                   tiles) whenever the geometry allows.  Same results bit for bit.  */
+    int split_k;                                /* small problems (few output tiles, long K): split K over the grid into
+                                                   `ws` partial sums + a finishing pass.  0 = never; 1 = decided by the
+                                                   per-sample geometry (a sample's bits do not depend on the batch
+                                                   size); 2 = decided by the total grid size (best at 1-2 samples per
+                                                   GPU).  Used by algo 1 and by algo 0's 4x4/s2 tiles (mode 0 and 2).  */
+    int wino_tile;                              /* algo 1 only: 0 / 1 = the 2-waves-per-SIMD tile (4x32 px x 64 ch
+                                                   workgroups; the default); 2 = the persistent one-wave-per-SIMD tile
+                                                   (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
+                                                   geometry allows.  Same results bit for bit; 2 measured slower.     */
     float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
                                                    aligned, private to this stream until the call's work has run;
                                                    NULL: never split                                            */
 } refid_conv_desc;
 
-/* Scratch bytes refid_conv2d(d) wants in d->ws (0 = none); depends on the geometry fields and wino_split only. */
+/* Scratch bytes refid_conv2d(d) wants in d->ws (0 = none); depends on the geometry fields and split_k only. */
 size_t refid_conv_workspace_bytes(const refid_conv_desc* d);
 int refid_conv2d(const refid_conv_desc* d, void* stream);
 

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("mode", C.c_int),
         ("slope_pre", C.c_float), ("slope_post", C.c_float), ("slope_mask", C.c_float),
         ("algo", C.c_int),
-        ("wino_split", C.c_int), ("wino_tile", C.c_int),
+        ("split_k", C.c_int), ("wino_tile", C.c_int),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
     ]
 

@@ -26,6 +26,7 @@ struct ConvKArgs {
 // ws / ws_bytes: caller-provided split-K workspace (refid_wino3x3_workspace_bytes; NULL = never split)
 size_t refid_wino3x3_workspace_bytes(const ConvKArgs& a, int split_mode);
 int refid_launch_wino3x3(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st);
+int refid_launch_splitk_finish(const ConvKArgs& f, const float* ws, int ldW, long long npix, hipStream_t st);
 // conv_wino2.hip: persistent one-wave-per-SIMD variant for problems with >= 2 tiles per CU
 bool refid_wino3x3_p_eligible(const ConvKArgs& a, int cus);
 int refid_launch_wino3x3_p(const ConvKArgs& a, int cus, hipStream_t st);

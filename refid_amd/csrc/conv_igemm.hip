@@ -78,7 +78,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     const int wm = wave / C::WN, wn = wave % C::WN;
     const int li = lane & 31, kh = lane >> 5;
 
-    int bt = blockIdx.x;
+    // split-K (small grids): blockIdx.x = tile * ksplit + part; part reduces K chunks [kc0, kc1) into a raw partial output
+    const int kpart = blockIdx.x % a.ksplit;
+    const int kper = (a.nchunks + a.ksplit - 1) / a.ksplit;
+    const int kc0 = kpart * kper, kc1 = min(a.nchunks, kc0 + kper);
+    int bt = blockIdx.x / a.ksplit;
     const int tx = bt % a.tilesX; bt /= a.tilesX;
     const int ty = bt % a.tilesY;
     const int n = bt / a.tilesY;
@@ -184,12 +188,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
     const int bcol = wn * C::NT * 32 + li;
 
-    load_chunk(0);
-    store_chunk();
+    if (kc0 < kc1) {
+        load_chunk(kc0);
+        store_chunk();
+    }
     __syncthreads();
 
-    for (int ch = 0; ch < a.nchunks; ++ch) {
-        const bool more = ch + 1 < a.nchunks;
+    for (int ch = kc0; ch < kc1; ++ch) {
+        const bool more = ch + 1 < kc1;
         if (more) load_chunk(ch + 1);
 
 #pragma unroll
@@ -264,6 +270,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 if (C::MODE == 0) op = (long long)(n * OH + oy) * OW + ox;
                 else op = (long long)(n * OH + 2 * oy + sy) * OW + 2 * ox + sx;
                 f32x4 v;
+                if (a.ksplit > 1) {          // raw partial sums (workspace in the OUTPUT's pixel / channel coordinates)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[m][nn][4 * g + k];
+                    *reinterpret_cast<f32x4*>(a.out + kpart * a.wsStride + op * a.ldO + ch) = v;
+                    continue;
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = lrelu(acc[m][nn][4 * g + k] + bv[k], a.slopePre);
                 if (vec) {
@@ -292,23 +304,69 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
 }
 
+// split-K plan of the direct tile: only the long-K / few-tile 4x4 stride-2 family (conv_down forward and its input
+// gradient) uses it; same policy values as the Winograd tile (refid_conv_desc.split_k)
+struct SplitArgs { float* ws; size_t ws_bytes; int mode; };
+
+template <class C>
+int igemm_ksplit(const ConvKArgs& a, int ncls, int split_mode, bool bf) {
+    if (!split_mode || !(C::MODE == 0 || C::MODE == 2) || !a.vecOK || a.Cout % 4) return 1;
+    const int tiles1 = cdiv(a.Wo, C::TW) * cdiv(a.Ho, C::TH);                  // per sample
+    const int nwg = tiles1 * (split_mode == 2 ? a.N : 8) * cdiv(a.Cout, C::BN) * ncls;
+    const int nchunks = cdiv(a.Ctot, C::KC * (bf ? 2 : 1));
+    int ks = 1;
+    if (nwg <= 128 && nchunks >= 8) {          // (one workgroup per CU already: splitting then only adds the finishing pass)
+        ks = 512 / nwg;
+        if (ks > nchunks / 4) ks = nchunks / 4;
+        if (ks > 8) ks = 8;
+        if (ks < 1) ks = 1;
+    }
+    return ks;
+}
+
+template <class C>
+size_t igemm_ws_bytes(const ConvKArgs& a, int ncls, int split_mode, bool bf) {
+    const int ks = igemm_ksplit<C>(a, ncls, split_mode, bf);
+    if (ks == 1) return 0;
+    const long long opix = (long long)a.N * a.Ho * a.Wo * (C::MODE == 2 ? 4 : 1);
+    return (size_t)ks * opix * round_up(a.Cout, 4) * sizeof(float);
+}
+
 template <class C, bool BF>
-int launch_t(const ConvKArgs& ka, int ncls, hipStream_t st) {
+int launch_t(const ConvKArgs& ka, int ncls, const SplitArgs& sp, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = refid_lds_attr_once(attr_done, &conv_igemm_kernel<C, BF>, C::LDS_BYTES, "conv")) return rc;
     ConvKArgs a = ka;
     a.tilesX = cdiv(a.Wo, C::TW);
     a.tilesY = cdiv(a.Ho, C::TH);
     a.nchunks = cdiv(a.Ctot, C::KC * (BF ? 2 : 1));
-    dim3 grid(a.tilesX * a.tilesY * a.N, cdiv(a.Cout, C::BN), ncls);
-    hipLaunchKernelGGL((conv_igemm_kernel<C, BF>), grid, dim3(256), C::LDS_BYTES, st, a);
-    REFID_LAUNCH_CHECK("conv_igemm");
-    return 0;
+    const int ks = sp.ws ? igemm_ksplit<C>(a, ncls, sp.mode, BF) : 1;
+    dim3 grid(a.tilesX * a.tilesY * a.N * ks, cdiv(a.Cout, C::BN), ncls);
+    if (ks == 1) {
+        hipLaunchKernelGGL((conv_igemm_kernel<C, BF>), grid, dim3(256), C::LDS_BYTES, st, a);
+        REFID_LAUNCH_CHECK("conv_igemm");
+        return 0;
+    }
+    const long long opix = (long long)a.N * a.Ho * a.Wo * (C::MODE == 2 ? 4 : 1);
+    const int ldW = round_up(a.Cout, 4);
+    const size_t need = (size_t)ks * opix * ldW * sizeof(float);
+    if (need > sp.ws_bytes || (reinterpret_cast<uintptr_t>(sp.ws) & 15)) {
+        refid_set_error("conv_igemm: split-K workspace too small or misaligned (%zu bytes given, %zu needed: "
+                        "refid_conv_workspace_bytes)", sp.ws_bytes, need);
+        return 1;
+    }
+    ConvKArgs p = a;                       // partial pass: raw sums into the workspace (output coordinates)
+    p.ksplit = ks; p.wsStride = opix * ldW; p.out = sp.ws; p.ldO = ldW;
+    hipLaunchKernelGGL((conv_igemm_kernel<C, BF>), grid, dim3(256), C::LDS_BYTES, st, p);
+    REFID_LAUNCH_CHECK("conv_igemm/splitk");
+    ConvKArgs f = a;
+    f.ksplit = ks; f.wsStride = opix * ldW;
+    return refid_launch_splitk_finish(f, sp.ws, ldW, opix, st);
 }
 
 template <class C>
-int launch(const ConvKArgs& ka, int ncls, hipStream_t st) {
-    return ka.bf16 ? launch_t<C, true>(ka, ncls, st) : launch_t<C, false>(ka, ncls, st);
+int launch(const ConvKArgs& ka, int ncls, hipStream_t st, const SplitArgs& sp = SplitArgs{nullptr, 0, 0}) {
+    return ka.bf16 ? launch_t<C, true>(ka, ncls, sp, st) : launch_t<C, false>(ka, ncls, sp, st);
 }
 
 // tile families: <KH,KW,S, WM,WN,MT,NT, NSUB, MODE>
@@ -379,12 +437,21 @@ extern "C" const char* refid_conv_tile_name(int kh, int kw, int stride, int mode
 }
 
 extern "C" size_t refid_conv_workspace_bytes(const refid_conv_desc* d) {
-    if (!d || d->algo != 1 || d->wino_split == 0) return 0;       // only the Winograd tile's split-K uses one
+    if (!d || d->split_k == 0) return 0;
     ConvKArgs a;
     a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
     a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
-    return refid_wino3x3_workspace_bytes(a, d->wino_split);
+    a.vecOK = 1;
+    if (d->algo == 1) return refid_wino3x3_workspace_bytes(a, d->split_k);
+    if (d->algo != 0 && d->algo != 2) return 0;
+    const bool bf = d->algo == 2;
+    const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
+    switch (family_of(d->kh, d->kw, d->stride, d->mode)) {
+        case F_4x4s2: return igemm_ws_bytes<C4S2_64>(a, 1, d->split_k, bf);
+        case F_downDgrad: return bn == 64 ? igemm_ws_bytes<CD_64>(a, 4, d->split_k, bf) : igemm_ws_bytes<CD_128>(a, 4, d->split_k, bf);
+        default: return 0;
+    }
 }
 
 extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
@@ -451,7 +518,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
                         (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
                     "conv2d: tensor too large for the Winograd tile's 32-bit offsets (use algo 0)");
-        return refid_launch_wino3x3(a, d->ws, d->ws_bytes, d->wino_split, d->wino_tile, st);
+        return refid_launch_wino3x3(a, d->ws, d->ws_bytes, d->split_k, d->wino_tile, st);
     }
     switch (f) {
         case F_3x3:
@@ -463,10 +530,13 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
             if (bn == 32) return launch<C1_32>(a, 1, st);
             if (bn == 64) return launch<C1_64>(a, 1, st);
             return launch<C1_128>(a, 1, st);
-        case F_4x4s2: return launch<C4S2_64>(a, 1, st);
+        case F_4x4s2: return launch<C4S2_64>(a, 1, st, SplitArgs{d->ws, d->ws_bytes, d->split_k});
         case F_2x2s2: return bn == 64 ? launch<C2S2_64>(a, 1, st) : launch<C2S2_128>(a, 1, st);
         case F_convT: return bn == 64 ? launch<CT_64>(a, 1, st) : launch<CT_128>(a, 1, st);
-        case F_downDgrad: return bn == 64 ? launch<CD_64>(a, 4, st) : launch<CD_128>(a, 4, st);
+        case F_downDgrad: {
+            const SplitArgs sp{d->ws, d->ws_bytes, d->split_k};
+            return bn == 64 ? launch<CD_64>(a, 4, st, sp) : launch<CD_128>(a, 4, st, sp);
+        }
         default: break;
     }
     refid_set_error("conv2d: no tile for this geometry");

@@ -444,6 +444,17 @@ size_t refid_wino3x3_workspace_bytes(const ConvKArgs& ka, int split_mode) {
     return (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float);
 }
 
+// Generic finishing pass of a split-K launch (also used by the direct tile): out = epilogue(sum_s ws[s]) over an
+// output of npix pixels x a.Cout channels (a.out / ldO / res / mask / bias describe the final tensor).
+int refid_launch_splitk_finish(const ConvKArgs& f, const float* ws, int ldW, long long npix, hipStream_t st) {
+    const long long tot4 = npix * (ldW / 4);
+    int nb = (int)((tot4 + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(wino_splitk_finish_kernel, dim3(nb), dim3(256), 0, st, f, ws, ldW, npix, ldW / 4);
+    REFID_LAUNCH_CHECK("splitk_finish");
+    return 0;
+}
+
 namespace {
 // CU count per device (persistent-tile grid size); 0 = query failed -> the persistent tile is not used
 int device_cus() {
@@ -461,11 +472,13 @@ int device_cus() {
 
 int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
     ConvKArgs a = ka;
-    // tile_hint (refid_conv_desc.wino_tile): 0 = choose by problem size, 1 = the 2-waves-per-SIMD tile, 2 = the
-    // persistent one-wave-per-SIMD tile whenever the geometry allows it (both produce the same bits)
-    if (tile_hint != 1 && a.vecOK && a.Cout % 4 == 0) {
+    // tile_hint (refid_conv_desc.wino_tile): 0 / 1 = the 2-waves-per-SIMD tile; 2 = the persistent one-wave-per-SIMD
+    // tile (conv_wino2.hip) whenever the geometry allows it.  Same bits.  The persistent tile is opt-in: measured 10-30 %
+    // slower at every config-2 shape (a lone wave per SIMD pays ~130 cycles per buffer-load issue and every LDS /
+    // barrier stall itself; two co-resident workgroups hide exactly that -- DESIGN.md, profiles/r02_wino_*).
+    if (tile_hint == 2 && a.vecOK && a.Cout % 4 == 0) {
         const int cus = device_cus();
-        if (cus > 0 && refid_wino3x3_p_eligible(a, tile_hint == 2 ? 0 : cus)) return refid_launch_wino3x3_p(a, cus, st);
+        if (cus > 0 && refid_wino3x3_p_eligible(a, 0)) return refid_launch_wino3x3_p(a, cus, st);
     }
     // no workspace from the caller = no split (still correct, one K loop per workgroup)
     const WinoPlan pl = wino_plan(a, ws ? split_mode : 0);
@@ -497,10 +510,5 @@ int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int sp
     REFID_LAUNCH_CHECK("conv_wino/splitk");
     ConvKArgs f = a;
     f.ksplit = ks; f.wsStride = npix * ldW;
-    const long long tot4 = npix * (ldW / 4);
-    int nb = (int)((tot4 + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(wino_splitk_finish_kernel, dim3(nb), dim3(256), 0, st, f, ws, ldW, npix, ldW / 4);
-    REFID_LAUNCH_CHECK("conv_wino/finish");
-    return 0;
+    return refid_launch_splitk_finish(f, ws, ldW, npix, st);
 }

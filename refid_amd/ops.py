@@ -15,8 +15,9 @@ from ._lib import ConvDesc, WgradDesc, check, lib
 ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_FWD, ROLE_WINO_DGRAD = range(7)
 
 
-# Winograd split-K policy (refid_conv_desc.wino_split): REFID_WINO_SPLITK = sample (default) | auto | 0
-WINO_SPLIT = {"0": 0, "a": 2}.get(os.environ.get("REFID_WINO_SPLITK", "sample")[:1], 1)
+# split-K policy for small grids (refid_conv_desc.split_k): REFID_SPLITK = auto (default: by total grid size) |
+# sample (by per-sample geometry: a sample's bits do not depend on the batch it is in) | 0 (never)
+WINO_SPLIT = {"0": 0, "s": 1}.get(os.environ.get("REFID_SPLITK", os.environ.get("REFID_WINO_SPLITK", "auto"))[:1], 2)
 
 # Winograd tile selection (refid_conv_desc.wino_tile): 0 = by problem size, 1 = 2-waves tile, 2 = persistent tile
 WINO_TILE = int(os.environ.get("REFID_WINO_TILE", "0"))
@@ -132,8 +133,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
     d.algo = algo
     d.wino_tile = WINO_TILE
-    if algo == 1 and WINO_SPLIT:
-        d.wino_split = WINO_SPLIT
+    if WINO_SPLIT and algo in (0, 1, 2):
+        d.split_k = WINO_SPLIT
         need = lib().refid_conv_workspace_bytes(C.byref(d))
         if need:
             ws = _workspace(need, in_a.device, "conv")

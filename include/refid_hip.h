@@ -141,7 +141,10 @@ typedef struct refid_wgrad_desc {
     int i_base, i_total;                        /* dw second-dim offset / full size (slices) */
     int o_real;                                 /* rows of dw/db actually written (<= c_o); the
                                                    rest of g's channels is padding        */
-    int algo;                                   /* 0 = direct; 1 = Winograd F(2x2,3x3) (3x3 stride 1) */
+    int algo;                                   /* 0 = direct; 1 = Winograd F(2x2,3x3) (3x3 stride 1);
+                                                   2 = direct with bf16 MFMA operands (3x3 stride 1 pad 1, more than 32
+                                                   output and input channels; fp32 accumulation / slabs / dw; slab
+                                                   geometry and phases identical to algo 0)                   */
     int phase;                                  /* 0 = partial products + reduction in one call;
                                                    weights shared over the T recurrent steps can instead
                                                    keep accumulating in their own `slabs`:

@@ -16,21 +16,13 @@
 // second kernel reduces the slabs and ACCUMULATES into the parameter-layout gradient,
 // because weights are shared over the T recurrent steps.
 #include "common.h"
+#include "wgrad_args.h"
 #include <cstdlib>
 
 namespace {
 
 const bool USE_THIN_WGRAD = !(getenv("REFID_THIN_WGRAD") && getenv("REFID_THIN_WGRAD")[0] == '0');
 
-struct WgKArgs {
-    const float* g; int ldG, Co;
-    const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
-    float* slabs; float* bslabs;
-    int N, H, W, Ho, Wo, pad;
-    int tilesX, tilesY, ntiles, nsplit;
-    int CoP, CiP;
-    int accum;                 // add into the slabs instead of overwriting them
-};
 
 template <int KH_, int KW_, int S_, int TPW_, int SM_, int SN_, int WR_, int WC_, int WT_, int TH_, int TW_>
 struct WCfg {
@@ -686,8 +678,10 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
                 d->wo, eh, ew);
     REFID_CHECK(d->i_total > d->i_base && d->i_base >= 0 && d->o_real > 0 && d->o_real <= d->c_o,
                 "wgrad: i_base/i_total/o_real inconsistent");
-    REFID_CHECK(d->algo == 0 || (d->algo == 1 && d->kh == 3 && d->kw == 3 && d->stride == 1),
+    REFID_CHECK(d->algo == 0 || ((d->algo == 1 || d->algo == 2) && d->kh == 3 && d->kw == 3 && d->stride == 1),
                 "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
+    REFID_CHECK(d->algo != 2 || (p.id == P_W3 && d->pad == 1),
+                "wgrad: algo 2 (bf16 operands) needs more than 32 output and input channels and pad 1");
     if (d->algo == 1) return refid_wgrad_wino_launch(d, st);
     if (thin_ok(d)) {
         REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
@@ -743,6 +737,8 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
         else hipLaunchKernelGGL(wgrad_pw_kernel<1>, grid, dim3(256), 0, st, w);
         REFID_LAUNCH_CHECK("wgrad_pw");
         rc = 0;
+    } else if (d->phase != 3 && d->algo == 2) {
+        rc = refid_wgrad_bf16_launch(a, g.nciT, g.ncoT, st);
     } else if (d->phase != 3) switch (p.id) {
         case P_W3: rc = launch_w<W3>(a, g, st); break;
         case P_W3_64x32: rc = launch_w<W3_64x32>(a, g, st); break;

@@ -349,6 +349,8 @@ class ConvOp:
                 ops.colsum(g, self.gb)
             return
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci >= 32) else 0
+        if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
+            algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
                                       db=self.gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
                                       slabs=self.wslab)

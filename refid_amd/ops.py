@@ -148,7 +148,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     e1.record()
     taps = {0: kh * kw, 1: 1, 2: 16}[mode]
     flops = 2.0 * d.n * d.ho * d.wo * cout * (d.c_a + d.c_b) * taps
-    name = "conv_igemm_kernel<" + lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode() + ">"
+    name = "conv_igemm_kernel<" + lib().refid_conv_tile_name(kh, kw, stride, mode, cout).decode() + \
+        (", true> [bf16 operands]" if algo == 2 else ">")
     if algo == 1:
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
     if algo == 3:
@@ -226,7 +227,8 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     e1.record()
     flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
     nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + d.n * d.ho * d.wo * d.c_o)
-    PROFILE.append((("wgrad_wino_kernel" if algo == 1 else f"wgrad_kernel<{kh}x{kw}s{stride}>"), flops, e0, e1,
+    PROFILE.append((("wgrad_wino_kernel" if algo == 1 else ("wgrad_bf16_kernel" if algo == 2 else
+                                                           f"wgrad_kernel<{kh}x{kw}s{stride}>")), flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None)), nbytes))
     return slabs
 

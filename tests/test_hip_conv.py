@@ -705,3 +705,41 @@ def test_direct_tile_splitk_small_grids(kind):
     assert _lib.lib().refid_conv_workspace_bytes(C.byref(d)) > 0          # this shape IS split
     np.testing.assert_allclose(outs[0].cpu().numpy(), outs[1].cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(nchw(outs[0]).numpy(), ref.numpy(), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 35, 128, 0, 64), (1, 8, 8, 256, 256, 256),
+                                 (1, 5, 3, 64, 0, 128)])
+def test_bf16_weight_gradient_tile(cfg):
+    """refid_conv2d_wgrad algo 2 (csrc/wgrad_bf16.hip): bf16 matrix-core operands, fp32 accumulation.  Against a float64
+    reference on the bf16-ROUNDED operands the result is exact to fp32 summation error; against the unrounded fp32
+    reference it carries the operands' 2^-9 rounding (the config-3 criterion is PSNR / loss-level)."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    x = rnd(N, Ca + Cb, H, W, seed=1)
+    g = rnd(N, Co, H, W, seed=4)
+    w = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    F.conv2d(x, w, b, 1, 1).backward(g)
+    xr, gr = x.float().bfloat16().double(), g.float().bfloat16().double()
+    w2 = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
+    F.conv2d(xr, w2, None, 1, 1).backward(gr)
+    dw = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")
+    xa = nhwc(x[:, :Ca]); xb = nhwc(x[:, Ca:]) if Cb else None
+    # two calls accumulate (weights shared over the T steps); persistent-slab phases as for the other tiles
+    ops.conv2d_wgrad(nhwc(g), xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=2)
+    sl = ops.conv2d_wgrad(nhwc(g), xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=2, phase=1, i_total=Ca + Cb)
+    ops.conv2d_wgrad(nhwc(g), xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=2, phase=2, slabs=sl, i_total=Ca + Cb)
+    ops.conv2d_wgrad(nhwc(g), xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=2, phase=3, slabs=sl, i_total=Ca + Cb)
+    got = dw.double().cpu() / 3                      # one-shot + (overwrite, add) reduced once = 3 contributions
+    scale = float(w2.grad.abs().max())
+    assert float((got - w2.grad).abs().max()) <= 2e-5 * scale, "bf16 tile vs float64 on the rounded operands"
+    assert float((got - w.grad).abs().max()) <= 2e-2 * float(w.grad.abs().max())
+    # bias gradient sums the fp32 (unrounded) gradient
+    np.testing.assert_allclose(db.double().cpu().numpy() / 3, b.grad.numpy(), rtol=1e-4, atol=1e-4 * float(b.grad.abs().max()))
+    # first recurrent step: the second source does not exist yet, the slab geometry already covers it (i_total)
+    if Cb:
+        dw1 = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda")
+        s1 = ops.conv2d_wgrad(nhwc(g), xa, dw1, kh=3, kw=3, stride=1, pad=1, algo=2, phase=1, i_total=Ca + Cb)
+        ops.conv2d_wgrad(nhwc(g), xa, dw1, kh=3, kw=3, stride=1, pad=1, algo=2, phase=3, slabs=s1, i_total=Ca + Cb)
+        assert float((dw1[:, :Ca].double().cpu() - w2.grad[:, :Ca]).abs().max()) <= 2e-5 * scale
+        assert float(dw1[:, Ca:].abs().max()) == 0.0

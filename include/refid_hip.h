@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 2
+#define REFID_ABI_VERSION 3
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -65,6 +65,29 @@ int refid_device_cu_count(void);
  * mode 2: input-gradient of conv4x4/stride2/pad1 (`conv_down`): four output-parity
  *         classes, each a 2x2-tap conv over the (h,w) gradient, stored at (2y+py,2x+px).
  * ---------------------------------------------------------------------------------- */
+/* Fusions around a POINTWISE conv (algo 3, more than 32 output channels) -- the non-GEMM steps of EGACA
+ * (fusion_modules.py:290-333) folded into its 1x1 convs; every member is optional (NULL / 0 = off):
+ *   ln_*   LayerNorm2d PROLOGUE (fm:97-108,300,302,323-325): the operand is normalised over its (<= 64, one source)
+ *          channels -- mean / biased variance, eps inside the root, times ln_gamma plus ln_beta -- before the GEMM;
+ *          ln_out (pitch ld_ln_out) receives the normalised tensor (the training stash conv's weight gradient needs).
+ *   se_*   SQUEEZE-EXCITE in the kernel (fm:253-260,309-315): `pool` holds the per-workgroup partial sums of the
+ *          depthwise kernel, (n, pool_parts, se_c); every workgroup derives its sample's
+ *          s = sigmoid(W2 relu(W1 mean + b1) + b2) and multiplies operand channel k by s[k mod se_c] as it is loaded
+ *          ([xi*s | xe*s] is never materialised; xs_out optionally receives it for conv3's weight gradient);
+ *          se_m / se_z1 / se_s (n,se_c) / (n,se_c/2) / (n,se_c) optionally receive the vectors SE's backward needs.
+ *          hw = pixels per sample, must be a multiple of 128.
+ *   res2   second residual tensor added with `res` (y = ev + img + beta*conv3(.), fm:319).
+ *   out2   receives GELU_erf(out) (fm:327-329); `out` keeps the pre-activation for the backward pass. */
+typedef struct refid_pw_extras {
+    const float* ln_gamma; const float* ln_beta; float ln_eps; float* ln_out; int ld_ln_out;
+    const float* pool; int pool_parts; float inv_hw; int hw; int se_c;
+    const float* se_w1; const float* se_b1; const float* se_w2; const float* se_b2;
+    float* se_m; float* se_z1; float* se_s;
+    float* xs_out; int ld_xs_out;
+    const float* res2; int ld_res2;
+    float* out2; int ld_out2;
+} refid_pw_extras;
+
 typedef struct refid_conv_desc {
     const float* in_a;  const float* in_b;      /* NHWC sources                         */
     int ld_a, ld_b;                             /* pixel pitch (floats)                 */
@@ -100,6 +123,7 @@ typedef struct refid_conv_desc {
                                                    workgroups; the default); 2 = the persistent one-wave-per-SIMD tile
                                                    (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
                                                    geometry allows.  Same results bit for bit; 2 measured slower.     */
+    const refid_pw_extras* pw;                  /* algo 3 only: fusions around the pointwise conv, or NULL               */
     float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
                                                    aligned, private to this stream until the call's work has run;
                                                    NULL: never split                                            */

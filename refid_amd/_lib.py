@@ -14,6 +14,19 @@ class RefidHipError(RuntimeError):
     pass
 
 
+class PwExtras(C.Structure):
+    _fields_ = [
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p),
+        ("ld_ln_out", C.c_int),
+        ("pool", C.c_void_p), ("pool_parts", C.c_int), ("inv_hw", C.c_float), ("hw", C.c_int), ("se_c", C.c_int),
+        ("se_w1", C.c_void_p), ("se_b1", C.c_void_p), ("se_w2", C.c_void_p), ("se_b2", C.c_void_p),
+        ("se_m", C.c_void_p), ("se_z1", C.c_void_p), ("se_s", C.c_void_p),
+        ("xs_out", C.c_void_p), ("ld_xs_out", C.c_int),
+        ("res2", C.c_void_p), ("ld_res2", C.c_int),
+        ("out2", C.c_void_p), ("ld_out2", C.c_int),
+    ]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ("in_a", C.c_void_p), ("in_b", C.c_void_p),
@@ -31,6 +44,7 @@ class ConvDesc(C.Structure):
         ("slope_pre", C.c_float), ("slope_post", C.c_float), ("slope_mask", C.c_float),
         ("algo", C.c_int),
         ("split_k", C.c_int), ("wino_tile", C.c_int),
+        ("pw", C.POINTER(PwExtras)),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
     ]
 
@@ -49,7 +63,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 2          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 3          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 

@@ -31,4 +31,15 @@ int refid_launch_splitk_finish(const ConvKArgs& f, const float* ws, int ldW, lon
 bool refid_wino3x3_p_eligible(const ConvKArgs& a, int cus);
 int refid_launch_wino3x3_p(const ConvKArgs& a, int cus, hipStream_t st);
 // conv_pw.hip
-int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st);
+// Fusions around a pointwise conv (refid_pw_extras in refid_hip.h): EGACA's LayerNorm2d prologue, the squeeze-excite
+// vector computed in the kernel and applied to the operand, second residual, GELU second output.
+struct PwExtra {
+    const float* lnG = nullptr; const float* lnB = nullptr; float lnEps = 0.f; float* lnOut = nullptr; int ldLn = 0;
+    const float* pool = nullptr; int poolParts = 0; float invHW = 0.f; int hw = 0; int seC = 0;
+    const float* seW1 = nullptr; const float* seB1 = nullptr; const float* seW2 = nullptr; const float* seB2 = nullptr;
+    float* seM = nullptr; float* seZ1 = nullptr; float* seS = nullptr;
+    float* xsOut = nullptr; int ldXs = 0;
+    const float* res2 = nullptr; int ldR2 = 0;
+    float* out2 = nullptr; int ldO2 = 0;
+};
+int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st, const PwExtra* ex = nullptr);

@@ -469,6 +469,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     REFID_CHECK(d->n > 0 && d->h > 0 && d->w > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0,
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
+    REFID_CHECK(d->pw == nullptr || d->algo == 3, "conv2d: pw fusions belong to the pointwise tile (algo 3)");
     REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3) || (d->algo == 3 && f == F_1x1),
                 "conv2d: algo %d does not fit this geometry (1 = 3x3 stride 1, 3 = 1x1)", d->algo);
     REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
@@ -510,6 +511,22 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
                         (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
                     "conv2d: tensor too large for the pointwise tile's 32-bit offsets (use algo 0)");
+        if (d->pw != nullptr) {
+            const refid_pw_extras* x = d->pw;
+            PwExtra e;
+            e.lnG = x->ln_gamma; e.lnB = x->ln_beta; e.lnEps = x->ln_eps; e.lnOut = x->ln_out; e.ldLn = x->ld_ln_out;
+            e.pool = x->pool; e.poolParts = x->pool_parts; e.invHW = x->inv_hw; e.hw = x->hw; e.seC = x->se_c;
+            e.seW1 = x->se_w1; e.seB1 = x->se_b1; e.seW2 = x->se_w2; e.seB2 = x->se_b2;
+            e.seM = x->se_m; e.seZ1 = x->se_z1; e.seS = x->se_s;
+            e.xsOut = x->xs_out; e.ldXs = x->ld_xs_out;
+            e.res2 = x->res2; e.ldR2 = x->ld_res2;
+            e.out2 = x->out2; e.ldO2 = x->ld_out2;
+            auto al = [](const void* q, int ld) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0 && ld % 4 == 0; };
+            REFID_CHECK((!e.lnOut || al(e.lnOut, e.ldLn)) && (!e.xsOut || al(e.xsOut, e.ldXs)) && (!e.res2 || al(e.res2, e.ldR2)) &&
+                            (!e.out2 || al(e.out2, e.ldO2)) && (!e.lnG || (al(e.lnG, 4) && al(e.lnB, 4))),
+                        "conv2d: pointwise fusion tensors must be 16-byte aligned with pitches that are multiples of 4");
+            return refid_launch_pointwise(a, st, &e);
+        }
         return refid_launch_pointwise(a, st);
     }
     if (d->algo == 1) {

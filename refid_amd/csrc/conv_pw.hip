@@ -22,8 +22,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr int KC = 8;
 constexpr int OOB = -1;
 
-template <int NT, int XD>      // NT: 32-channel column tiles per wave (Cout tile = 32*NT); XD: activation prefetch depth
-__global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a) {
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+// NT: 32-channel column tiles per wave (Cout tile = 32*NT); XD: activation prefetch depth; EX: the EGACA fusions of
+// PwExtra are compiled in (fusion_modules.py:290-333):
+//   * LayerNorm2d PROLOGUE (e.lnG): K <= 8*2*XD channels, so a lane holds its half of the pixel's channels in the
+//     2*XD staging registers at once -- mean / variance over the channel axis (two-pass, the partner half arrives by one
+//     cross-lane exchange), normalise in registers, optionally store the normalised tensor (training stash), then the
+//     MFMAs: conv(LN(x)) in one pass over x;
+//   * SQUEEZE-EXCITE in the kernel (e.pool): every workgroup reduces the per-workgroup pool partials of the depthwise
+//     kernel for ITS sample, runs the two tiny mat-vecs + sigmoid (global-pool -> 1x1 -> ReLU -> 1x1 -> sigmoid,
+//     fm:253-260) and multiplies the operand channels by the result while they are loaded (fm:312-315: the scaled
+//     [xi*s | xe*s] concatenation is never a tensor on the inference path; training stores it once for conv3's weight
+//     gradient);
+//   * a second residual (y = ev + img + beta*conv3(.), fm:319) and a GELU second output (fm:327-329).
+template <int NT, int XD, bool EX>
+__global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, const PwExtra e) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const long long npix = (long long)a.N * a.H * a.W;
@@ -76,22 +90,107 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a) {
     f32x4 xr[2 * XD];
     f32x4 wr[2][NT];
     const int nch = a.nchunks;
+    __shared__ float sS[EX ? 128 : 1];                       // squeeze-excite vector of this workgroup's sample
+    bool ln_done = false;
+    if constexpr (EX) {
+        if (e.pool != nullptr) {
+            __shared__ float sM[128], sZ[64];
+            const int C = e.seC, Ch = C / 2, tid = threadIdx.x;
+            const int n = (int)(((long long)blockIdx.x * 128) / e.hw);          // host: hw % 128 == 0
+            for (int c = tid; c < C; c += 256) {
+                const float* pp = e.pool + (long long)n * e.poolParts * C + c;
+                float s0 = 0.f;
+                for (int r = 0; r < e.poolParts; ++r) s0 += pp[(long long)r * C];      // fixed order: deterministic
+                sM[c] = s0 * e.invHW;
+            }
+            __syncthreads();
+            for (int j = tid; j < Ch; j += 256) {
+                float z = e.seB1[j];
+                for (int c = 0; c < C; ++c) z += e.seW1[j * C + c] * sM[c];
+                sZ[j] = z > 0.f ? z : 0.f;
+            }
+            __syncthreads();
+            for (int c = tid; c < C; c += 256) {
+                float v = e.seB2[c];
+                for (int j = 0; j < Ch; ++j) v += e.seW2[c * Ch + j] * sZ[j];
+                sS[c] = 1.f / (1.f + __expf(-v));
+            }
+            __syncthreads();
+            if (e.seS != nullptr && blockIdx.y == 0 && ((long long)blockIdx.x * 128) % e.hw == 0) {   // one writer per sample
+                for (int c = tid; c < C; c += 256) { e.seM[n * C + c] = sM[c]; e.seS[n * C + c] = sS[c]; }
+                for (int j = tid; j < Ch; j += 256) e.seZ1[n * Ch + j] = sZ[j];
+            }
+        }
+        if (e.lnG != nullptr) {
+            // LayerNorm2d prologue: all nch (<= 2*XD) chunks of this lane's half of the pixel in registers
 #pragma unroll
-    for (int j = 0; j < XD; ++j)
-        if (j < nch) xr[j] = load_x(j);
-    load_w(0, wr[0]);
-    for (int c0 = 0; c0 < nch; c0 += 2 * XD) {
+            for (int j = 0; j < 2 * XD; ++j) xr[j] = (j < nch) ? load_x(j) : f32x4{0.f, 0.f, 0.f, 0.f};
+            load_w(0, wr[0]);
+            float s1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 2 * XD; ++j) {
-            const int c = c0 + j;
-            if (c < nch) {
-                if (c + 1 < nch) load_w(c + 1, wr[(j + 1) & 1]);
-                if (c + XD < nch) xr[(j + XD) % (2 * XD)] = load_x(c + XD);
+            for (int j = 0; j < 2 * XD; ++j) s1 += (xr[j][0] + xr[j][1]) + (xr[j][2] + xr[j][3]);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = s1 / (float)a.Ctot;
+            float s2 = 0.f;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
+            for (int j = 0; j < 2 * XD; ++j)
+                if (j < nch) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+                    for (int k = 0; k < 4; ++k) { const float d = xr[j][k] - mu; s2 += d * d; }
+                }
+            s2 += __shfl_xor(s2, 32, 64);
+            const float rstd = 1.f / sqrtf(s2 / (float)a.Ctot + e.lnEps);
+#pragma unroll
+            for (int j = 0; j < 2 * XD; ++j)
+                if (j < nch) {
+                    const int c = j * KC + kh * 4;
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(e.lnG + c);
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(e.lnB + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) xr[j][k] = (xr[j][k] - mu) * rstd * gv[k] + bv[k];
+                    if (e.lnOut != nullptr && blockIdx.y == 0 && pok)
+                        *reinterpret_cast<f32x4*>(e.lnOut + p * e.ldLn + c) = xr[j];
+                }
+#pragma unroll
+            for (int j = 0; j < 2 * XD; ++j)
+                if (j < nch) {
+                    if (j + 1 < nch) load_w(j + 1, wr[(j + 1) & 1]);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+                }
+            ln_done = true;
+        }
+    }
+    if (!ln_done) {
+#pragma unroll
+        for (int j = 0; j < XD; ++j)
+            if (j < nch) xr[j] = load_x(j);
+        load_w(0, wr[0]);
+        for (int c0 = 0; c0 < nch; c0 += 2 * XD) {
+#pragma unroll
+            for (int j = 0; j < 2 * XD; ++j) {
+                const int c = c0 + j;
+                if (c < nch) {
+                    if (c + 1 < nch) load_w(c + 1, wr[(j + 1) & 1]);
+                    if (c + XD < nch) xr[(j + XD) % (2 * XD)] = load_x(c + XD);
+                    if constexpr (EX) {
+                        if (e.pool != nullptr) {                   // operand channel k scaled by s[k mod C]
+                            const int k0 = c * KC + kh * 4;
+                            const f32x4 sv = *reinterpret_cast<const f32x4*>(&sS[k0 % e.seC]);
+                            xr[j] *= sv;
+                            if (e.xsOut != nullptr && blockIdx.y == 0 && pok)
+                                *reinterpret_cast<f32x4*>(e.xsOut + p * e.ldXs + k0) = xr[j];
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -131,6 +230,9 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePre);
                 if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pp * a.ldR + j0);
+                if constexpr (EX) {
+                    if (e.res2) v += *reinterpret_cast<const f32x4*>(e.res2 + pp * e.ldR2 + j0);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
                 if (a.mask) {
@@ -139,6 +241,14 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a) {
                     for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
                 }
                 *reinterpret_cast<f32x4*>(a.out + pp * a.ldO + j0) = v;
+                if constexpr (EX) {
+                    if (e.out2) {
+                        f32x4 gl;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) gl[k] = gelu_erf(v[k]);
+                        *reinterpret_cast<f32x4*>(e.out2 + pp * e.ldO2 + j0) = gl;
+                    }
+                }
             }
         }
         return;
@@ -166,14 +276,27 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a) {
 
 }  // namespace
 
-int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st) {
+int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* ex) {
     ConvKArgs a = ka;
     a.nchunks = cdiv(a.Ctot, KC);
     const long long npix = (long long)a.N * a.H * a.W;
     const int nb = (int)((npix + 127) / 128);
+    if (ex != nullptr) {
+        REFID_CHECK(a.vecOK && a.Cout > 32, "conv2d: pointwise fusions need 16-byte aligned tensors and more than 32 outputs");
+        REFID_CHECK(!ex->lnG || (a.inB == nullptr && a.Ctot % 8 == 0 && a.Ctot <= 64 && ex->lnB),
+                    "conv2d: the LayerNorm prologue needs one source of at most 64 channels (got %d)", a.Ctot);
+        REFID_CHECK(!ex->pool || (ex->hw > 0 && ex->hw % 128 == 0 && ex->seC >= 8 && ex->seC <= 128 && ex->seC % 8 == 0 &&
+                                  a.Ctot % ex->seC == 0 && ex->poolParts > 0 && ex->seW1 && ex->seB1 && ex->seW2 && ex->seB2 &&
+                                  (!ex->seS || (ex->seM && ex->seZ1)) && !ex->lnG),
+                    "conv2d: bad squeeze-excite fusion arguments (pixels per sample must be a multiple of 128)");
+        hipLaunchKernelGGL((conv_pw_kernel<2, 4, true>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, *ex);
+        REFID_LAUNCH_CHECK("conv_pw/fused");
+        return 0;
+    }
+    const PwExtra none;
     // wider layers run as 64-channel column tiles (grid.y): 4 waves/SIMD beat re-using the activations
-    if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1, 8>), dim3(nb, 1), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_pw_kernel<2, 4>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a);
+    if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1, 8, false>), dim3(nb, 1), dim3(256), 0, st, a, none);
+    else hipLaunchKernelGGL((conv_pw_kernel<2, 4, false>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, none);
     REFID_LAUNCH_CHECK("conv_pw");
     return 0;
 }

@@ -138,6 +138,9 @@ USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
 USE_POINTWISE = os.environ.get("REFID_POINTWISE", "1") != "0"     # register-operand tile for 1x1 convs
 # weight-gradient kernels on a side HIP stream (REFID_OVERLAP_WGRAD=0: everything on one stream)
 OVERLAP_WGRAD = os.environ.get("REFID_OVERLAP_WGRAD", "1") != "0"
+# EGACA forward as 6 launches (LayerNorm prologues, squeeze-excite + scale inside conv3, GELU second output) instead of
+# 12; REFID_EGACA_FUSED=0: one kernel per reference op
+EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
 
 
 class _SideStreams:
@@ -228,6 +231,11 @@ class ConvOp:
         self.f_kc = ops.conv_kc(kh, kw, st, md)
         self.f_bn = ops.conv_bn(kh, kw, st, md, self.f_rows)
         self.f_algo = self.d_algo = 0
+        pointwise = USE_POINTWISE and kind == "conv" and k == 1 and self.ci % 16 == 0 and self.co % 16 == 0
+        if bf16 and pointwise:
+            # the 1x1 layers are bandwidth bound on fp32 tensors either way: the register-operand fp32 tile (no LDS,
+            # no conversion pass) beats the LDS-staged bf16 tile on them (39.5 -> 34 ms / step), at full precision
+            bf16 = self.bf16 = False
         if bf16:
             # bf16 MFMA operands on the direct tile (fp32 accumulate / epilogue / tensors); no Winograd:
             # its transforms would amplify the operand rounding, and bf16 MFMA is 16x the fp32 rate anyway
@@ -237,7 +245,7 @@ class ConvOp:
             if self.co >= 16:                  # pred (3 channels) stays on the direct tile
                 self.f_algo, self.f_role, self.f_kc, self.f_bn = 1, ops.ROLE_WINO_FWD, 8, 64
             self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
-        elif USE_POINTWISE and kind == "conv" and k == 1 and self.ci % 16 == 0 and self.co % 16 == 0:
+        elif pointwise:
             self.f_algo = self.d_algo = 3
             self.f_kc, self.f_bn = 8, 32
         self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
@@ -282,7 +290,7 @@ class ConvOp:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 
     # ---- forward ---------------------------------------------------------------------------
-    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None):
+    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None, pw=None):
         n, h, w, _ = a.shape
         if self.kind == "conv":
             ho, wo, oc = h, w, self.co
@@ -298,7 +306,7 @@ class ConvOp:
         kh, kw, st, md = self.f_geo
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
                    cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post,
-                   algo=self.f_algo)
+                   algo=self.f_algo, pw=pw)
         return out
 
     # ---- input gradient ----------------------------------------------------------------------
@@ -519,13 +527,20 @@ class Engine:
     # -------------------------------------------------------------------------------------------
     def _egaca_img_path(self, A, img):
         """xi = GELU(dw3x3(conv1(LN1(img)))): t-independent, once per sweep (fm:300,303-305)."""
-        ln_i = ops.layernorm2d_fwd(img, A.p("norm1.weight"), A.p("norm1.bias"))
-        c1i = A.conv1.fwd(ln_i)
+        n, h, w, c = img.shape
+        if EGACA_FUSED and 32 < c <= 64 and c % 8 == 0 and A.conv1.f_algo == 3:
+            ln_i = torch.empty_like(img)                      # (kept: conv1's weight gradient reads it)
+            c1i = A.conv1.fwd(img, pw=dict(ln_gamma=A.p("norm1.weight"), ln_beta=A.p("norm1.bias"), ln_out=ln_i))
+        else:
+            ln_i = ops.layernorm2d_fwd(img, A.p("norm1.weight"), A.p("norm1.bias"))
+            c1i = A.conv1.fwd(ln_i)
         dwi, xi = ops.dwconv3x3_gelu_fwd(c1i, A.p("conv2.weight"), A.p("conv2.bias"))
         return dict(ln_i=ln_i, c1i=c1i, dwi=dwi, xi=xi, gxi=None)
 
     def _egaca_fwd(self, A, ev, img, ip, st):
         n, h, w, c = ev.shape
+        if EGACA_FUSED and (h * w) % 128 == 0 and 32 < c <= 64 and c % 8 == 0 and A.conv1_e.f_algo == 3:
+            return self._egaca_fwd_fused(A, ev, img, ip, st)
         ln_e = ops.layernorm2d_fwd(ev, A.p("norm1_e.weight"), A.p("norm1_e.bias"))
         c1e = A.conv1_e.fwd(ln_e)
         dwe, xe, pool = ops.dwconv3x3_gelu_fwd(c1e, A.p("conv2_e.weight"), A.p("conv2_e.bias"), want_pool=True)
@@ -542,6 +557,39 @@ class Engine:
         if st is not None:
             st["eg"] = dict(ev=ev, ln_e=ln_e, c1e=c1e, dwe=dwe, xe=xe, m=m, z1=z1, s=s, xs=xs, y=y, ln2=ln2,
                             c4=c4, f4=f4)
+        return out
+
+    def _egaca_fwd_fused(self, A, ev, img, ip, st):
+        """fusion_modules.py:290-333 in six launches (csrc/conv_pw.hip, refid_pw_extras):
+          1  c1e = conv1_e(LN1e(ev))                          LayerNorm2d in the conv's prologue
+          2  dwe, xe, pool partials = GELU(dw3x3(c1e))
+          3  y = ev + img + beta * conv3([xi*s | xe*s])      s = sigmoid(W2 relu(W1 mean(xe) + b1) + b2) computed per
+                                                              workgroup from the pool partials and applied to the operand
+          4  c4 = conv4(LN2(y)), f4 = GELU(c4)                LayerNorm prologue + GELU second output
+          5  side = conv_y_side(y)
+          6  out = side + gamma * conv5(f4)
+        In training the tensors the (unchanged) backward reads -- ln_e, xs, m / z1 / s, ln2, c4 -- are side outputs."""
+        n, h, w, c = ev.shape
+        save = st is not None
+        dev = ev.device
+        new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)          # noqa: E731
+        ln_e = new(n, h, w, c) if save else None
+        c1e = A.conv1_e.fwd(ev, pw=dict(ln_gamma=A.p("norm1_e.weight"), ln_beta=A.p("norm1_e.bias"), ln_out=ln_e))
+        dwe, xe, pool = ops.dwconv3x3_gelu_fwd(c1e, A.p("conv2_e.weight"), A.p("conv2_e.bias"), want_pool=True)
+        m = z1 = s = xs = None
+        if save:
+            m, z1, s, xs = new(n, c), new(n, c // 2), new(n, c), new(n, h, w, 2 * c)
+        y = A.conv3.fwd(ip["xi"], xe, res=ev,
+                        pw=dict(pool=pool, hw=h * w, se_w1=A.p("se_1.1.weight"), se_b1=A.p("se_1.1.bias"),
+                                se_w2=A.p("se_1.3.weight"), se_b2=A.p("se_1.3.bias"), se_m=m, se_z1=z1, se_s=s,
+                                xs_out=xs, res2=img))
+        ln2 = new(n, h, w, c) if save else None
+        f4 = new(n, h, w, A.conv4.co)
+        c4 = A.conv4.fwd(y, pw=dict(ln_gamma=A.p("norm2.weight"), ln_beta=A.p("norm2.bias"), ln_out=ln2, out2=f4))
+        side = A.side.fwd(y)
+        out = A.conv5.fwd(f4, res=side)
+        if save:
+            st["eg"] = dict(ev=ev, ln_e=ln_e, c1e=c1e, dwe=dwe, xe=xe, m=m, z1=z1, s=s, xs=xs, y=y, ln2=ln2, c4=c4, f4=f4)
         return out
 
     def _egaca_bwd(self, A, g_u, img_grad, ip, st):

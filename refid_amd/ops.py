@@ -98,10 +98,44 @@ def pack_conv_weights_bf16(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None)
     return out
 
 
+def _pw_extras(pw, out):
+    """refid_pw_extras from a dict of tensors / scalars (see include/refid_hip.h); returns (struct, keep-alive list)."""
+    x = _lib.PwExtras()
+    if pw.get("ln_gamma") is not None:
+        x.ln_gamma, x.ln_beta, x.ln_eps = _c(pw["ln_gamma"], "ln_gamma"), _c(pw["ln_beta"], "ln_beta"), pw.get("ln_eps", 1e-6)
+        if pw.get("ln_out") is not None:
+            x.ln_out, x.ld_ln_out = _nhwc(pw["ln_out"], "ln_out")
+    if pw.get("pool") is not None:
+        pool = pw["pool"]
+        x.pool, x.pool_parts, x.se_c = _c(pool, "pool"), pool.shape[1], pool.shape[2]
+        x.hw = pw["hw"]
+        x.inv_hw = 1.0 / pw["hw"]
+        x.se_w1, x.se_b1, x.se_w2, x.se_b2 = (_c(pw[k], k) for k in ("se_w1", "se_b1", "se_w2", "se_b2"))
+        if pw.get("se_s") is not None:
+            x.se_m, x.se_z1, x.se_s = _c(pw["se_m"], "se_m"), _c(pw["se_z1"], "se_z1"), _c(pw["se_s"], "se_s")
+        if pw.get("xs_out") is not None:
+            x.xs_out, x.ld_xs_out = _nhwc(pw["xs_out"], "xs_out")
+    if pw.get("res2") is not None:
+        if pw["res2"].shape != out.shape:
+            raise _lib.RefidHipError("conv2d: res2 shape differs from the output's")
+        x.res2, x.ld_res2 = _nhwc(pw["res2"], "res2")
+    if pw.get("out2") is not None:
+        if pw["out2"].shape != out.shape:
+            raise _lib.RefidHipError("conv2d: out2 shape differs from the output's")
+        x.out2, x.ld_out2 = _nhwc(pw["out2"], "out2")
+    return x
+
+
 def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_pad, co_base=0,
-           in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0):
-    """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc."""
+           in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0, pw=None):
+    """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc.  pw: dict of the pointwise tile's
+    EGACA fusions (refid_pw_extras)."""
     d = ConvDesc()
+    if pw is not None:
+        if algo != 3:
+            raise _lib.RefidHipError("conv2d: pw fusions need the pointwise tile (algo 3)")
+        pwx = _pw_extras(pw, out)
+        d.pw = C.pointer(pwx)
     d.in_a, d.ld_a = _nhwc(in_a, "in_a")
     d.c_a = in_a.shape[3]
     if in_b is not None:

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(libpath):
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in refid_hip.h but not exported: {missing}"
     lib.refid_abi_version.restype = ctypes.c_int
-    assert lib.refid_abi_version() == 2
+    assert lib.refid_abi_version() == 3
 
 
 def test_python_binding_loads_and_host_queries_work(libpath):
@@ -62,9 +62,11 @@ def test_struct_layouts_match_the_header():
             stmt = stmt.strip()
             if not stmt:
                 continue
-            names = re.sub(r"^(const\s+)?(float|int|size_t)\s*\*?", "", stmt)
+            names = re.sub(r"^(const\s+)?(float|int|size_t|refid_pw_extras)\s*\*?", "", stmt)
             out += [n.strip().lstrip("*").strip() for n in names.split(",")]
         return out
 
     assert fields("refid_conv_desc") == [f[0] for f in ConvDesc._fields_]
+    from refid_amd._lib import PwExtras
+    assert fields("refid_pw_extras") == [f[0] for f in PwExtras._fields_]
     assert fields("refid_wgrad_desc") == [f[0] for f in WgradDesc._fields_]

@@ -187,3 +187,76 @@ def test_charbonnier_norm_adamw():
         assert torch.equal(ops.grad_sqnorm(gd)[0], sq[0])          # deterministic
         ops.clip_adamw(p, gd, m, v, sq, max_norm=0.01, lr=2e-4, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-4, step=step)
         close(p, p_t.detach(), rtol=1e-5, atol=1e-7)
+
+
+def _egaca_ref(P, a, ev, img):
+    """fusion_modules.py:290-333 in float64 (NCHW), from a flat parameter dict with prefix a."""
+    g = lambda k: P[f"{a}.{k}"].double()                                       # noqa: E731
+
+    def ln(x, n):
+        mu = x.mean(1, keepdim=True)
+        var = (x - mu).pow(2).mean(1, keepdim=True)
+        return g(n + ".weight").view(1, -1, 1, 1) * ((x - mu) / (var + 1e-6).sqrt()) + g(n + ".bias").view(1, -1, 1, 1)
+
+    c = ev.shape[1]
+    xi = F.gelu(F.conv2d(F.conv2d(ln(img, "norm1"), g("conv1.weight"), g("conv1.bias")), g("conv2.weight"), g("conv2.bias"),
+                         padding=1, groups=c))
+    xe = F.gelu(F.conv2d(F.conv2d(ln(ev, "norm1_e"), g("conv1_e.weight"), g("conv1_e.bias")), g("conv2_e.weight"),
+                         g("conv2_e.bias"), padding=1, groups=c))
+    m = xe.mean((2, 3), keepdim=True)
+    s = torch.sigmoid(F.conv2d(F.relu(F.conv2d(m, g("se_1.1.weight"), g("se_1.1.bias"))), g("se_1.3.weight"), g("se_1.3.bias")))
+    zf = F.conv2d(torch.cat([xi * s, xe * s], 1), g("conv3.weight"), g("conv3.bias"))
+    y = ev + img + zf * g("beta")
+    ffn = F.conv2d(F.gelu(F.conv2d(ln(y, "norm2"), g("conv4.weight"), g("conv4.bias"))), g("conv5.weight"), g("conv5.bias"))
+    return F.conv2d(y, g("conv_y_side.weight"), g("conv_y_side.bias")) + ffn * g("gamma")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 16), (1, 24, 32), (3, 8, 16)])
+def test_egaca_fused_forward_six_launches(shape):
+    """The fused EGACA forward (LayerNorm prologues, squeeze-excite + operand scaling inside conv3, second residual, GELU
+    second output: refid_pw_extras) at the shipped width (64 -> 128 channels): output vs a float64 restatement of
+    fusion_modules.py:290-333, every stashed tensor vs the one-kernel-per-op path (which the backward pass was written
+    against), and the launch count."""
+    from oracle import refid_oracle as O
+    from refid_amd import engine as E, ops
+    from refid_amd.archs import define_network
+    n, h, w = shape
+    P = O.make_params(26, mode="hash", seed=3)
+    a = "encoders_forward.1.atten_fuse"
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2, num_encoders=3,
+                              base_num_channels=32, num_block=1, num_residual_blocks=2))
+    net.load_state_dict(P)
+    net = net.cuda()
+    eng = net.engine
+    eng.repack()
+    A = eng.enc_f[1].att
+    ev = rnd(n, 64, h, w, seed=1)
+    img = rnd(n, 64, h, w, seed=2)
+    ref = _egaca_ref(P, a, ev, img)
+    evd, imgd = dev(ev.permute(0, 2, 3, 1)), dev(img.permute(0, 2, 3, 1))
+    outs, stash, counts = {}, {}, {}
+    for fused in (True, False):
+        old, E.EGACA_FUSED = E.EGACA_FUSED, fused
+        calls = []
+        names = ("conv2d", "layernorm2d_fwd", "dwconv3x3_gelu_fwd", "se_fwd", "scale_cat", "add", "gelu_fwd")
+        saved = {k: getattr(ops, k) for k in names}
+        try:
+            for k in names:
+                setattr(ops, k, (lambda f, k: (lambda *aa, **kw: (calls.append(k), f(*aa, **kw))[1]))(saved[k], k))
+            ip = eng._egaca_img_path(A, imgd)
+            calls.clear()
+            st = {}
+            outs[fused] = eng._egaca_fwd(A, evd, imgd, ip, st)
+            stash[fused] = st["eg"]
+            counts[fused] = list(calls)
+            plain = eng._egaca_fwd(A, evd, imgd, ip, None)             # inference: no side outputs
+            assert torch.equal(plain, outs[fused])
+        finally:
+            for k in names:
+                setattr(ops, k, saved[k])
+            E.EGACA_FUSED = old
+    assert len(counts[True]) == 6 and len(counts[False]) == 12, (counts[True], counts[False])
+    close(outs[True].permute(0, 3, 1, 2), ref, rtol=1e-3, atol=1e-4)
+    close(outs[False].permute(0, 3, 1, 2), ref, rtol=1e-3, atol=1e-4)
+    for k in stash[False]:
+        close(stash[True][k], stash[False][k], rtol=1e-4, atol=2e-5)

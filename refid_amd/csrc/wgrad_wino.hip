@@ -61,8 +61,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     const int gco = co0 + gq * 4;
     const bool gcok = gco < a.Co;
     const int xc = ci0 + xq * 4;
-    const bool xFromA = xc < a.Ca;
     const bool xcok = xc < a.Ctot;
+    // the input-channel tile lies in one source (host: c_a % 32 == 0 for two sources), so the descriptor is
+    // workgroup-uniform; a tile beyond the sources (first recurrent step) keeps a valid descriptor, all lanes out of range
+    const bool xFromA = ci0 < a.Ca || ci0 >= a.Ctot;
     const float* xsrc = xFromA ? a.inA : a.inB;
     const int xld = xFromA ? a.ldA : a.ldB;
     const int xcc = xFromA ? xc : xc - a.Ca;
@@ -77,6 +79,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     f32x4 rg[G_ITEMS], rx[X_ITEMS];
 
+    // Tile loads: buffer loads with 32-bit offsets.  A thread's pixel inside the tile never changes, so its offset is
+    // (tile origin pixel) * pitch + a per-thread constant; out-of-image pixels / channels get the out-of-range offset
+    // and come back as zeros (no per-lane branches around loads, no 64-bit address arithmetic per item).
+    const long long gpixAll = (long long)a.N * a.Ho * a.Wo, xpixAll = (long long)a.N * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.g), 0, (int)min(gpixAll * a.ldG * 4, 0x7fffffffLL), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xsrc), 0, (int)min(xpixAll * xld * 4, 0x7fffffffLL), 0x00020000);
     auto load_tile = [&](int pt) {
         int t = pt;
         const int tx = t % a.tilesX; t /= a.tilesX;
@@ -84,23 +94,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         const int n = t / a.tilesY;
         const int oy0 = ty * TH, ox0 = tx * TW;
         const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+        const int gbase = ((n * a.Ho + oy0) * a.Wo + ox0) * a.ldG * 4 + gco * 4;          // bytes, < 2^31 (host check)
+        const int xbase = ((n * a.H + iy0) * a.W + ix0) * xld * 4 + xcc * 4;
 #pragma unroll
         for (int it = 0; it < G_ITEMS; ++it) {
             const int p = tid / G4 + it * (256 / G4);
-            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gcok && oy < a.Ho && ox < a.Wo)
-                v = *reinterpret_cast<const f32x4*>(a.g + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
-            rg[it] = v;
+            const int dy = p / TW, dx = p % TW;
+            const bool ok = gcok && oy0 + dy < a.Ho && ox0 + dx < a.Wo;
+            const int vo = ok ? gbase + (dy * a.Wo + dx) * a.ldG * 4 : -1;
+            rg[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsG, vo, 0, 0));
         }
 #pragma unroll
         for (int it = 0; it < X_ITEMS; ++it) {
             const int hp = tid / X4 + it * (256 / X4);
-            const int iy = iy0 + hp / HWD, ix = ix0 + hp % HWD;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (xcok && hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                v = *reinterpret_cast<const f32x4*>(xsrc + ((long long)(n * a.H + iy) * a.W + ix) * xld + xcc);
-            rx[it] = v;
+            const int dy = hp / HWD, dx = hp % HWD;
+            const int iy = iy0 + dy, ix = ix0 + dx;
+            const bool ok = xcok && hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const int vo = ok ? xbase + (dy * a.W + dx) * xld * 4 : -1;
+            rx[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, vo, 0, 0));
         }
     };
     auto store_tile = [&]() {
@@ -301,6 +312,13 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino_kernel, LDS_BYTES, "wgrad_wino")) return rc;
     const Geo g = geo_of(d);
+    REFID_CHECK(d->c_b == 0 || d->c_a % CIT == 0, "wgrad (Winograd): c_a must be a multiple of %d for two sources", CIT);
+    {
+        const long long lim = 0x7fffffffLL;
+        REFID_CHECK((long long)d->n * d->ho * d->wo * d->ld_g * 4 < lim && (long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&
+                        (d->c_b == 0 || (long long)d->n * d->h * d->w * d->ld_b * 4 < lim),
+                    "wgrad (Winograd): tensor too large for 32-bit buffer offsets (use algo 0)");
+    }
     WwArgs a;
     a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;
     a.inA = d->in_a; a.inB = d->in_b; a.ldA = d->ld_a; a.ldB = d->ld_b;

@@ -103,13 +103,20 @@ def test_config2_train_step_gradient_properties():
     e2, k2 = _per_tensor_err(eng, eng.arena.flat_g, base)
     assert e2 <= 1e-5, (e2, k2)
     assert float((p0 - pred).abs().max()) <= 1e-5
-    # (3) linearity over samples + accumulation, at T=23
-    run(x[2:4], ev[2:4], gt[2:4])
-    two = eng.arena.flat_g.clone()
-    run(x[2:3], ev[2:3], gt[2:3])
-    run(x[3:4], ev[3:4], gt[3:4], zero=False)
-    e3, k3 = _per_tensor_err(eng, eng.arena.flat_g, two)
-    assert e3 <= 2e-5, (e3, k3)
+    # (3) linearity over samples + accumulation, at T=23.  Under the default split-K policy (by total grid size) a
+    # 2-sample launch and two 1-sample launches split K differently: equal to summation-order rounding; under the
+    # per-sample policy the partial sums are the same ones
+    for policy, tol in ((ops.WINO_SPLIT, 2e-4), (1, 2e-5)):
+        olds, ops.WINO_SPLIT = ops.WINO_SPLIT, policy
+        try:
+            run(x[2:4], ev[2:4], gt[2:4])
+            two = eng.arena.flat_g.clone()
+            run(x[2:3], ev[2:3], gt[2:3])
+            run(x[3:4], ev[3:4], gt[3:4], zero=False)
+        finally:
+            ops.WINO_SPLIT = olds
+        e3, k3 = _per_tensor_err(eng, eng.arena.flat_g, two)
+        assert e3 <= tol, (policy, e3, k3)
 
 
 def test_config2_oracle_crop_gradients():

@@ -285,6 +285,11 @@ int refid_colsum(const float* g, int ld_g, float* db, long long npix, int c, voi
 /* *loss_sum = sum sqrt((pred-gt)^2+eps); grad = (pred-gt)/sqrt(.)*grad_scale (grad may be NULL) */
 int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, long long count,
                       float eps, float grad_scale, void* stream);
+/* PSNRLoss (losses.py:95-120, toY = False; image_event_restoration_model.py uses it for the HINet network):
+ * *loss = weight * 10/ln10 * mean_b log(mse_b + 1e-8), mse_b over the per_sample elements of sample b;
+ * grad (may be NULL) = d loss / d pred; sq = scratch of n_samples doubles. */
+int refid_psnr_loss(const float* pred, const float* gt, float* grad, double* sq, double* loss, int n_samples,
+                    long long per_sample, float weight, void* stream);
 /* out[0] = sum g^2 (deterministic two-stage reduction: replicas of a data-parallel job must agree bit for
  * bit); `out` must hold REFID_SQNORM_WORDS doubles (out[1..] is scratch). */
 #define REFID_SQNORM_WORDS 2049

@@ -129,6 +129,7 @@ def _bind_extra(L):
     L.refid_colsum.argtypes = [vp, i, vp, ll, i, vp]
     L.refid_charbonnier.argtypes = [vp, vp, vp, vp, ll, f, f, vp]
     L.refid_grad_sqnorm.argtypes = [vp, vp, ll, vp]
+    L.refid_psnr_loss.argtypes = [vp, vp, vp, vp, vp, i, ll, f, vp]
     L.refid_clip_adamw.argtypes = [vp, vp, vp, vp, vp, f, f, f, f, f, f, f, i, ll, vp]
     L.refid_clip_adamw_dev.argtypes = [vp, vp, vp, vp, vp, f, f, vp, f, f, f, f, ll, vp]
     d = C.c_double

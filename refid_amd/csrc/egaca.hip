@@ -66,22 +66,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
     __syncthreads();
     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + q * 4);
     f32x4 pdw = {0.f, 0.f, 0.f, 0.f}, pdb = {0.f, 0.f, 0.f, 0.f};
-    for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / LPP; p < npix; p += (long long)gridDim.x * PPB) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + p * ldx + q * 4);
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + p * ldg + q * 4);
-        const float mu = group_sum<LPP>(v[0] + v[1] + v[2] + v[3]) * (1.f / C);
-        const f32x4 d = v - mu;
-        const float var = group_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
-        const float rstd = 1.f / sqrtf(var + eps);
-        const f32x4 y = d * rstd;
-        const f32x4 gh = gv * wv;
-        const float m1 = group_sum<LPP>(gh[0] + gh[1] + gh[2] + gh[3]) * (1.f / C);
-        const float m2 = group_sum<LPP>(gh[0] * y[0] + gh[1] * y[1] + gh[2] * y[2] + gh[3] * y[3]) * (1.f / C);
-        f32x4 r = (gh - y * m2 - m1) * rstd;
-        if (res) r += *reinterpret_cast<const f32x4*>(res + p * ldr + q * 4);     // res may alias gx
-        *reinterpret_cast<f32x4*>(gx + p * ldgx + q * 4) = r;
-        pdw += gv * y;
-        pdb += gv;
+    // U pixels per thread per iteration: their 2-3 loads each are issued together (the four lane-group reductions per
+    // pixel are dependent shuffle chains: with one pixel in flight the kernel sat at 0.42 of the HBM rate; now 0.54)
+    constexpr int U = 4;
+    const long long stride = (long long)gridDim.x * PPB;
+    for (long long p0 = blockIdx.x * (long long)PPB + threadIdx.x / LPP; p0 < npix; p0 += stride * U) {
+        f32x4 v[U], gv[U], rv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long p = p0 + u * stride;
+            ok[u] = p < npix;
+            const long long pc = ok[u] ? p : p0;                 // clamped: loads stay unconditional
+            v[u] = *reinterpret_cast<const f32x4*>(x + pc * ldx + q * 4);
+            gv[u] = *reinterpret_cast<const f32x4*>(g + pc * ldg + q * 4);
+            rv[u] = res ? *reinterpret_cast<const f32x4*>(res + pc * ldr + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float mu = group_sum<LPP>(v[u][0] + v[u][1] + v[u][2] + v[u][3]) * (1.f / C);
+            const f32x4 d = v[u] - mu;
+            const float var = group_sum<LPP>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.f / C);
+            const float rstd = 1.f / sqrtf(var + eps);
+            const f32x4 y = d * rstd;
+            const f32x4 gh = gv[u] * wv;
+            const float m1 = group_sum<LPP>(gh[0] + gh[1] + gh[2] + gh[3]) * (1.f / C);
+            const float m2 = group_sum<LPP>(gh[0] * y[0] + gh[1] * y[1] + gh[2] * y[2] + gh[3] * y[3]) * (1.f / C);
+            const f32x4 r = (gh - y * m2 - m1) * rstd + rv[u];
+            if (ok[u]) {                                           // res may alias gx: each pixel is read before it is written
+                *reinterpret_cast<f32x4*>(gx + (p0 + u * stride) * ldgx + q * 4) = r;
+                pdw += gv[u] * y;
+                pdb += gv[u];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) { atomicAdd(&sdw[q * 4 + k], pdw[k]); atomicAdd(&sdb[q * 4 + k], pdb[k]); }

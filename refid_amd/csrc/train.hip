@@ -41,6 +41,39 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const f32x4* __restric
     if (threadIdx.x == 0) atomicAdd(loss_sum, t);
 }
 
+// PSNRLoss (losses.py:95-120, toY = False): loss = w * 10/ln10 * mean_b log(mse_b + 1e-8), mse_b over (C,H,W).
+// Pass 1: sq[b] += sum (pred - gt)^2 of sample b (grid.y = b).  Pass 2: grad = (pred - gt) * 2 w scale / (n_b B (mse_b + 1e-8));
+// block 0 also writes the loss itself.
+__global__ __launch_bounds__(256) void psnr_sq_kernel(const f32x4* __restrict__ pred, const f32x4* __restrict__ gt,
+                                                     double* __restrict__ sq, long long per4) {
+    __shared__ double sh[4];
+    const long long base = (long long)blockIdx.y * per4;
+    float acc = 0.f;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < per4; i += (long long)gridDim.x * 256) {
+        const f32x4 d = pred[base + i] - gt[base + i];
+        acc += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+    }
+    const double t = block_sum_double((double)acc, sh);
+    if (threadIdx.x == 0) atomicAdd(sq + blockIdx.y, t);
+}
+
+__global__ __launch_bounds__(256) void psnr_grad_kernel(const f32x4* __restrict__ pred, const f32x4* __restrict__ gt,
+                                                       f32x4* __restrict__ grad, const double* __restrict__ sq,
+                                                       double* __restrict__ loss, long long per4, int nb, float weight) {
+    const double scale = 10.0 / log(10.0);
+    const double per = (double)per4 * 4.0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        double l = 0.0;
+        for (int b = 0; b < nb; ++b) l += log(sq[b] / per + 1e-8);
+        *loss = weight * scale * l / nb;
+    }
+    if (!grad) return;
+    const float coef = (float)(weight * scale * 2.0 / (per * nb) / (sq[blockIdx.y] / per + 1e-8));
+    const long long base = (long long)blockIdx.y * per4;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < per4; i += (long long)gridDim.x * 256)
+        grad[base + i] = (pred[base + i] - gt[base + i]) * coef;
+}
+
 __global__ __launch_bounds__(256) void sqnorm_kernel(const f32x4* __restrict__ g, double* __restrict__ out, long long n4) {
     __shared__ double sh[4];
     float acc = 0.f;
@@ -111,6 +144,24 @@ extern "C" int refid_charbonnier(const float* pred, const float* gt, float* grad
     hipLaunchKernelGGL(charbonnier_kernel, dim3(nblocks(count / 4)), dim3(256), 0, st, (const f32x4*)pred,
                        (const f32x4*)gt, (f32x4*)grad, loss_sum, eps, grad_scale, count / 4);
     REFID_LAUNCH_CHECK("charbonnier");
+    return 0;
+}
+
+extern "C" int refid_psnr_loss(const float* pred, const float* gt, float* grad, double* sq, double* loss, int n_samples,
+                               long long per_sample, float weight, void* stream) {
+    REFID_CHECK(pred && gt && sq && loss && n_samples > 0 && per_sample > 0 && per_sample % 4 == 0,
+                "psnr_loss: bad arguments (per_sample=%lld)", per_sample);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sq, 0, sizeof(double) * n_samples, st);
+    REFID_CHECK(e == hipSuccess, "psnr_loss: memset failed: %s", hipGetErrorString(e));
+    int nb = nblocks(per_sample / 4);
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(psnr_sq_kernel, dim3(nb, n_samples), dim3(256), 0, st, (const f32x4*)pred, (const f32x4*)gt, sq,
+                       per_sample / 4);
+    REFID_LAUNCH_CHECK("psnr_loss/sq");
+    hipLaunchKernelGGL(psnr_grad_kernel, dim3(nb, n_samples), dim3(256), 0, st, (const f32x4*)pred, (const f32x4*)gt,
+                       (f32x4*)grad, sq, loss, per_sample / 4, n_samples, weight);
+    REFID_LAUNCH_CHECK("psnr_loss/grad");
     return 0;
 }
 

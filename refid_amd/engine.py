@@ -539,7 +539,9 @@ class Engine:
 
     def _egaca_fwd(self, A, ev, img, ip, st):
         n, h, w, c = ev.shape
-        if EGACA_FUSED and (h * w) % 128 == 0 and 32 < c <= 64 and c % 8 == 0 and A.conv1_e.f_algo == 3:
+        # (every conv3 workgroup re-reduces the pool partials of its sample: bounded to 256 rows, i.e. 256x256 pixels)
+        if EGACA_FUSED and (h * w) % 128 == 0 and 32 < c <= 64 and c % 8 == 0 and A.conv1_e.f_algo == 3 and \
+                ops.dwconv_pool_parts(h, w, c) <= 256:
             return self._egaca_fwd_fused(A, ev, img, ip, st)
         ln_e = ops.layernorm2d_fwd(ev, A.p("norm1_e.weight"), A.p("norm1_e.bias"))
         c1e = A.conv1_e.fwd(ln_e)

@@ -357,6 +357,10 @@ def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, res=None, eps=1e-6):
     return gx
 
 
+def dwconv_pool_parts(h, w, c):
+    return lib().refid_dwconv_pool_parts(h, w, c)
+
+
 def dwconv3x3_gelu_fwd(x, w, b, want_pool=False):
     """Returns (pre, act) or (pre, act, pool_parts) with pool_parts (n, parts, c) per-workgroup sums of act."""
     px, ld = _nhwc(x, "x")
@@ -480,6 +484,16 @@ def charbonnier(pred, gt, grad=None, eps=1e-12, grad_scale=None):
     check(lib().refid_charbonnier(_c(pred, "pred"), _c(gt, "gt"), grad.data_ptr() if grad is not None else None,
                                   loss_sum.data_ptr(), n, eps, grad_scale, _stream()), "refid_charbonnier")
     return loss_sum
+
+
+def psnr_loss(pred, gt, grad=None, weight=1.0):
+    """PSNRLoss (losses.py:95-120) of (B, ...) tensors; returns the 1-element double device tensor holding the loss."""
+    nb = pred.shape[0]
+    per = pred.numel() // nb
+    buf = torch.empty(nb + 1, dtype=torch.float64, device=pred.device)
+    check(lib().refid_psnr_loss(_c(pred, "pred"), _c(gt, "gt"), grad.data_ptr() if grad is not None else None,
+                                buf.data_ptr(), buf[nb:].data_ptr(), nb, per, weight, _stream()), "refid_psnr_loss")
+    return buf[nb:]
 
 
 SQNORM_WORDS = 2049

@@ -370,13 +370,10 @@ class ImageEventRestorationModel(TwoImageEventRecurrentRestorationModel):
     def _loss_and_grad(self, pred):
         if self.pixel_type != "PSNRLoss":
             return super()._loss_and_grad(pred)
-        # PSNRLoss = w * 10/ln10 * mean_b log(mse_b + 1e-8): a (B,C,H,W)-sized elementwise expression, on the GPU
-        scale = 10.0 / math.log(10.0)
-        d = pred - self.gt
-        mse = (d * d).mean(dim=(1, 2, 3))
-        loss = scale * torch.log(mse + 1e-8).mean()
-        coef = self.loss_weight * scale * 2.0 / (d[0].numel() * d.shape[0]) / (mse + 1e-8)
-        return d * coef.view(-1, 1, 1, 1), loss.double().reshape(1), 1
+        # PSNRLoss = w * 10/ln10 * mean_b log(mse_b + 1e-8) and its gradient: two kernels (csrc/train.hip)
+        gpred = torch.empty_like(pred)
+        loss = ops.psnr_loss(pred.contiguous(), self.gt.contiguous(), gpred, weight=self.loss_weight)
+        return gpred, loss, (self.loss_weight or 1.0)        # the kernel's value already carries the weight: l_pix = w * value / w
 
     def test(self):
         self.net_g.eval()

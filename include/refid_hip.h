@@ -152,6 +152,7 @@ int refid_conv_bn(int kh, int kw, int stride, int mode, int cout);
  * that ACCUMULATES into dw/db (gradients of weights shared over the T steps add up,
  * SURVEY.md A.2 first row).
  * ---------------------------------------------------------------------------------- */
+#define REFID_WGRAD_MAX_GROUPS 8
 typedef struct refid_wgrad_desc {
     const float* g;      int ld_g;   int c_o;   /* output-gradient, (n,ho,wo,c_o)       */
     const float* in_a;   const float* in_b;     /* conv input sources, (n,h,w,c_a|c_b)  */
@@ -176,6 +177,14 @@ typedef struct refid_wgrad_desc {
                                                    2 = partial products, ADD into slabs (later steps),
                                                    3 = reduction of the slabs into dw/db only (after BPTT);
                                                    the slab geometry depends on (c_o, i_total), not on c_a/c_b */
+    int groups;                                 /* phases 0-2 (not the thin / 1x1 register tiles): 2..REFID_WGRAD_MAX_GROUPS = this launch also adds the
+                                                   partial products of groups-1 MORE time steps of the same convolution
+                                                   (weights are shared over the T steps; same geometry, pitches and
+                                                   source split): one pass over the slabs instead of one per step.
+                                                   0 / 1 = just (g, in_a, in_b).                                        */
+    const float* g_more[REFID_WGRAD_MAX_GROUPS - 1];
+    const float* in_a_more[REFID_WGRAD_MAX_GROUPS - 1];
+    const float* in_b_more[REFID_WGRAD_MAX_GROUPS - 1];
 } refid_wgrad_desc;
 
 size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d);

@@ -60,6 +60,8 @@ class WgradDesc(C.Structure):
         ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
         ("i_base", C.c_int), ("i_total", C.c_int), ("o_real", C.c_int), ("algo", C.c_int),
         ("phase", C.c_int),
+        ("groups", C.c_int),
+        ("g_more", C.c_void_p * 7), ("in_a_more", C.c_void_p * 7), ("in_b_more", C.c_void_p * 7),
     ]
 
 

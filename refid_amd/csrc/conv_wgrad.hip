@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
     const int xc = ci0 + xq * 4;
     const bool xFromA = xc < a.Ca;
     const bool xcok = xc < a.Ctot;
-    const float* xsrc = xFromA ? a.inA : a.inB;
     const int xld = xFromA ? a.ldA : a.ldB;
+    const int ntAll = a.ntiles * a.groups;             // tiles of all grouped time steps
     const int xcc = xFromA ? xc : xc - a.Ca;
 
     int tdy[C::TPW], tdx[C::TPW];
@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
     f32x4 rg[C::G_ITEMS], rx[C::X_ITEMS];
 
     auto load_tile = [&](int pt) {
-        int t = pt;
+        const int grp = pt / a.ntiles;                  // workgroup-uniform: the time step this tile belongs to
+        const float* gsrc = a.g[grp];
+        const float* xsrc = xFromA ? a.inA[grp] : a.inB[grp];
+        int t = pt - grp * a.ntiles;
         const int tx = t % a.tilesX; t /= a.tilesX;
         const int ty = t % a.tilesY;
         const int n = t / a.tilesY;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
             const int oy = oy0 + p / C::TW, ox = ox0 + p % C::TW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (gcok && p < C::PX && oy < a.Ho && ox < a.Wo)
-                v = *reinterpret_cast<const f32x4*>(a.g + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
+                v = *reinterpret_cast<const f32x4*>(gsrc + ((long long)(n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco);
             rg[it] = v;
         }
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
     };
 
     int pt = split;
-    if (pt < a.ntiles) {
+    if (pt < ntAll) {
         load_tile(pt);
         store_tile();
     }
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
     const int aoff = wr * C::SM * 32 + li;
     const int boff = wc * C::SN * 32 + li;
 
-    for (; pt < a.ntiles; pt += a.nsplit) {
-        const bool more = pt + a.nsplit < a.ntiles;
+    for (; pt < ntAll; pt += a.nsplit) {
+        const bool more = pt + a.nsplit < ntAll;
         if (more) load_tile(pt + a.nsplit);
 
         // All LDS operands of a K step (pixel pair) are read up front, then the MFMAs consume them as they arrive
@@ -680,6 +683,9 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
                 "wgrad: i_base/i_total/o_real inconsistent");
     REFID_CHECK(d->algo == 0 || ((d->algo == 1 || d->algo == 2) && d->kh == 3 && d->kw == 3 && d->stride == 1),
                 "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
+    REFID_CHECK(d->groups <= REFID_WGRAD_MAX_GROUPS, "wgrad: at most %d grouped time steps", REFID_WGRAD_MAX_GROUPS);
+    REFID_CHECK(d->groups <= 1 || (d->phase != 3 && !thin_ok(d) && (d->algo != 0 || p.id != P_PW)),
+                "wgrad: grouped time steps are not implemented by the thin-input and 1x1 register tiles (and mean nothing in phase 3)");
     REFID_CHECK(d->algo != 2 || (p.id == P_W3 && d->pad == 1),
                 "wgrad: algo 2 (bf16 operands) needs more than 32 output and input channels and pad 1");
     if (d->algo == 1) return refid_wgrad_wino_launch(d, st);
@@ -706,8 +712,17 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     }
     const Geo g = geo_of(d, p);
     WgKArgs a;
-    a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;
-    a.inA = d->in_a; a.inB = d->in_b; a.ldA = d->ld_a; a.ldB = d->ld_b;
+    const int ngrp = d->groups > 1 ? d->groups : 1;
+    for (int k = 0; k < REFID_WGRAD_MAX_GROUPS; ++k) {
+        const bool on = k > 0 && k < ngrp;
+        a.g[k] = on ? d->g_more[k - 1] : d->g;
+        a.inA[k] = on ? d->in_a_more[k - 1] : d->in_a;
+        a.inB[k] = on ? d->in_b_more[k - 1] : d->in_b;
+        REFID_CHECK(a.g[k] && a.inA[k] && (d->c_b == 0 || a.inB[k]), "wgrad: null tensor pointer in group %d", k);
+    }
+    a.groups = ngrp;
+    a.ldG = d->ld_g; a.Co = d->c_o;
+    a.ldA = d->ld_a; a.ldB = d->ld_b;
     a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
     a.slabs = d->slabs;
     a.bslabs = d->db ? d->slabs + (size_t)g.nsplit * p.ntaps * g.CoP * g.CiP : nullptr;

@@ -2,9 +2,15 @@
 // every one of them fills the same private slabs [split][tap][CoP][CiP] (+ bias slabs [split][CoP]).
 #pragma once
 
+#include "../../include/refid_hip.h"
+
 struct WgKArgs {
-    const float* g; int ldG, Co;
-    const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
+    // up to REFID_WGRAD_MAX_GROUPS time steps of the same convolution (same geometry): their tiles form one K range, the
+    // slabs are read-modify-written once per group instead of once per step (refid_wgrad_desc.groups)
+    const float* g[REFID_WGRAD_MAX_GROUPS]; const float* inA[REFID_WGRAD_MAX_GROUPS]; const float* inB[REFID_WGRAD_MAX_GROUPS];
+    int groups;
+    int ldG, Co;
+    int ldA, ldB, Ca, Ctot;
     float* slabs; float* bslabs;
     int N, H, W, Ho, Wo, pad;
     int tilesX, tilesY, ntiles, nsplit;

@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgKArgs a) {
     // channel quads beyond the sources (first recurrent step: no second source yet) read a valid dummy address of the
     // first source and are zeroed by the select below
     const bool xFromA = xc < a.Ca || !xcok;
-    const float* xsrc = xFromA ? a.inA : a.inB;
     const int xld = xFromA ? a.ldA : a.ldB;
+    const int ntAll = a.ntiles * a.groups;                 // tiles of all grouped time steps
     const int xcc = xFromA ? xc : xc - a.Ca;
 
     f32x16 acc[9];
@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgKArgs a) {
     f32x4 rg[4], rx[10];
 
     auto load_tile = [&](int pt) {
-        int t = pt;
+        const int grp = pt / a.ntiles;                     // workgroup-uniform: the time step this tile belongs to
+        const float* gsrc = a.g[grp];
+        const float* xsrc = xFromA ? a.inA[grp] : a.inB[grp];
+        int t = pt - grp * a.ntiles;
         const int tx = t % a.tilesX; t /= a.tilesX;
         const int ty = t % a.tilesY;
         const int n = t / a.tilesY;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgKArgs a) {
             const int oy = oy0 + (gpg >> 3), oxb = ox0 + (gpg & 7) * 4;
             // clamped address + select: a per-lane branch around a load makes the compiler wait for it on the spot
             const bool rowok = gcok && oy < a.Ho;
-            const float* base = a.g + ((long long)(n * a.Ho + (rowok ? oy : 0)) * a.Wo) * a.ldG + (gcok ? gco : 0);
+            const float* base = gsrc + ((long long)(n * a.Ho + (rowok ? oy : 0)) * a.Wo) * a.ldG + (gcok ? gco : 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ox = oxb + j;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgKArgs a) {
     };
 
     int pt = split;
-    if (pt < a.ntiles) {
+    if (pt < ntAll) {
         load_tile(pt);
         store_tile();
     }
@@ -138,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgKArgs a) {
     const char* gA = sG + (wr * 32 + li) * GP + kh * 16;            // + kstep * 32 bytes
     const char* xB = sX + (wc * 32 + li) * XP + kh * 16;            // + (kx * CIT) * XP + ((r + ky) * 4 + half * 2) * 16
 
-    for (; pt < a.ntiles; pt += a.nsplit) {
-        const bool more = pt + a.nsplit < a.ntiles;
+    for (; pt < ntAll; pt += a.nsplit) {
+        const bool more = pt + a.nsplit < ntAll;
         if (more) load_tile(pt + a.nsplit);
 #pragma unroll
         for (int ks = 0; ks < TH * 2; ++ks) {                        // 16 pixels per step: row ks / 2, columns (ks & 1) * 16 ..

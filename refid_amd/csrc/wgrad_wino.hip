@@ -27,8 +27,11 @@ constexpr int G_ITEMS = G_TOTAL / 256, X_ITEMS = (X_TOTAL + 255) / 256;
 constexpr int LDS_BYTES = (G_TOTAL + X_TOTAL) * 16 + COT * 4;
 
 struct WwArgs {
-    const float* g; int ldG, Co;
-    const float* inA; const float* inB; int ldA, ldB, Ca, Ctot;
+    // up to REFID_WGRAD_MAX_GROUPS time steps of the same convolution (same geometry): their tiles are one K range
+    const float* g[REFID_WGRAD_MAX_GROUPS]; const float* inA[REFID_WGRAD_MAX_GROUPS]; const float* inB[REFID_WGRAD_MAX_GROUPS];
+    int groups;
+    int ldG, Co;
+    int ldA, ldB, Ca, Ctot;
     float* slabs; float* bslabs;
     int N, H, W, Ho, Wo, pad;
     int tilesX, tilesY, ntiles, nsplit;
@@ -65,7 +68,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     // the input-channel tile lies in one source (host: c_a % 32 == 0 for two sources), so the descriptor is
     // workgroup-uniform; a tile beyond the sources (first recurrent step) keeps a valid descriptor, all lanes out of range
     const bool xFromA = ci0 < a.Ca || ci0 >= a.Ctot;
-    const float* xsrc = xFromA ? a.inA : a.inB;
     const int xld = xFromA ? a.ldA : a.ldB;
     const int xcc = xFromA ? xc : xc - a.Ca;
 
@@ -83,12 +85,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     // (tile origin pixel) * pitch + a per-thread constant; out-of-image pixels / channels get the out-of-range offset
     // and come back as zeros (no per-lane branches around loads, no 64-bit address arithmetic per item).
     const long long gpixAll = (long long)a.N * a.Ho * a.Wo, xpixAll = (long long)a.N * a.H * a.W;
-    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.g), 0, (int)min(gpixAll * a.ldG * 4, 0x7fffffffLL), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(xsrc), 0, (int)min(xpixAll * xld * 4, 0x7fffffffLL), 0x00020000);
+    const int limG = (int)min(gpixAll * a.ldG * 4, 0x7fffffffLL), limX = (int)min(xpixAll * xld * 4, 0x7fffffffLL);
+    const int ntAll = a.ntiles * a.groups;                 // tiles of all grouped time steps
     auto load_tile = [&](int pt) {
-        int t = pt;
+        const int grp = pt / a.ntiles;                     // workgroup-uniform: which time step this tile belongs to
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[grp]), 0, limG, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xFromA ? a.inA[grp] : a.inB[grp]), 0, limX, 0x00020000);
+        int t = pt - grp * a.ntiles;
         const int tx = t % a.tilesX; t /= a.tilesX;
         const int ty = t % a.tilesY;
         const int n = t / a.tilesY;
@@ -130,14 +134,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     };
 
     int pt = split;
-    if (pt < a.ntiles) {
+    if (pt < ntAll) {
         load_tile(pt);
         store_tile();
     }
     __syncthreads();
 
-    for (; pt < a.ntiles; pt += a.nsplit) {
-        const bool more = pt + a.nsplit < a.ntiles;
+    for (; pt < ntAll; pt += a.nsplit) {
+        const bool more = pt + a.nsplit < ntAll;
         if (more) load_tile(pt + a.nsplit);
 
         // 16 K steps per K tile, fully unrolled (every LDS address is base + immediate).  A step pairs the two tile
@@ -320,8 +324,18 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
                     "wgrad (Winograd): tensor too large for 32-bit buffer offsets (use algo 0)");
     }
     WwArgs a;
-    a.g = d->g; a.ldG = d->ld_g; a.Co = d->c_o;
-    a.inA = d->in_a; a.inB = d->in_b; a.ldA = d->ld_a; a.ldB = d->ld_b;
+    const int ngrp = d->groups > 1 ? d->groups : 1;
+    REFID_CHECK(ngrp <= REFID_WGRAD_MAX_GROUPS, "wgrad: at most %d grouped time steps", REFID_WGRAD_MAX_GROUPS);
+    for (int k = 0; k < REFID_WGRAD_MAX_GROUPS; ++k) {
+        const bool on = k > 0 && k < ngrp;
+        a.g[k] = k == 0 ? d->g : (on ? d->g_more[k - 1] : d->g);
+        a.inA[k] = k == 0 ? d->in_a : (on ? d->in_a_more[k - 1] : d->in_a);
+        a.inB[k] = k == 0 ? d->in_b : (on ? d->in_b_more[k - 1] : d->in_b);
+        REFID_CHECK(a.g[k] && a.inA[k] && (d->c_b == 0 || a.inB[k]), "wgrad: null tensor pointer in group %d", k);
+    }
+    a.groups = ngrp;
+    a.ldG = d->ld_g; a.Co = d->c_o;
+    a.ldA = d->ld_a; a.ldB = d->ld_b;
     a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
     a.slabs = d->slabs;
     a.bslabs = d->db ? d->slabs + (size_t)g.nsplit * 16 * g.CoP * g.CiP : nullptr;

@@ -166,6 +166,10 @@ class _SideStreams:
 
 WGRAD_STREAM = _SideStreams()
 WGRAD_BATCH = int(os.environ.get("REFID_WGRAD_BATCH", "8"))     # deferred launches per cross-stream dependency
+# The weight gradients of up to this many consecutive time steps of one conv are ONE launch (the weights are shared over
+# T: their partial-sum slabs -- 134-537 MB of read-modify-write per launch at B=8 -- are then touched once per group
+# instead of once per step; 3x3 and 4x4/stride-2 convs; 1 = off)
+WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 
 
 def flush_wgrads(device):
@@ -279,6 +283,7 @@ class ConvOp:
         self.wslab = None
         self.w_calls = 0
         self.w_last = None
+        self.w_pend = []                      # Winograd weight-gradient calls waiting for their group (WGRAD_GROUP)
 
     def repack(self):
         k = self.k
@@ -359,18 +364,36 @@ class ConvOp:
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci >= 32) else 0
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
+        if WGRAD_GROUP > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):
+            # same source split as the waiting calls (the first recurrent step has no second source yet)?
+            if self.w_pend and (self.w_pend[0][2] is None) != (b is None):
+                self._launch_group()
+            self.w_pend.append((g, a, b))
+            self.w_algo = algo
+            if len(self.w_pend) >= WGRAD_GROUP:
+                self._launch_group()
+            return
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
                                       db=self.gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
                                       slabs=self.wslab)
         self.w_calls += 1
         self.w_last = (g, a, b, algo)
 
+    def _launch_group(self):
+        (g, a, b), more = self.w_pend[0], self.w_pend[1:]
+        self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
+                                      db=self.gb, i_total=self.ci, algo=self.w_algo, phase=1 if self.w_calls == 0 else 2,
+                                      slabs=self.wslab, more=more)
+        self.w_calls += 1
+        self.w_last = (g, a, b, self.w_algo)
+        self.w_pend = []
+
     def finish_wgrad(self):
         """Reduce the accumulated slabs into the parameter gradient (once per step, after BPTT)."""
         side = WGRAD_STREAM.get(self.w.device) if OVERLAP_WGRAD else None
         if side is not None:
             flush_wgrads(self.w.device)                    # this op's launches may still be deferred
-        if self.w_calls == 0:
+        if self.w_calls == 0 and not self.w_pend:
             return
         if side is not None:
             with torch.cuda.stream(side):
@@ -379,6 +402,8 @@ class ConvOp:
             self._finish_wgrad()
 
     def _finish_wgrad(self):
+        if self.w_pend:
+            self._launch_group()                           # the last, possibly shorter, group
         g, a, b, algo = self.w_last
         ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
                          db=self.gb, i_total=self.ci, algo=algo, phase=3, slabs=self.wslab)
@@ -805,7 +830,7 @@ class Engine:
             raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
         WGRAD_STREAM.pending.clear()          # leftovers of a backward that raised must never be launched
         for o in self.all_ops:                # ... nor may its half-filled slabs be added to (phase 2) or reduced
-            o.w_calls, o.w_last = 0, None
+            o.w_calls, o.w_last, o.w_pend = 0, None, []
         self.fold_scratch.zero_()             # folded-weight gradients of THIS backward only (see ConvOp.__init__)
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]

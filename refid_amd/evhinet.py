@@ -239,7 +239,7 @@ class EvhinetEngine:
             raise RefidHipError("backward: no saved forward (call forward(save=True) first)")
         WGRAD_STREAM.pending.clear()          # leftovers of a backward that raised must never be launched
         for o in self.all_ops:                # ... nor may its half-filled slabs be added to / reduced
-            o.w_calls, o.w_last = 0, None
+            o.w_calls, o.w_last, o.w_pend = 0, None, []
         Bn, H, W = c["shape"]
         gout = gout.to(self.device, torch.float32).contiguous()
         g4 = ops.nchw_to_nhwc(gout, _pad4(self.in_chn))

@@ -212,7 +212,7 @@ def _workspace(nbytes, device, kind="wgrad"):
 
 
 def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_base=0, i_total=None, algo=0,
-                 phase=0, slabs=None):
+                 phase=0, slabs=None, more=()):
     """phase 0: one-shot.  phase 1/2: partial products into the caller's persistent `slabs`
     (overwrite / add); phase 3: reduce `slabs` into dw/db (see refid_wgrad_desc).  Returns `slabs`."""
     """dw (+)= wgrad, db (+)= sum g; dw in the reference layout (c_o, i_total, kh, kw)."""
@@ -232,6 +232,17 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     d.o_real = dw.shape[0]
     d.algo = algo
     d.phase = phase
+    # more: up to 3 further (g, in_a, in_b) triples -- other time steps of the same conv, added in the same launch
+    if more:
+        d.groups = 1 + len(more)
+        for k, (g2, a2, b2) in enumerate(more):
+            pg, ldg = _nhwc(g2, "g (group)")
+            pa, lda = _nhwc(a2, "in_a (group)")
+            pb, ldb = _nhwc(b2, "in_b (group)") if b2 is not None else (None, d.ld_b)
+            if g2.shape != g.shape or a2.shape != in_a.shape or (b2 is None) != (in_b is None) or \
+                    (ldg, lda, ldb) != (d.ld_g, d.ld_a, d.ld_b):
+                raise _lib.RefidHipError("wgrad: grouped time steps must share shapes, pitches and the source split")
+            d.g_more[k], d.in_a_more[k], d.in_b_more[k] = pg, pa, pb
     if not dw.is_contiguous() or dw.dim() != 4 or dw.shape[1] != d.i_total or dw.shape[2:] != (kh, kw) \
             or d.o_real > d.c_o:
         raise _lib.RefidHipError(f"wgrad: dw shape {tuple(dw.shape)} does not match g/in channels "
@@ -259,8 +270,9 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     e0.record()
     check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
     e1.record()
-    flops = 2.0 * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
-    nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + d.n * d.ho * d.wo * d.c_o)
+    ngrp = max(1, d.groups)
+    flops = 2.0 * ngrp * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
+    nbytes = 4.0 * ngrp * (d.n * d.h * d.w * (d.c_a + d.c_b) + d.n * d.ho * d.wo * d.c_o)
     PROFILE.append((("wgrad_wino_kernel" if algo == 1 else ("wgrad_bf16_kernel" if algo == 2 else
                                                            f"wgrad_kernel<{kh}x{kw}s{stride}>")), flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None)), nbytes))

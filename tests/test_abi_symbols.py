@@ -63,7 +63,7 @@ def test_struct_layouts_match_the_header():
             if not stmt:
                 continue
             names = re.sub(r"^(const\s+)?(float|int|size_t|refid_pw_extras)\s*\*?", "", stmt)
-            out += [n.strip().lstrip("*").strip() for n in names.split(",")]
+            out += [re.sub(r"\[.*\]$", "", n.strip().lstrip("*").strip()) for n in names.split(",")]
         return out
 
     assert fields("refid_conv_desc") == [f[0] for f in ConvDesc._fields_]

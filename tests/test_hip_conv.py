@@ -743,3 +743,73 @@ def test_bf16_weight_gradient_tile(cfg):
         ops.conv2d_wgrad(nhwc(g), xa, dw1, kh=3, kw=3, stride=1, pad=1, algo=2, phase=3, slabs=s1, i_total=Ca + Cb)
         assert float((dw1[:, :Ca].double().cpu() - w2.grad[:, :Ca]).abs().max()) <= 2e-5 * scale
         assert float(dw1[:, Ca:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 33, 64, 64, 128)])
+def test_winograd_wgrad_grouped_time_steps(cfg):
+    """refid_wgrad_desc.groups: the Winograd weight gradients of several time steps of one conv in ONE launch (the weights
+    are shared over T) == the same calls one by one -- persistent-slab phases included."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    steps = []
+    for t in range(4):
+        x = rnd(N, Ca + Cb, H, W, seed=10 + t)
+        g = rnd(N, Co, H, W, seed=20 + t)
+        steps.append((nhwc(g), nhwc(x[:, :Ca]), nhwc(x[:, Ca:]) if Cb else None))
+    kw = dict(kh=3, kw=3, stride=1, pad=1, algo=1, i_total=Ca + Cb)
+
+    def run(grouping):
+        dw = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")
+        sl, first = None, True
+        for grp in grouping:
+            (g, a, b), more = steps[grp[0]], [steps[i] for i in grp[1:]]
+            sl = ops.conv2d_wgrad(g, a, dw, in_b=b, db=db, phase=1 if first else 2, slabs=sl, more=more, **kw)
+            first = False
+        g, a, b = steps[0]
+        ops.conv2d_wgrad(g, a, dw, in_b=b, db=db, phase=3, slabs=sl, **kw)
+        return dw, db
+
+    dw1, db1 = run([[0], [1], [2], [3]])
+    for grouping in ([[0, 1, 2, 3]], [[0, 1, 2], [3]], [[0], [1, 2, 3]]):
+        dw2, db2 = run(grouping)
+        scale = float(dw1.abs().max())
+        assert float((dw2 - dw1).abs().max()) <= 1e-5 * scale, grouping
+        np.testing.assert_allclose(db2.cpu().numpy(), db1.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(db1.abs().max()))
+    # one-shot (phase 0) grouping
+    dw3 = torch.zeros_like(dw1); db3 = torch.zeros_like(db1)
+    ops.conv2d_wgrad(*steps[0][:2], dw3, in_b=steps[0][2], db=db3, phase=0, more=steps[1:], **kw)
+    assert float((dw3 - dw1).abs().max()) <= 1e-5 * float(dw1.abs().max())
+
+
+@pytest.mark.parametrize("algo,k,stride,cfg", [(0, 3, 1, (2, 16, 32, 32, 0, 32)), (0, 4, 2, (1, 32, 64, 64, 0, 64)),
+                                               (2, 3, 1, (1, 16, 32, 64, 64, 64)), (0, 3, 1, (1, 24, 40, 32, 32, 32))])
+def test_direct_and_bf16_wgrad_grouped_time_steps(algo, k, stride, cfg):
+    """The same grouping for the direct fp32 tiles (3x3 narrow, 4x4 stride 2) and the bf16 tile: 8 time steps in one or
+    three launches == one launch per step."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    pad = 1
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    steps = []
+    for t in range(8):
+        x = rnd(N, Ca + Cb, H, W, seed=10 + t)
+        g = rnd(N, Co, Ho, Wo, seed=30 + t)
+        steps.append((nhwc(g), nhwc(x[:, :Ca]), nhwc(x[:, Ca:]) if Cb else None))
+    kw = dict(kh=k, kw=k, stride=stride, pad=pad, algo=algo, i_total=Ca + Cb)
+
+    def run(grouping):
+        dw = torch.zeros(Co, Ca + Cb, k, k, device="cuda"); db = torch.zeros(Co, device="cuda")
+        sl, first = None, True
+        for grp in grouping:
+            (g, a, b), more = steps[grp[0]], [steps[i] for i in grp[1:]]
+            sl = ops.conv2d_wgrad(g, a, dw, in_b=b, db=db, phase=1 if first else 2, slabs=sl, more=more, **kw)
+            first = False
+        g, a, b = steps[0]
+        ops.conv2d_wgrad(g, a, dw, in_b=b, db=db, phase=3, slabs=sl, **kw)
+        return dw, db
+
+    dw1, db1 = run([[i] for i in range(8)])
+    for grouping in ([list(range(8))], [[0, 1, 2], [3, 4, 5, 6], [7]]):
+        dw2, db2 = run(grouping)
+        assert float((dw2 - dw1).abs().max()) <= 1e-5 * float(dw1.abs().max()), grouping
+        np.testing.assert_allclose(db2.cpu().numpy(), db1.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(db1.abs().max()))

@@ -314,6 +314,7 @@ def main(argv=None):
         # every kernel alone on one stream (same as REFID_OVERLAP_WGRAD=0).
         from refid_amd import engine as _engine
         overlap, _engine.OVERLAP_WGRAD = _engine.OVERLAP_WGRAD, False
+        pipeline, _engine.PIPELINE = _engine.PIPELINE, False
         if hasattr(model, "set_graph_mode"):
             model.set_graph_mode(False)
         if rank == 0:
@@ -323,6 +324,7 @@ def main(argv=None):
         model.optimize_parameters(it)
         torch.cuda.synchronize()
         _engine.OVERLAP_WGRAD = overlap
+        _engine.PIPELINE = pipeline
         if rank == 0:
             prof, ops.PROFILE = ops.PROFILE, None
             agg = {}

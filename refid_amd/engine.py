@@ -143,6 +143,16 @@ OVERLAP_WGRAD = os.environ.get("REFID_OVERLAP_WGRAD", "1") != "0"
 EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
 
 
+# The forward pass as a WAVEFRONT over HIP streams: EvR level i of step t needs level i-1 of step t and its own state of the
+# previous step; the bottleneck / decoders / pred of step t need step t's encoder outputs and their own states of the previous
+# step.  So level 0 (t+2), level 1 (t+1), level 2 (t) and the decoders (t-1) are independent kernel chains: each gets its own
+# stream, joined by one cross-stream dependency per level and step.  The ramp-up / tail of one chain's launches and the small
+# grids of the deep levels overlap the other chains (B=1: 124 -> 112 ms/step; B=8: < 1 %).  BPTT stays on one stream + the
+# weight-gradient side stream: the same wavefront over BPTT measured SLOWER (B=1 120 ms, B=8 544 ms: the weight-gradient
+# stream then has to wait for every chain).  REFID_PIPELINE=0: one chain.
+PIPELINE = os.environ.get("REFID_PIPELINE", "1") != "0"
+
+
 class _SideStreams:
     def __init__(self):
         self._s = {}
@@ -165,6 +175,8 @@ class _SideStreams:
 
 
 WGRAD_STREAM = _SideStreams()
+DEC_STREAM = _SideStreams()                  # the decoder chain of the forward-sweep pipeline (PIPELINE)
+LV_STREAMS = (_SideStreams(), _SideStreams())   # EvR levels 1 and 2 (level 0 runs on the caller's stream)
 WGRAD_BATCH = int(os.environ.get("REFID_WGRAD_BATCH", "8"))     # deferred launches per cross-stream dependency
 # The weight gradients of up to this many consecutive time steps of one conv are ONE launch (the weights are shared over
 # T: their partial-sum slabs -- 134-537 MB of read-modify-write per launch at B=8 -- are then touched once per group
@@ -748,6 +760,22 @@ class Engine:
         ip_b = self._egaca_img_path(self.enc_b[1].att, xb[0])
         ip_f = self._egaca_img_path(self.enc_f[1].att, xb[0])
 
+        main = torch.cuda.current_stream()
+        lvs = [main, LV_STREAMS[0].get(dev), LV_STREAMS[1].get(dev)] if PIPELINE else [main, main, main]
+        for s_ in lvs[1:]:
+            if s_ is not main:
+                s_.wait_stream(main)                   # image branch, event head: everything issued so far
+
+        def level(L, i, cur, h_prev, Sb_i, ip, st):
+            """EvR level i on its stream, after the producer of `cur` (level i-1 of the same step)."""
+            if lvs[i] is main and i == 0:
+                return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st)
+            if lvs[i] is not lvs[i - 1]:
+                lvs[i].wait_stream(lvs[i - 1])
+                cur.record_stream(lvs[i])
+            with torch.cuda.stream(lvs[i]):
+                return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st)
+
         hb = [None, None, None]
         steps_b = []
         for t in range(T - 1, -1, -1):                                     # arch:172-181
@@ -755,7 +783,7 @@ class Engine:
             sts = []
             for i in range(3):
                 st = {} if save else None
-                cur, hb[i] = self._evr_fwd(self.enc_b[i], cur, xb, hb[i], None, ip_b, st)
+                cur, hb[i] = level(self.enc_b[i], i, cur, hb[i], None, ip_b, st)
                 sts.append(st)
             steps_b.append((t, sts))
         Sb = hb                                                            # aliasing: final states only
@@ -765,16 +793,13 @@ class Engine:
         hf = [None, None, None]
         hd = [None, None, None]
         steps_f = []
-        for t in range(T):                                                 # arch:185-216
-            cur = e_all[t * B:(t + 1) * B]
-            sts, eb = [], []
-            for i in range(3):
-                st = {} if save else None
-                cur, hf[i] = self._evr_fwd(self.enc_f[i], cur, xb, hf[i], Sb[i], ip_f, st)
-                sts.append(st)
-                eb.append(cur)
+        dstream = DEC_STREAM.get(dev) if PIPELINE else None
+        if dstream is not None:
+            dstream.wait_stream(main)                  # xb, head ...: everything issued so far
+
+        def decode(t, eb, sts):
             bs = []
-            z = cur
+            z = eb[2]
             for i, (c1, c2) in enumerate(self.res):                        # arch:199-203, rsm:488-503
                 b0 = ops.add(z, xb[2]) if i == 0 else z
                 b1 = c1.fwd(b0, slope_pre=0.0)
@@ -797,6 +822,26 @@ class Engine:
                              dst_batch_stride=T * self.out_chn * H * W)
             if save:
                 steps_f.append(dict(lv=sts, bs=bs, ds=ds, pi=pi))
+
+        for t in range(T):                                                 # arch:185-216
+            cur = e_all[t * B:(t + 1) * B]
+            sts, eb = [], []
+            for i in range(3):
+                st = {} if save else None
+                cur, hf[i] = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st)
+                sts.append(st)
+                eb.append(cur)
+            if dstream is None:
+                decode(t, eb, sts)
+            else:
+                for i in range(3):
+                    dstream.wait_stream(lvs[i])        # step t's encoder outputs
+                    eb[i].record_stream(dstream)       # (allocated on another stream's pool)
+                with torch.cuda.stream(dstream):
+                    decode(t, eb, sts)
+        for s_ in lvs[1:] + ([dstream] if dstream is not None else []):
+            if s_ is not main:
+                main.wait_stream(s_)
         if save:
             self.ctx = dict(B=B, T=T, H=H, W=W, x_in=x_in, ev_in=ev_in, head=head, e_all=e_all, xb=xb,
                             img_saved=img_saved, ip_b=ip_b, ip_f=ip_f, steps_b=steps_b, steps_f=steps_f, Sb=Sb)

@@ -161,7 +161,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak runs: skip the extra strong-scaling timing")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from captured hipGraphs (auto = off: measured slower than eager launches)")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="fp32 = BASELINE configs[1] (headline); bf16 = config-3 style compute (bf16 MFMA operands)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: --dry-run only")
     ap.add_argument("--dry-run", dest="dry_run", action="store_true",
@@ -351,7 +351,11 @@ def main(argv=None):
             peak = FP32_MFMA_PEAK_TFLOPS
             ach = executed / sec / 1e12
             bound, unit = "mfma", "TFLOP/s"
-            if "bf16" in name:
+            if "split" in name:
+                # split-bf16 tile: `terms` bf16 MFMAs per direct-conv multiply (+ 1/9 for the zero tenth tap of its tap pairs)
+                executed = fl * int(name.split("<")[1].split(">")[0]) * 10.0 / 9.0
+                ach = executed / sec / 1e12
+            if "bf16" in name or "split" in name:
                 # bf16 matrix-core operands: the dense bf16 MFMA peak is 2.5 PFLOP/s (MI355X_MICROARCH.md); such a
                 # tile streams fp32 tensors and is priced against whichever roof it is closer to
                 peak = 2500.0
@@ -387,7 +391,8 @@ def main(argv=None):
             "metric": METRIC, "value": None if args.dry_run else round(frames / dt, 3),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32" if args.dtype == "fp32" else "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 tensors/accumulation, 3x3 conv products as 3 bf16 MFMAs (2^-16)",
+                                          "bf16": "bf16"}[args.dtype], "data": "synthetic",
             "rccl_ranks": world if (use_dist and args.backend == "nccl") else (0 if not use_dist else None),
             "config": {"workload": f"GoPro 11+1 blur-VFI train step, batch {per_gpu}/GPU"
                                    f"{' (global batch ' + str(gbatch) + ' sharded)' if args.scaling == 'strong' else ''}, "

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 3
+#define REFID_ABI_VERSION 4
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -113,7 +113,13 @@ typedef struct refid_conv_desc {
                                                    kc = 8);
                                                    2 = direct tile with bf16 MFMA operands (fp32
                                                    accumulate/epilogue/tensors; w_packed from
-                                                   refid_pack_conv_weights_bf16 with kc doubled)   */
+                                                   refid_pack_conv_weights_bf16 with kc doubled);
+                                                   4 = direct 3x3 / stride-1 tile with SPLIT fp32 operands on
+                                                   the bf16 matrix cores (mode 0; w_packed from
+                                                   refid_pack_conv_weights_split with the same number of
+                                                   planes): every fp32 operand is the exact sum of three bf16
+                                                   numbers, six bf16 MFMAs give the fp32 product to one
+                                                   rounding (see `mfma_terms`)                     */
     int split_k;                                /* small problems (few output tiles, long K): split K over the grid into
                                                    `ws` partial sums + a finishing pass.  0 = never; 1 = decided by the
                                                    per-sample geometry (a sample's bits do not depend on the batch
@@ -124,6 +130,10 @@ typedef struct refid_conv_desc {
                                                    (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
                                                    geometry allows.  Same results bit for bit; 2 measured slower.     */
     const refid_pw_extras* pw;                  /* algo 3 only: fusions around the pointwise conv, or NULL               */
+    int mfma_terms;                             /* algo 4 only: 0 / 6 = three bf16 planes per operand, six products
+                                                   (error <= 2^-23 per product: fp32 class, closer to the fp64 result
+                                                   than the fp32 Winograd tile); 3 = two planes, three products
+                                                   (2^-16 per product: explicit opt-in, still finer than TF32)       */
     float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
                                                    aligned, private to this stream until the call's work has run;
                                                    NULL: never split                                            */
@@ -215,6 +225,13 @@ int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* p
 /* bf16 copy of the same packed layout (RNE), kc = 2 * refid_conv_kc(...); oscale may be NULL. */
 int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* packed_bf16, int role, int o, int i,
                                  int kh, int kw, int kc, int bn, void* stream);
+/* Split-bf16 packing for refid_conv2d algo 4 (3x3, REFID_ROLE_FWD / REFID_ROLE_DGRAD): every weight (times
+ * oscale[row] when given) is written as `planes` bf16 numbers h = rne(v), m = rne(v - h), l = v - h - m (planes = 3:
+ * exact; planes = 2: h, m only), layout [chunk of 8 channels][plane][tap 0..9][rows padded to bn][8] (tap 9 = zeros).
+ * refid_packed_weight_split_bytes gives the buffer size. */
+size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes);
+int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,
+                                  int kh, int kw, int bn, int planes, void* stream);
 int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
 /* After BPTT, turn the gradient of the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r]) of THIS backward pass
  * (gw_folded, gb_folded: private buffers, zero before BPTT) into gradients of (W, b, scale) and ACCUMULATE them:

@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("algo", C.c_int),
         ("split_k", C.c_int), ("wino_tile", C.c_int),
         ("pw", C.POINTER(PwExtras)),
+        ("mfma_terms", C.c_int),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
     ]
 
@@ -65,7 +66,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 3          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 4          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 
@@ -94,6 +95,9 @@ def lib():
     L.refid_conv2d_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]
     L.refid_packed_weight_floats.argtypes = [C.c_int] * 7
     L.refid_packed_weight_floats.restype = C.c_size_t
+    L.refid_packed_weight_split_bytes.restype = C.c_size_t
+    L.refid_packed_weight_split_bytes.argtypes = [C.c_int] * 7
+    L.refid_pack_conv_weights_split.argtypes = [C.c_void_p] * 3 + [C.c_int] * 7 + [C.c_void_p]
     L.refid_pack_conv_weights.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
     L.refid_nchw_to_nhwc.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
     L.refid_nchw_tsum_to_nhwc.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p] + [C.c_int] * 5 + \

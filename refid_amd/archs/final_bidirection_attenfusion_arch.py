@@ -33,8 +33,8 @@ class FinalBidirectionAttenfusion(nn.Module):
         (default, the reference's arithmetic) or 'bf16' (BASELINE config 3: bf16 matrix-core operands for
         the conv forward / input gradients, fp32 everything else)."""
         super().__init__()
-        if compute_dtype not in ('fp32', 'bf16'):
-            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        if compute_dtype not in ('fp32', 'bf16x3', 'bf16'):
+            raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3' or 'bf16', got {compute_dtype!r}")
         self.compute_dtype = compute_dtype
         assert ev_chn > 0 and img_chn > 0 and out_chn > 0                      # arch:45-47
         unsupported = []

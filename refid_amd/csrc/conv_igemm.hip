@@ -470,8 +470,8 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
     REFID_CHECK(d->pw == nullptr || d->algo == 3, "conv2d: pw fusions belong to the pointwise tile (algo 3)");
-    REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3) || (d->algo == 3 && f == F_1x1),
-                "conv2d: algo %d does not fit this geometry (1 = 3x3 stride 1, 3 = 1x1)", d->algo);
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 4) && f == F_3x3) || (d->algo == 3 && f == F_1x1),
+                "conv2d: algo %d does not fit this geometry (1, 4 = 3x3 stride 1, 3 = 1x1)", d->algo);
     REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
     REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
@@ -528,6 +528,11 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
             return refid_launch_pointwise(a, st, &e);
         }
         return refid_launch_pointwise(a, st);
+    }
+    if (d->algo == 4) {
+        static int cus = 0;
+        if (cus == 0) cus = refid_device_cu_count();
+        return refid_launch_split3x3(a, d->mfma_terms ? d->mfma_terms : 6, cus > 0 ? cus : 256, st);
     }
     if (d->algo == 1) {
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");

@@ -1,0 +1,410 @@
+// Direct 3x3 / stride-1 convolution tile with SPLIT fp32 operands on the gfx950 bf16 matrix cores.
+//
+//   out = mask( post( pre(conv3x3(src) + bias) + res ) ),   src = in_a or [in_a | in_b]
+// (same contract, epilogue and two-source input as conv_igemm.hip / conv_wino.hip; serves the forward conv and,
+// on flipped/transposed weights, the input gradient.)
+//
+// Why: the fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 32 MAC/clk/SIMD, the bf16 one (v_mfma_f32_32x32x16_bf16) at
+// 512 -- sixteen times the rate with the same fp32 accumulator.  An fp32 number is EXACTLY the sum of three bf16
+// numbers (8 + 8 + 8 significand bits: h = rne(v), m = rne(v - h), l = v - h - m), so
+//     a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)  + O(2^-24 |ab|)
+// -- six bf16 MFMAs reproduce the fp32 product to one fp32 rounding (the three dropped cross terms are below
+// 2^-24 relative), at 6/16 of the fp32 MFMA's pipe time.  The direct 3x3 conv issues 2.25x the multiplies of
+// Winograd F(2x2,3x3): 2.25 * 6/16 = 0.84 of the Winograd tile's matrix-pipe time, but WITHOUT its per-chunk
+// transforms (VALU + LDS work that does not hide under MFMAs on this chip), without its 16-way weight-fragment
+// traffic, and without the transforms' error amplification -- this tile is closer to the fp64 result than the
+// fp32 Winograd tile is (tests/test_hip_conv.py::test_split_tile_accuracy).  TERMS = 3 keeps the first three
+// products only (two planes per operand, 2^-16 relative: better than TF32, which is what the reference's own GPU
+// path multiplies with by default); it is an explicit opt-in.
+//
+// Mapping (one workgroup = 256 threads = 4 waves, one per SIMD; two workgroups per CU cover each other's staging,
+// barriers, prologue and epilogue -- the regime the trace of the Winograd tile showed to work on this chip):
+//   * workgroup tile = (4*MT) x 32 output pixels x (32*NT) output channels; wave w owns rows w*MT .. of the tile
+//     for all column tiles: MT*NT accumulators of 16 registers.
+//   * K walks input channels in chunks of 8.  The bf16 MFMA's K = 16 is filled with TWO TAPS x 8 channels: lanes
+//     0-31 supply tap 2j, lanes 32-63 tap 2j+1 of the same 8 channels (five steps per chunk, the tenth tap is zero
+//     weights: 10 % of the issued MFMAs, the price of a chunk that is small enough -- 47 KB of LDS -- for two
+//     workgroups per CU).  Per chunk the raw fp32 halo ((4*MT+2) x 34 pixels x 8 channels) is fetched once with
+//     buffer loads (hardware zero fill outside the image), split into its bf16 planes on the way to LDS
+//     ([plane][pixel] 16-byte slots) and re-used by all taps and all output channels; the weights come pre-split
+//     from the pack kernel ([chunk][plane][tap 0..9][cout][8]) and are staged next to it.  A lane's MFMA fragment is
+//     ONE ds_read_b128 (conflict free: consecutive lanes, consecutive slots).
+//   * per step: PL*(MT+NT) LDS reads feed TERMS*MT*NT MFMAs (12 reads : 24 MFMAs at MT=NT=2); measured with
+//     tools/probes/mfma_lds_feed.hip: fragment reads at this density hide completely under bf16 MFMAs with two waves
+//     per SIMD (0.88 of the nominal peak = the same as with no reads at all).  The next chunk's global loads are in
+//     flight during the MFMAs; the split + LDS store sits between two barriers (register double buffering).
+//   * epilogue: each wave turns its accumulator rows around in its own LDS strip (no barrier) so that every
+//     bias / residual / mask load and the store is a contiguous 1 KB per wave instruction.
+#include "common.h"
+#include "conv_args.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int TW = 32;                  // output pixels per tile row
+constexpr int KC = 8;                   // input channels per chunk (x 2 taps = K of one bf16 MFMA)
+constexpr int HWD = TW + 2;
+constexpr int NTH = 256;
+constexpr int NTAP = 10;                // 9 taps + one of zero weights (tap pairs)
+constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
+
+// tools/probes/split_trace.py builds this file with -DREFID_SPLIT_TRACE: every workgroup stamps the 100 MHz wall clock
+// at its phase boundaries (+ the CU it ran on), one chosen workgroup stamps every K-loop phase.  Never in the product build.
+#ifdef REFID_SPLIT_TRACE
+__device__ unsigned long long* g_split_trace = nullptr;
+__device__ unsigned long long* g_split_ktrace = nullptr;
+__device__ int g_split_ktrace_wg = -1;
+#define SPLIT_STAMP(slot)                                                                    \
+    do {                                                                                     \
+        if (g_split_trace && threadIdx.x == 0) g_split_trace[(size_t)blockIdx.x * 8 + (slot)] = wall_clock64(); \
+    } while (0)
+#define SPLIT_KSTAMP(ch, slot)                                                               \
+    do {                                                                                     \
+        if (ktrace && (threadIdx.x & 63) == 0)                                               \
+            g_split_ktrace[(((threadIdx.x >> 6) * 64 + ((ch) & 63)) * 8) + (slot)] = wall_clock64(); \
+    } while (0)
+#else
+#define SPLIT_STAMP(slot) do {} while (0)
+#define SPLIT_KSTAMP(ch, slot) do {} while (0)
+#endif
+
+template <int MT_, int NT_, int PL_>
+struct SCfg {
+    static constexpr int MT = MT_, NT = NT_, PL = PL_;
+    static constexpr int TH = 4 * MT, BN = 32 * NT;
+    static constexpr int HP = (TH + 2) * HWD;               // halo pixels
+    static constexpr int A_SLOTS = HP;                      // per plane: [pixel]
+    static constexpr int B_SLOTS = NTAP * BN;               // per plane: [tap][cout]
+    static constexpr int A_ITEMS = (A_SLOTS + NTH - 1) / NTH;
+    static constexpr int B_ITEMS = (PL * B_SLOTS + NTH - 1) / NTH;
+    static constexpr int C4 = BN / 4;                       // float4 per output pixel
+    static constexpr int XS = C4 + 1;                       // padded pixel pitch of the epilogue strip
+    static constexpr int LDS_LOOP = PL * (A_SLOTS + B_SLOTS) * 16;
+    static constexpr int LDS_EPI = 4 * 32 * XS * 16;
+    static constexpr int LDS_BYTES = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
+};
+
+// v (8 fp32 channels) -> PL bf16 planes; the planes sum to v exactly for PL = 3 and to 2^-17 |v| for PL = 2
+template <int PL>
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (&pl)[PL]) {
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = k < 4 ? v0[k] : v1[k - 4];
+        const __bf16 h = (__bf16)v;
+        p0[k] = h;
+        if (PL >= 2) {
+            const float r = v - (float)h;
+            const __bf16 m = (__bf16)r;
+            p1[k] = m;
+            if (PL == 3) p2[k] = (__bf16)(r - (float)m);
+        }
+    }
+    pl[0] = __builtin_bit_cast(f32x4, p0);
+    if constexpr (PL >= 2) pl[1] = __builtin_bit_cast(f32x4, p1);
+    if constexpr (PL == 3) pl[2] = __builtin_bit_cast(f32x4, p2);
+}
+
+template <int MT, int NT, int PL>
+__global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
+    using C = SCfg<MT, NT, PL>;
+    constexpr int HP = C::HP, BN = C::BN;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* sA = reinterpret_cast<f32x4*>(smem);              // [PL][HP]
+    f32x4* sB = sA + PL * C::A_SLOTS;                        // [PL][10][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+
+    // XCD-aware work mapping (as conv_wino.hip): the channel tiles of one pixel tile run back to back on one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int bt = (slot / a.ncot) * 8 + xcd;
+    if (bt >= a.tilesX * a.tilesY * a.N) return;
+    const int n0 = (slot % a.ncot) * BN;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int n = bt / a.tilesY;
+    const int oy0 = ty * C::TH, ox0 = tx * TW;
+    SPLIT_STAMP(0);
+#ifdef REFID_SPLIT_TRACE
+    const bool ktrace = g_split_ktrace && (int)blockIdx.x == g_split_ktrace_wg;
+    if (g_split_trace && tid == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_split_trace[(size_t)blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
+
+    // ---- loaders: per-thread byte offsets that never change across chunks ----------------------------------
+    const int limA = (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL);
+    const int limB = a.inB ? (int)min((long long)a.N * a.H * a.W * a.ldB * 4, 0x7fffffffLL) : 0;
+    const int wChunk = PL * NTAP * a.CoutPad * 16;           // bytes of packed weights per K chunk
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * wChunk, 0x7fffffffLL), 0x00020000);
+    int voA[C::A_ITEMS], voB[C::A_ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::A_ITEMS; ++it) {
+        const int hp = tid + it * NTH;
+        const int iy = oy0 - a.pad + hp / HWD, ix = ox0 - a.pad + hp % HWD;
+        const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const int pix = (n * a.H + iy) * a.W + ix;
+        voA[it] = ok ? pix * a.ldA * 4 : OOB;
+        voB[it] = ok ? pix * a.ldB * 4 : OOB;
+    }
+    int voW[C::B_ITEMS];
+#pragma unroll
+    for (int it = 0; it < C::B_ITEMS; ++it) {
+        const int s = tid + it * NTH;                        // LDS slot [plane][tap][cout]
+        const int co = s % BN, r = s / BN;                   // r = plane*10 + tap
+        const int row = a.coBase + n0 + co;
+        voW[it] = (s < PL * C::B_SLOTS && row < a.CoutPad) ? (r * a.CoutPad + row) * 16 : OOB;
+    }
+
+    f32x4 ra[C::A_ITEMS][2], rb[C::B_ITEMS];
+    // the 2*A_ITEMS + B_ITEMS loads of a chunk are issued in five parts, one per MFMA step of the previous chunk: a
+    // wave that issues them back to back sits 0.8 us per chunk in the vector-memory issue queue (64 B/clk per CU for
+    // both workgroups' 83 KB: tools/probes/split_trace.py), spread out they cost nothing
+    constexpr int NLD = 2 * C::A_ITEMS + C::B_ITEMS;
+    auto load_part = [&](int ch, int part) {
+        const int c0 = ch * KC;                              // chunk-uniform source: Ca % 8 == 0 for two sources
+        const bool fromA = c0 < a.Ca;
+        const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            if (i * 5 / NLD != part && part >= 0) continue;
+            if (i < 2 * C::A_ITEMS) {
+                const int it = i >> 1;
+                const int vo = fromA ? voA[it] : voB[it];
+                ra[it][i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16 * (i & 1), 0));
+            } else {
+                const int it = i - 2 * C::A_ITEMS;
+                rb[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[it], ch * wChunk, 0));
+            }
+        }
+    };
+    auto load_chunk = [&](int ch) { load_part(ch, -1); };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::A_ITEMS; ++it) {
+            const int hp = tid + it * NTH;
+            f32x4 pl[PL];
+            split8<PL>(ra[it][0], ra[it][1], pl);
+            if (hp < HP) {
+#pragma unroll
+                for (int p = 0; p < PL; ++p) sA[p * HP + hp] = pl[p];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < C::B_ITEMS; ++it) {
+            const int s = tid + it * NTH;
+            if (s < PL * C::B_SLOTS) sB[s] = rb[it];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.f;
+
+    // products kept: (activation plane, weight plane), largest first
+    constexpr int TERMS = (PL == 3) ? 6 : (PL == 2 ? 3 : 1);
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1};
+    constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
+
+    // MFMA step j of a chunk: K = {tap 2j (lanes 0-31), tap 2j+1 (lanes 32-63)} x 8 channels
+    int aoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int t = min(2 * j + kh, 8);                    // the tenth tap has zero weights: any valid address
+        aoff[j] = (wave * MT + t / 3) * HWD + (t % 3) + li;
+    }
+    const f32x4* pB = sB + kh * BN + li;
+
+    load_chunk(0);
+    store_chunk();
+    __syncthreads();
+    SPLIT_STAMP(1);
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const bool more = ch + 1 < a.nchunks;
+        SPLIT_KSTAMP(ch, 0);
+        SPLIT_KSTAMP(ch, 1);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (more) load_part(ch + 1, j);
+            f32x4 af[PL][MT], bf[PL][NT];
+#pragma unroll
+            for (int p = 0; p < PL; ++p) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) af[p][m] = sA[p * C::A_SLOTS + m * HWD + aoff[j]];
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn) bf[p][nn] = pB[(p * NTAP + 2 * j) * BN + nn * 32];
+            }
+#pragma unroll
+            for (int e = 0; e < TERMS; ++e)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nn = 0; nn < NT; ++nn)      // consecutive MFMAs hit different accumulators
+                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, bf[TB[e]][nn]), __builtin_bit_cast(bf16x8, af[TA[e]][m]),
+                            acc[m][nn], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);           // keep the step's loads with the step
+        }
+        SPLIT_KSTAMP(ch, 2);
+        __syncthreads();
+        SPLIT_KSTAMP(ch, 3);
+#ifdef REFID_SPLIT_TRACE
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): separate the load wait from the store phase in the trace
+#endif
+        SPLIT_KSTAMP(ch, 4);
+        if (more) {
+            store_chunk();
+            SPLIT_KSTAMP(ch, 5);
+            __syncthreads();
+        }
+        SPLIT_KSTAMP(ch, 6);
+    }
+    SPLIT_STAMP(2);
+
+    // ---- fused epilogue, coalesced ------------------------------------------------------------------------------
+    // D[cout][pixel]: lane (li = pixel column, kh) holds, per register quad g, output channels 8g + 4kh + {0..3} of
+    // pixel li.  Each wave writes one of its pixel rows into its private LDS strip ([pixel][channel quad], pitch
+    // C4 + 1 slots: conflict free both ways) and reads it back as thread -> (pixel, channel quad) in memory order.
+    constexpr int C4 = C::C4, XS = C::XS;
+    constexpr int EIT = (32 * C4) / 64;
+    f32x4* ex = reinterpret_cast<f32x4*>(smem) + wave * (32 * XS);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + wave * MT + m;
+        // residual / mask of this row are requested before the turn-around so their latency hides behind it
+        f32x4 pres[EIT], pmask[EIT];
+        const bool pre = a.vecOK && (a.res != nullptr || a.mask != nullptr);
+        if (pre) {
+#pragma unroll
+            for (int it = 0; it < EIT; ++it) {
+                const int f = it * 64 + lane;
+                const int c4 = f % C4, px = f / C4;
+                const int ox = ox0 + px, j0 = n0 + c4 * 4;
+                const bool ok = oy < a.Ho && ox < a.Wo && j0 + 3 < a.Cout;
+                const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+                pres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                pmask[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+                if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+                if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+            }
+        }
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = acc[m][nn][4 * g + k];
+                ex[li * XS + nn * 8 + 2 * g + kh] = v;
+            }
+#pragma unroll
+        for (int it = 0; it < EIT; ++it) {
+            const int f = it * 64 + lane;
+            const int c4 = f % C4, px = f / C4;
+            const int ox = ox0 + px, j0 = n0 + c4 * 4;
+            f32x4 v = ex[px * XS + c4];
+            if (oy >= a.Ho || ox >= a.Wo || j0 >= a.Cout) continue;
+            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+            const bool vec = a.vecOK && (j0 + 3 < a.Cout);
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias) {
+                const float* bp = a.bias + a.coBase + j0;
+                if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+            if (vec) {
+                if (a.res) v += pres[it];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                if (a.mask) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] *= (pmask[it][k] > 0.f) ? 1.f : a.slopeMask;
+                }
+                *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (j0 + k >= a.Cout) break;
+                    float tv = v[k];
+                    if (a.res) tv += a.res[op * a.ldR + j0 + k];
+                    tv = lrelu(tv, a.slopePost);
+                    if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                    a.out[op * a.ldO + j0 + k] = tv;
+                }
+            }
+        }
+    }
+    SPLIT_STAMP(3);
+}
+
+template <int MT, int NT, int PL>
+int launch_split(const ConvKArgs& ka, hipStream_t st) {
+    using C = SCfg<MT, NT, PL>;
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL>, C::LDS_BYTES, "conv_split")) return rc;
+    ConvKArgs a = ka;
+    a.tilesX = cdiv(a.Wo, TW);
+    a.tilesY = cdiv(a.Ho, C::TH);
+    a.nchunks = cdiv(a.Ctot, KC);
+    a.ncot = cdiv(a.Cout, C::BN);
+    const int tiles = a.tilesX * a.tilesY * a.N;
+    dim3 grid(cdiv(tiles, 8) * 8 * a.ncot);
+    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL>), grid, dim3(NTH), C::LDS_BYTES, st, a);
+    REFID_LAUNCH_CHECK("conv_split");
+    return 0;
+}
+
+}  // namespace
+
+#ifdef REFID_SPLIT_TRACE
+extern "C" int refid_split_trace_set(unsigned long long* wg_stamps, unsigned long long* k_stamps, int wg) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_trace), &wg_stamps, sizeof(wg_stamps)) != hipSuccess) return 1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_ktrace), &k_stamps, sizeof(k_stamps)) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_split_ktrace_wg), &wg, sizeof(wg)) != hipSuccess;
+}
+#endif
+
+bool refid_split3x3_eligible(const ConvKArgs& a) {
+    const long long lim = 0x7fffffffLL;
+    return a.Ctot % 8 == 0 && (a.inB == nullptr || a.Ca % KC == 0) &&
+           (long long)a.N * a.H * a.W * a.ldA * 4 < lim && (!a.inB || (long long)a.N * a.H * a.W * a.ldB * 4 < lim) &&
+           a.ldA % 4 == 0 && (!a.inB || a.ldB % 4 == 0);
+}
+
+// terms: 6 (three planes per operand: fp32-class products) or 3 (two planes: 2^-16 relative)
+int refid_launch_split3x3(const ConvKArgs& a, int terms, int cus, hipStream_t st) {
+    REFID_CHECK(terms == 1 || terms == 3 || terms == 6, "conv2d: split tile takes 1, 3 or 6 product terms (got %d)", terms);
+    REFID_CHECK(refid_split3x3_eligible(a),
+                "conv2d: split tile needs channel counts that are multiples of 8 and tensors below 2 GiB");
+    const bool wide = a.Cout > 32;
+    // 8-row tiles when they still give every CU its two workgroups, 4-row tiles otherwise
+    const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * a.N * cdiv(a.Cout, wide ? 64 : 32);
+    const bool tall = wg8 >= 2 * cus;
+    if (terms == 6) {
+        if (wide) return tall ? launch_split<2, 2, 3>(a, st) : launch_split<1, 2, 3>(a, st);
+        return tall ? launch_split<2, 1, 3>(a, st) : launch_split<1, 1, 3>(a, st);
+    }
+    if (terms == 3) {
+        if (wide) return tall ? launch_split<2, 2, 2>(a, st) : launch_split<1, 2, 2>(a, st);
+        return tall ? launch_split<2, 1, 2>(a, st) : launch_split<1, 1, 2>(a, st);
+    }
+    if (wide) return tall ? launch_split<2, 2, 1>(a, st) : launch_split<1, 2, 1>(a, st);
+    return tall ? launch_split<2, 1, 1>(a, st) : launch_split<1, 1, 1>(a, st);
+}

@@ -162,6 +162,30 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs p) {
     }
 }
 
+// split-bf16 planes for conv_split.hip: [chunk of 8 channels][plane][tap 0..9][rowsPad][8]; the tenth tap is zero (the
+// tile fills the bf16 MFMA's K = 16 with two taps x 8 channels)
+__global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes) {
+    const int ntp = p.ntaps + 1;
+    const long long total = (long long)p.nchunks * planes * ntp * p.rowsPad * 8;
+    __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long r = e;
+        const int k8 = r % 8; r /= 8;
+        const int row = r % p.rowsPad; r /= p.rowsPad;
+        const int tap = r % ntp; r /= ntp;
+        const int plane = r % planes;
+        const int chunk = r / planes;
+        const int k = chunk * 8 + k8;
+        float v = 0.f;
+        if (tap < p.ntaps && row < p.rows && k < p.K) v = pack_fetch(p, 0, tap, row, k);
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        dst[e] = plane == 0 ? h : (plane == 1 ? m : l);
+    }
+}
+
 int pack_geometry(int role, int o, int i, int kh, int kw, int kc, int bn, PackArgs* p) {
     p->role = role; p->O = o; p->I = i; p->KH = kh; p->KW = kw; p->KC = kc;
     p->ncls = 1;
@@ -212,6 +236,28 @@ extern "C" int refid_pack_conv_weights_bf16(const float* w, const float* oscale,
     const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
     REFID_LAUNCH_CHECK("pack_conv_weights_bf16");
+    return 0;
+}
+
+extern "C" size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes) {
+    PackArgs p;
+    if ((role != REFID_ROLE_FWD && role != REFID_ROLE_DGRAD) || planes < 1 || planes > 3) return 0;
+    if (kh != 3 || kw != 3 || pack_geometry(role, o, i, kh, kw, 8, bn, &p)) return 0;
+    return (size_t)p.nchunks * planes * (p.ntaps + 1) * p.rowsPad * 8 * 2;
+}
+
+extern "C" int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,
+                                             int kh, int kw, int bn, int planes, void* stream) {
+    PackArgs p;
+    REFID_CHECK(w && packed, "pack_split: null pointer");
+    REFID_CHECK(role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD, "pack_split: FWD / DGRAD roles only");
+    REFID_CHECK(planes >= 1 && planes <= 3, "pack_split: 1, 2 or 3 planes (got %d)", planes);
+    REFID_CHECK(kh == 3 && kw == 3, "pack_split: 3x3 kernels only");
+    REFID_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_split: unknown role %d", role);
+    p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
+    const long long total = (long long)p.nchunks * planes * (p.ntaps + 1) * p.rowsPad * 8;
+    hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes);
+    REFID_LAUNCH_CHECK("pack_conv_weights_split");
     return 0;
 }
 

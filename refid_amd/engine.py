@@ -181,6 +181,11 @@ WGRAD_BATCH = int(os.environ.get("REFID_WGRAD_BATCH", "8"))     # deferred launc
 # The weight gradients of up to this many consecutive time steps of one conv are ONE launch (the weights are shared over
 # T: their partial-sum slabs -- 134-537 MB of read-modify-write per launch at B=8 -- are then touched once per group
 # instead of once per step; 3x3 and 4x4/stride-2 convs; 1 = off)
+# Split-bf16 direct 3x3 tile (refid_conv2d algo 4) in the fp32 modes: 0 = never (Winograd fp32 tile), 6 / 3 = that many
+# bf16 products per fp32 product.  compute_dtype "bf16x3" sets 3; "bf16" uses the tile with one product wherever it
+# beats the LDS-staged bf16 tile (single-source convs and every input gradient).  6 is an experiment switch: measured
+# equal to the Winograd tile at best (the bf16 matrix pipe is power limited with real data: DESIGN.md).
+MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
 WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 
 
@@ -200,10 +205,12 @@ def flush_wgrads(device):
 
 class ConvOp:
     """One convolution of the network: geometry + packed weights + the three kernels."""
+    default_split = 0                         # set by Engine.__init__ for the convs it builds (compute_dtype "bf16x3")
 
-    def __init__(self, arena, name, kind="conv", need_dgrad=True, scale_name=None, bf16=False):
+    def __init__(self, arena, name, kind="conv", need_dgrad=True, scale_name=None, bf16=False, split=0):
         self.arena, self.name, self.kind = arena, name, kind
         self.bf16 = bf16
+        self.split = 0                        # product terms of the split-bf16 tile (algo 4) this conv may use
         self.w = arena.p(name + ".weight")
         self.gw = arena.g(name + ".weight")
         self.has_bias = (name + ".bias") in arena.shapes
@@ -287,6 +294,24 @@ class ConvOp:
             self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
             self.wd = torch.empty(ops.packed_weight_floats(self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci),
                                   dtype=pdt, device=dev)
+        # split-bf16 direct tile (algo 4): second packing next to the default one
+        terms = 1 if bf16 else (split or ConvOp.default_split or MFMA_SPLIT)
+        self.wps = self.wds = None
+        if terms and kind == "conv" and k == 3 and self.ci % 8 == 0 and self.co >= 16:
+            self.split = terms
+            planes = {1: 1, 3: 2, 6: 3}[terms]
+            self.s_planes = planes
+            self.sf_bn = ops.conv_bn(3, 3, 1, 0, self.co)
+            self.sf_pad = -(-self.co // self.sf_bn) * self.sf_bn
+            self.wps = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, self.sf_bn, 3, 3, self.co, self.ci, planes) // 2,
+                                   dtype=torch.bfloat16, device=dev)
+            if need_dgrad and self.co % 8 == 0:
+                self.sd_bn = self.d_bn if self.d_algo != 1 else ops.conv_bn(3, 3, 1, 0, min(self.ci, 128))
+                if self.ci == 2 * self.co:
+                    self.sd_bn = ops.conv_bn(3, 3, 1, 0, self.co)
+                self.sd_pad = -(-self.ci // self.sd_bn) * self.sd_bn
+                self.wds = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DGRAD, self.sd_bn, 3, 3, self.co, self.ci, planes) // 2,
+                                       dtype=torch.bfloat16, device=dev)
         self.b_eff = self.b
         if self.scale is not None and self.has_bias:
             self.b_eff = torch.empty_like(self.b)
@@ -303,6 +328,12 @@ class ConvOp:
         pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp, oscale=self.scale)
         if self.wd is not None:
             pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd, oscale=self.scale)
+        if self.wps is not None:
+            ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, planes=self.s_planes,
+                                        out=self.wps, oscale=self.scale)
+        if self.wds is not None:
+            ops.pack_conv_weights_split(self.w, ops.ROLE_DGRAD, self.sd_bn, k, k, self.co, self.ci, planes=self.s_planes,
+                                        out=self.wds, oscale=self.scale)
         if self.scale is not None and self.has_bias:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 
@@ -321,6 +352,11 @@ class ConvOp:
                 out.zero_()
                 out = out[..., :oc]
         kh, kw, st, md = self.f_geo
+        if self.wps is not None and (self.split > 1 or b is None) and a.shape[3] % 8 == 0 and pw is None:
+            # (one product = plain bf16 operands: only where this tile beats the LDS-staged one -- single-source convs)
+            ops.conv2d(a, self.wps, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.co, cout_pad=self.sf_pad, in_b=b,
+                       bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split)
+            return out
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
                    cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post,
                    algo=self.f_algo, pw=pw)
@@ -344,6 +380,10 @@ class ConvOp:
         pad = self.pad if self.kind == "conv" else (1 if self.kind == "down" else 0)
         if self.kind == "conv":
             pad = self.k - 1 - self.pad
+        if self.wds is not None:
+            ops.conv2d(g, self.wds, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.sd_pad, co_base=base,
+                       res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split)
+            return out
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
                    co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo)
         return out
@@ -487,8 +527,12 @@ class Engine:
                  compute_dtype="fp32"):
         if base % 8 != 0:
             raise ValueError("base_num_channels must be a multiple of 8")
-        if compute_dtype not in ("fp32", "bf16"):
-            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        if compute_dtype not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3' or 'bf16', got {compute_dtype!r}")
+        # "bf16x3": fp32 tensors, fp32 accumulation; the 3x3 forward / input-gradient convs multiply on the bf16 matrix
+        # cores with every operand split in two bf16 numbers and three products per fp32 product (2^-16 relative per
+        # product, 64x finer than TF32); weight gradients and everything else as in "fp32".  Explicit opt-in.
+        ConvOp.default_split = 3 if compute_dtype == "bf16x3" else 0
         # "bf16": BASELINE config 3 -- conv forward / input-gradient operands in bf16 on the matrix cores,
         # fp32 accumulation, fp32 master weights, activations, weight gradients, loss, grad-norm, optimizer
         self.compute_dtype = compute_dtype

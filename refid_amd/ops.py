@@ -98,6 +98,28 @@ def pack_conv_weights_bf16(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None)
     return out
 
 
+def packed_weight_split_bytes(role, bn, kh, kw, o, i, planes):
+    return lib().refid_packed_weight_split_bytes(role, o, i, kh, kw, bn, planes)
+
+
+def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscale=None):
+    """Split-bf16 packed weights for conv2d(algo=4): `planes` bf16 numbers per weight (3 = exact, 2 = 2^-17)."""
+    L = lib()
+    nb = L.refid_packed_weight_split_bytes(role, o, i, kh, kw, bn, planes)
+    if nb == 0:
+        raise _lib.RefidHipError("pack_conv_weights_split: bad geometry")
+    if not w.is_contiguous():
+        raise _lib.RefidHipError("pack_conv_weights_split: weight must be contiguous")
+    if out is None:
+        out = torch.empty(nb // 2, dtype=torch.bfloat16, device=w.device)
+    elif out.numel() * out.element_size() != nb:
+        raise _lib.RefidHipError("pack_conv_weights_split: out has the wrong size")
+    check(L.refid_pack_conv_weights_split(w.data_ptr(), oscale.data_ptr() if oscale is not None else None,
+                                          out.data_ptr(), role, o, i, kh, kw, bn, planes, _stream()),
+          "refid_pack_conv_weights_split")
+    return out
+
+
 def _pw_extras(pw, out):
     """refid_pw_extras from a dict of tensors / scalars (see include/refid_hip.h); returns (struct, keep-alive list)."""
     x = _lib.PwExtras()
@@ -127,10 +149,12 @@ def _pw_extras(pw, out):
 
 
 def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_pad, co_base=0,
-           in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0, pw=None):
+           in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0, pw=None,
+           terms=0):
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc.  pw: dict of the pointwise tile's
-    EGACA fusions (refid_pw_extras)."""
+    EGACA fusions (refid_pw_extras); terms: algo 4's product count (0 / 6, or 3)."""
     d = ConvDesc()
+    d.mfma_terms = terms
     if pw is not None:
         if algo != 3:
             raise _lib.RefidHipError("conv2d: pw fusions need the pointwise tile (algo 3)")
@@ -186,6 +210,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
         (", true> [bf16 operands]" if algo == 2 else ">")
     if algo == 1:
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
+    if algo == 4:
+        name = "conv_split_kernel<%d>" % (terms or 6)
     if algo == 3:
         name = "conv_pw_kernel<1, 8>" if cout <= 32 else "conv_pw_kernel<2, 4>"
     opix = d.n * out.shape[1] * out.shape[2]

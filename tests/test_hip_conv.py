@@ -813,3 +813,139 @@ def test_direct_and_bf16_wgrad_grouped_time_steps(algo, k, stride, cfg):
         dw2, db2 = run(grouping)
         assert float((dw2 - dw1).abs().max()) <= 1e-5 * float(dw1.abs().max()), grouping
         np.testing.assert_allclose(db2.cpu().numpy(), db1.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(db1.abs().max()))
+
+
+# ---------------------------------------------------------------------------------------------
+# split-bf16 direct 3x3 tile (algo=4): fp32 operands as sums of bf16 numbers on the bf16 matrix cores
+# ---------------------------------------------------------------------------------------------
+def _split_planes(t, planes):
+    """What the tile multiplies with: the sum of the first `planes` bf16 numbers of every fp32 operand."""
+    t = t.float()
+    acc = torch.zeros_like(t)
+    r = t.clone()
+    for _ in range(planes):
+        h = r.bfloat16().float()
+        acc += h
+        r = r - h
+    return acc.double()
+
+
+def run_split(N, H, W, Ca, Cb, Co, terms, bias=True, res=False, slope_pre=1.0, slope_post=1.0, mask=False, tol=None):
+    ops = _ops()
+    planes = {6: 3, 3: 2, 1: 1}[terms]
+    Ci = Ca + Cb
+    xa = rnd(N, Ca, H, W, seed=1)
+    xb = rnd(N, Cb, H, W, seed=2) if Cb else None
+    w = rnd(Co, Ci, 3, 3, seed=3, scale=1.0 / np.sqrt(Ci * 9))
+    b = rnd(Co, seed=4) if bias else None
+    x = torch.cat([xa, xb], 1) if Cb else xa
+    # x6: the fp32 operands themselves; x1: what a bf16 conv multiplies (the error of the dropped cross terms is
+    # covered by the tolerance for x3)
+    xr, wr = (x, w) if terms != 1 else (_split_planes(x, 1), _split_planes(w, 1))
+    ref = lrelu(F.conv2d(xr, wr, b, 1, 1), slope_pre)
+    r = rnd(N, Co, H, W, seed=5) if res else None
+    if res:
+        ref = ref + r
+    ref = lrelu(ref, slope_post)
+    m = rnd(N, Co, H, W, seed=6) if mask else None
+    if mask:
+        ref = ref * torch.where(m > 0, 1.0, 0.3)
+    bn = ops.conv_bn(3, 3, 1, 0, Co)
+    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_FWD, bn, 3, 3, Co, Ci, planes=planes)
+    Cop = -(-Co // 4) * 4
+    outbuf = torch.full((N, H, W, Cop), 7.0, device="cuda")
+    out = outbuf[..., :Co]
+    ops.conv2d(nhwc(xa), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=-(-Co // bn) * bn, algo=4, terms=terms,
+               in_b=nhwc(xb) if Cb else None, bias=b.float().cuda() if bias else None,
+               res=nhwc(r) if res else None, mask=nhwc(m) if mask else None,
+               slope_pre=slope_pre, slope_post=slope_post, slope_mask=0.3)
+    rtol, atol = tol or (RTOL, ATOL)
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=rtol, atol=atol)
+    if Cop != Co:
+        assert float(outbuf[..., Co:].min()) == 7.0
+
+
+@pytest.mark.parametrize("terms", [6, 3, 1])
+@pytest.mark.parametrize("cfg", [
+    (2, 16, 32, 32, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 128, 128, 128), (1, 12, 20, 64, 0, 256),
+    (2, 16, 16, 32, 32, 32), (1, 5, 3, 64, 0, 64), (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 0, 3), (1, 9, 70, 8, 0, 16),
+    (3, 64, 64, 64, 0, 64),
+])
+def test_split_tile_forward_geometries(cfg, terms):
+    # six products: the fp32 tolerance of this file; three: 2^-16 per product on O(1) sums
+    run_split(*cfg, terms, tol={6: (RTOL, ATOL), 3: (2e-4, 6e-5), 1: (RTOL, ATOL)}[terms])
+
+
+@pytest.mark.parametrize("terms", [6, 1])
+def test_split_tile_fused_epilogues(terms):
+    run_split(1, 16, 32, 64, 0, 64, terms, slope_pre=0.04)
+    run_split(1, 16, 32, 64, 0, 64, terms, res=True)
+    run_split(1, 8, 32, 128, 0, 128, terms, res=True, slope_post=0.0)
+    run_split(1, 8, 32, 64, 64, 64, terms, slope_pre=0.1)
+    run_split(1, 8, 32, 64, 0, 64, terms, bias=False, res=True, mask=True)
+    run_split(1, 40, 32, 32, 0, 32, terms, bias=False, res=True, mask=True)
+
+
+@pytest.mark.parametrize("terms", [6, 3])
+@pytest.mark.parametrize("cfg", [(1, 16, 32, 32, 64), (1, 9, 24, 128, 64), (1, 8, 16, 256, 128)])
+def test_split_tile_dgrad(cfg, terms):
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
+    g = rnd(N, Co, H, W, seed=3)
+    F.conv2d(x, w, None, 1, 1).backward(g)
+    bn = ops.conv_bn(3, 3, 1, 0, min(Ci, 128))
+    wd = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_DGRAD, bn, 3, 3, Co, Ci, planes={6: 3, 3: 2}[terms])
+    rp = -(-Ci // bn) * bn
+    gd = nhwc(g)
+    rtol, atol = (RTOL, ATOL) if terms == 6 else (2e-4, 2e-4)
+    out = torch.empty(N, H, W, Ci, device="cuda")
+    ops.conv2d(gd, wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=rp, algo=4, terms=terms)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=rtol, atol=atol)
+    if Ci >= 64:        # row-range issue (two-source convs): second half of the rows
+        half = Ci // 2
+        o2 = torch.empty(N, H, W, half, device="cuda")
+        ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=rp, co_base=half, algo=4, terms=terms)
+        np.testing.assert_allclose(nchw(o2).numpy(), x.grad[:, half:].numpy(), rtol=rtol, atol=atol)
+
+
+def test_split_tile_accuracy_classes():
+    """Largest deviation from the fp64 convolution, K = 9 x 256: six products sit in the fp32 class (with the Winograd
+    tile, both a few 1e-6 on O(1) sums), three products at ~3e-5, one product (plain bf16 operands) at ~1e-2."""
+    ops = _ops()
+    N, H, W, Ci, Co = 1, 32, 64, 256, 64
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=3.0 / np.sqrt(Ci * 9))
+    ref = F.conv2d(x, w, None, 1, 1)
+    xd = nhwc(x)
+    errs = {}
+    for terms in (6, 3, 1):
+        wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_FWD, 64, 3, 3, Co, Ci, planes={6: 3, 3: 2, 1: 1}[terms])
+        out = torch.empty(N, H, W, Co, device="cuda")
+        ops.conv2d(xd, wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=64, algo=4, terms=terms)
+        errs[terms] = float((nchw(out) - ref).abs().max())
+    ww = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+    out = torch.empty(N, H, W, Co, device="cuda")
+    ops.conv2d(xd, ww, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=64, algo=1)
+    errs["wino"] = float((nchw(out) - ref).abs().max())
+    scale = float(ref.abs().max())
+    assert errs[6] < 4e-6 * scale and errs["wino"] < 4e-6 * scale, errs
+    assert errs[6] < errs[3] < errs[1], errs
+    assert errs[3] < 4e-5 * scale and errs[1] > 1e-3 * scale, errs
+
+
+def test_split_tile_rejects_bad_arguments():
+    ops = _ops()
+    from refid_amd._lib import RefidHipError
+    w = torch.randn(64, 36, 3, 3, device="cuda")
+    x = torch.randn(1, 8, 32, 36, device="cuda")
+    out = torch.empty(1, 8, 32, 64, device="cuda")
+    wp = ops.pack_conv_weights_split(w, ops.ROLE_FWD, 64, 3, 3, 64, 36, planes=3)
+    with pytest.raises(RefidHipError, match="multiples of 8"):
+        ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=64, cout_pad=64, algo=4)
+    x = torch.randn(1, 8, 32, 32, device="cuda")
+    with pytest.raises(RefidHipError, match="1, 3 or 6"):
+        ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=64, cout_pad=64, algo=4, terms=4)
+    with pytest.raises(RefidHipError):
+        ops.pack_conv_weights_split(torch.randn(64, 32, 5, 5, device="cuda"), ops.ROLE_FWD, 64, 5, 5, 64, 32, planes=3)

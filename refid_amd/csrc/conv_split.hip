@@ -47,6 +47,7 @@ constexpr int HWD = TW + 2;
 constexpr int NTH = 256;
 constexpr int NTAP = 10;                // 9 taps + one of zero weights (tap pairs)
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
+__device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
 // tools/probes/split_trace.py builds this file with -DREFID_SPLIT_TRACE: every workgroup stamps the 100 MHz wall clock
 // at its phase boundaries (+ the CU it ran on), one chosen workgroup stamps every K-loop phase.  Never in the product build.
@@ -68,9 +69,9 @@ __device__ int g_split_ktrace_wg = -1;
 #define SPLIT_KSTAMP(ch, slot) do {} while (0)
 #endif
 
-template <int MT_, int NT_, int PL_>
+template <int MT_, int NT_, int PL_, int KS_>
 struct SCfg {
-    static constexpr int MT = MT_, NT = NT_, PL = PL_;
+    static constexpr int MT = MT_, NT = NT_, PL = PL_, KS = KS_;   // KS: 8-channel sub-chunks per LDS stage (barrier pair)
     static constexpr int TH = 4 * MT, BN = 32 * NT;
     static constexpr int HP = (TH + 2) * HWD;               // halo pixels
     static constexpr int A_SLOTS = HP;                      // per plane: [pixel]
@@ -79,7 +80,7 @@ struct SCfg {
     static constexpr int B_ITEMS = (PL * B_SLOTS + NTH - 1) / NTH;
     static constexpr int C4 = BN / 4;                       // float4 per output pixel
     static constexpr int XS = C4 + 1;                       // padded pixel pitch of the epilogue strip
-    static constexpr int LDS_LOOP = PL * (A_SLOTS + B_SLOTS) * 16;
+    static constexpr int LDS_LOOP = KS * PL * (A_SLOTS + B_SLOTS) * 16;
     static constexpr int LDS_EPI = 4 * 32 * XS * 16;
     static constexpr int LDS_BYTES = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 };
@@ -105,13 +106,13 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (
     if constexpr (PL == 3) pl[2] = __builtin_bit_cast(f32x4, p2);
 }
 
-template <int MT, int NT, int PL>
+template <int MT, int NT, int PL, int KS>
 __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
-    using C = SCfg<MT, NT, PL>;
+    using C = SCfg<MT, NT, PL, KS>;
     constexpr int HP = C::HP, BN = C::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4* sA = reinterpret_cast<f32x4*>(smem);              // [PL][HP]
-    f32x4* sB = sA + PL * C::A_SLOTS;                        // [PL][10][BN]
+    f32x4* sA = reinterpret_cast<f32x4*>(smem);              // [KS][PL][HP]
+    f32x4* sB = sA + KS * PL * C::A_SLOTS;                   // [KS][PL][10][BN]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     const int limB = a.inB ? (int)min((long long)a.N * a.H * a.W * a.ldB * 4, 0x7fffffffLL) : 0;
     const int wChunk = PL * NTAP * a.CoutPad * 16;           // bytes of packed weights per K chunk
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * wChunk, 0x7fffffffLL), 0x00020000);
+        const_cast<float*>(a.w), 0, (int)min((long long)cdiv_dev(a.Ctot, KC) * wChunk, 0x7fffffffLL), 0x00020000);
     int voA[C::A_ITEMS], voB[C::A_ITEMS];
 #pragma unroll
     for (int it = 0; it < C::A_ITEMS; ++it) {
@@ -162,46 +163,53 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
         voW[it] = (s < PL * C::B_SLOTS && row < a.CoutPad) ? (r * a.CoutPad + row) * 16 : OOB;
     }
 
-    f32x4 ra[C::A_ITEMS][2], rb[C::B_ITEMS];
-    // the 2*A_ITEMS + B_ITEMS loads of a chunk are issued in five parts, one per MFMA step of the previous chunk: a
-    // wave that issues them back to back sits 0.8 us per chunk in the vector-memory issue queue (64 B/clk per CU for
-    // both workgroups' 83 KB: tools/probes/split_trace.py), spread out they cost nothing
+    f32x4 ra[KS][C::A_ITEMS][2], rb[KS][C::B_ITEMS];
+    // the KS * (2*A_ITEMS + B_ITEMS) loads of a stage are issued in 5*KS parts, one per MFMA step of the previous stage
+    // (a wave that issues them back to back sits in the vector-memory issue queue: tools/probes/split_trace.py)
     constexpr int NLD = 2 * C::A_ITEMS + C::B_ITEMS;
     auto load_part = [&](int ch, int part) {
-        const int c0 = ch * KC;                              // chunk-uniform source: Ca % 8 == 0 for two sources
-        const bool fromA = c0 < a.Ca;
-        const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            if (i * 5 / NLD != part && part >= 0) continue;
-            if (i < 2 * C::A_ITEMS) {
-                const int it = i >> 1;
-                const int vo = fromA ? voA[it] : voB[it];
-                ra[it][i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16 * (i & 1), 0));
-            } else {
-                const int it = i - 2 * C::A_ITEMS;
-                rb[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[it], ch * wChunk, 0));
+        for (int sub = 0; sub < KS; ++sub) {
+            const int c0 = (ch * KS + sub) * KC;             // sub-chunk-uniform source: Ca % 8 == 0 for two sources
+            const bool fromA = c0 < a.Ca;
+            const bool cok = c0 < a.Ctot;                    // past the last channel: zeros (weights: buffer range check)
+            const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) {
+                if ((sub * NLD + i) * 5 / NLD != part && part >= 0) continue;
+                if (i < 2 * C::A_ITEMS) {
+                    const int it = i >> 1;
+                    const int vo = cok ? (fromA ? voA[it] : voB[it]) : OOB;
+                    ra[sub][it][i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16 * (i & 1), 0));
+                } else {
+                    const int it = i - 2 * C::A_ITEMS;
+                    rb[sub][it] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[it], (ch * KS + sub) * wChunk, 0));
+                }
             }
         }
     };
     auto load_chunk = [&](int ch) { load_part(ch, -1); };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int it = 0; it < C::A_ITEMS; ++it) {
-            const int hp = tid + it * NTH;
-            f32x4 pl[PL];
-            split8<PL>(ra[it][0], ra[it][1], pl);
-            if (hp < HP) {
+        for (int sub = 0; sub < KS; ++sub) {
 #pragma unroll
-                for (int p = 0; p < PL; ++p) sA[p * HP + hp] = pl[p];
+            for (int it = 0; it < C::A_ITEMS; ++it) {
+                const int hp = tid + it * NTH;
+                f32x4 pl[PL];
+                split8<PL>(ra[sub][it][0], ra[sub][it][1], pl);
+                if (hp < HP) {
+#pragma unroll
+                    for (int p = 0; p < PL; ++p) sA[(sub * PL + p) * HP + hp] = pl[p];
+                }
             }
-        }
 #pragma unroll
-        for (int it = 0; it < C::B_ITEMS; ++it) {
-            const int s = tid + it * NTH;
-            if (s < PL * C::B_SLOTS) sB[s] = rb[it];
+            for (int it = 0; it < C::B_ITEMS; ++it) {
+                const int s = tid + it * NTH;
+                if (s < PL * C::B_SLOTS) sB[sub * PL * C::B_SLOTS + s] = rb[sub][it];
+            }
         }
     };
 
@@ -237,15 +245,16 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
         SPLIT_KSTAMP(ch, 0);
         SPLIT_KSTAMP(ch, 1);
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            if (more) load_part(ch + 1, j);
+        for (int sj = 0; sj < 5 * KS; ++sj) {
+            const int sub = sj / 5, j = sj % 5;
+            if (more) load_part(ch + 1, sj);
             f32x4 af[PL][MT], bf[PL][NT];
 #pragma unroll
             for (int p = 0; p < PL; ++p) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[p][m] = sA[p * C::A_SLOTS + m * HWD + aoff[j]];
+                for (int m = 0; m < MT; ++m) af[p][m] = sA[(sub * PL + p) * C::A_SLOTS + m * HWD + aoff[j]];
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) bf[p][nn] = pB[(p * NTAP + 2 * j) * BN + nn * 32];
+                for (int nn = 0; nn < NT; ++nn) bf[p][nn] = pB[((sub * PL + p) * NTAP + 2 * j) * BN + nn * 32];
             }
 #pragma unroll
             for (int e = 0; e < TERMS; ++e)
@@ -354,21 +363,30 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     SPLIT_STAMP(3);
 }
 
-template <int MT, int NT, int PL>
+template <int MT, int NT, int PL, int KS>
 int launch_split(const ConvKArgs& ka, hipStream_t st) {
-    using C = SCfg<MT, NT, PL>;
+    using C = SCfg<MT, NT, PL, KS>;
     static std::atomic<unsigned long long> attr_done{0};
-    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL>, C::LDS_BYTES, "conv_split")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL, KS>, C::LDS_BYTES, "conv_split")) return rc;
     ConvKArgs a = ka;
     a.tilesX = cdiv(a.Wo, TW);
     a.tilesY = cdiv(a.Ho, C::TH);
-    a.nchunks = cdiv(a.Ctot, KC);
+    a.nchunks = cdiv(a.Ctot, KC * KS);
     a.ncot = cdiv(a.Cout, C::BN);
     const int tiles = a.tilesX * a.tilesY * a.N;
     dim3 grid(cdiv(tiles, 8) * 8 * a.ncot);
-    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL>), grid, dim3(NTH), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL, KS>), grid, dim3(NTH), C::LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_split");
     return 0;
+}
+
+// stage depth KS = 1: deeper stages (2 sub-chunks for two planes, 4 for one: fewer barriers, same LDS as three planes)
+// measured 4-8 % SLOWER on every shape -- the barrier pair is not what the short stages wait for
+template <int PL>
+int launch_split_pl(const ConvKArgs& a, bool wide, bool tall, hipStream_t st) {
+    constexpr int KS = 1;
+    if (wide) return tall ? launch_split<2, 2, PL, KS>(a, st) : launch_split<1, 2, PL, KS>(a, st);
+    return tall ? launch_split<2, 1, PL, KS>(a, st) : launch_split<1, 1, PL, KS>(a, st);
 }
 
 }  // namespace
@@ -397,14 +415,7 @@ int refid_launch_split3x3(const ConvKArgs& a, int terms, int cus, hipStream_t st
     // 8-row tiles when they still give every CU its two workgroups, 4-row tiles otherwise
     const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * a.N * cdiv(a.Cout, wide ? 64 : 32);
     const bool tall = wg8 >= 2 * cus;
-    if (terms == 6) {
-        if (wide) return tall ? launch_split<2, 2, 3>(a, st) : launch_split<1, 2, 3>(a, st);
-        return tall ? launch_split<2, 1, 3>(a, st) : launch_split<1, 1, 3>(a, st);
-    }
-    if (terms == 3) {
-        if (wide) return tall ? launch_split<2, 2, 2>(a, st) : launch_split<1, 2, 2>(a, st);
-        return tall ? launch_split<2, 1, 2>(a, st) : launch_split<1, 1, 2>(a, st);
-    }
-    if (wide) return tall ? launch_split<2, 2, 1>(a, st) : launch_split<1, 2, 1>(a, st);
-    return tall ? launch_split<2, 1, 1>(a, st) : launch_split<1, 1, 1>(a, st);
+    if (terms == 6) return launch_split_pl<3>(a, wide, tall, st);
+    if (terms == 3) return launch_split_pl<2>(a, wide, tall, st);
+    return launch_split_pl<1>(a, wide, tall, st);
 }

@@ -143,6 +143,31 @@ def test_bf16_compute_path_psnr_parity(golden_dir):
     assert int((gn == 0).sum()) == 13
 
 
+def test_bf16x3_compute_path_stays_inside_the_fp32_bar(golden_dir):
+    """compute_dtype 'bf16x3' (opt-in): 3x3 forward / input-gradient products as three bf16 MFMAs (2^-16 per product), fp32
+    tensors and accumulation.  Outputs still meet the north-star bar against the reference's fp32 fixture (rtol 1e-3 /
+    atol 1e-4), loss to 1e-5, every gradient tensor to 1 % of its norm; PSNR against the fp32 output > 90 dB."""
+    from refid_amd.archs import define_network
+    z, P, x, ev, gt, img_chn, base = load(golden_dir, "full26_train")
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=3,
+                              base_num_channels=base, num_block=1, num_residual_blocks=2, compute_dtype="bf16x3"))
+    net.load_state_dict(P, strict=True)
+    net = net.cuda()
+    assert any(getattr(o, "split", 0) == 3 for o in net.engine.all_ops)
+    pred = net(x=x.cuda(), event=ev.cuda())
+    ref = torch.from_numpy(z["out"])
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-4)
+    assert O.psnr_between(pred.detach().cpu(), ref) > 90.0
+    loss = torch.sqrt((pred - gt.cuda()) ** 2 + 1e-12).mean()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(z["loss"]), rtol=1e-5)
+    gn = np.array([float(p.grad.norm()) for _, p in net.named_parameters()])
+    ref_gn = z["grad_norms_all"]
+    big = ref_gn > 1e-3 * ref_gn.max()
+    np.testing.assert_allclose(gn[big], ref_gn[big], rtol=0.01)
+    assert int((gn == 0).sum()) == 13
+
+
 def test_gradient_accumulation_over_two_backward_calls(golden_dir):
     """gradients delivered through autograd ACCUMULATE like any module's -- including the EGACA
     convs whose beta/gamma are folded into the packed weights (their un-fold must never rescale what is already

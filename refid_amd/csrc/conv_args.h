@@ -32,7 +32,7 @@ bool refid_wino3x3_p_eligible(const ConvKArgs& a, int cus);
 int refid_launch_wino3x3_p(const ConvKArgs& a, int cus, hipStream_t st);
 // conv_split.hip: direct 3x3 tile with split-bf16 operands (algo 4); terms = 6 (fp32-class products) or 3
 bool refid_split3x3_eligible(const ConvKArgs& a);
-int refid_launch_split3x3(const ConvKArgs& a, int terms, int cus, hipStream_t st);
+int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipStream_t st);
 // conv_pw.hip
 // Fusions around a pointwise conv (refid_pw_extras in refid_hip.h): EGACA's LayerNorm2d prologue, the squeeze-excite
 // vector computed in the kernel and applied to the operand, second residual, GELU second output.

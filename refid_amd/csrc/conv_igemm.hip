@@ -470,8 +470,10 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
     REFID_CHECK(d->pw == nullptr || d->algo == 3, "conv2d: pw fusions belong to the pointwise tile (algo 3)");
-    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 4) && f == F_3x3) || (d->algo == 3 && f == F_1x1),
-                "conv2d: algo %d does not fit this geometry (1, 4 = 3x3 stride 1, 3 = 1x1)", d->algo);
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3) || (d->algo == 3 && f == F_1x1) ||
+                    (d->algo == 4 && (f == F_3x3 || f == F_4x4s2 || f == F_downDgrad)),
+                "conv2d: algo %d does not fit this geometry (1 = 3x3 stride 1, 3 = 1x1, 4 = 3x3 stride 1 / 4x4 stride 2 and its "
+                "input gradient)", d->algo);
     REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
     REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
@@ -532,7 +534,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     if (d->algo == 4) {
         static int cus = 0;
         if (cus == 0) cus = refid_device_cu_count();
-        return refid_launch_split3x3(a, d->mfma_terms ? d->mfma_terms : 6, cus > 0 ? cus : 256, st);
+        REFID_CHECK(d->pad == 1, "conv2d: the split tile's geometries all have pad 1");
+        return refid_launch_split3x3(a, d->mfma_terms ? d->mfma_terms : 6, f == F_3x3 ? 0 : (f == F_4x4s2 ? 1 : 2),
+                                     cus > 0 ? cus : 256, st);
     }
     if (d->algo == 1) {
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");

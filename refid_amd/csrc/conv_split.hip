@@ -43,9 +43,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int TW = 32;                  // output pixels per tile row
 constexpr int KC = 8;                   // input channels per chunk (x 2 taps = K of one bf16 MFMA)
-constexpr int HWD = TW + 2;
 constexpr int NTH = 256;
-constexpr int NTAP = 10;                // 9 taps + one of zero weights (tap pairs)
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 __device__ __forceinline__ int cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 
@@ -69,11 +67,23 @@ __device__ int g_split_ktrace_wg = -1;
 #define SPLIT_KSTAMP(ch, slot) do {} while (0)
 #endif
 
-template <int MT_, int NT_, int PL_, int KS_>
+// MODE 0: 3x3 / stride 1 (9 taps + a tenth of zero weights = 5 tap pairs per 8-channel sub-chunk).
+// MODE 1: 4x4 / stride 2 / pad 1 (`conv_down` forward, recurrent_sub_modules.py:12-14) as a 2x2 / stride-1 conv over 2x2
+//         input BLOCKS that start at odd coordinates (block b = rows 2b-1, 2b): output row oy reads rows 2oy-1 .. 2oy+2 =
+//         blocks oy, oy+1, so K = 4 block taps x (4 positions inside a block x C channels) with no padding taps.  A stage
+//         holds the two column positions (KS = 2) of one row position of 8 channels; the block gather is address
+//         arithmetic in the loader.
+// MODE 2: input gradient of conv_down: four output-parity classes (blockIdx.y), each a 2x2-tap stride-1 conv over the
+//         output gradient with its own weights; output pixels (2y+py, 2x+px).
+template <int MT_, int NT_, int PL_, int KS_, int MODE_>
 struct SCfg {
     static constexpr int MT = MT_, NT = NT_, PL = PL_, KS = KS_;   // KS: 8-channel sub-chunks per LDS stage (barrier pair)
+    static constexpr int MODE = MODE_;
     static constexpr int TH = 4 * MT, BN = 32 * NT;
-    static constexpr int HP = (TH + 2) * HWD;               // halo pixels
+    static constexpr int HWD = (MODE == 1) ? TW + 1 : TW + 2;
+    static constexpr int NTAP = (MODE == 0) ? 10 : 4;        // taps per sub-chunk in LDS / packed weights
+    static constexpr int NSTEP = NTAP / 2;                   // MFMA steps (tap pairs) per sub-chunk
+    static constexpr int HP = ((MODE == 1) ? TH + 1 : TH + 2) * HWD;   // halo pixels (MODE 1: input blocks)
     static constexpr int A_SLOTS = HP;                      // per plane: [pixel]
     static constexpr int B_SLOTS = NTAP * BN;               // per plane: [tap][cout]
     static constexpr int A_ITEMS = (A_SLOTS + NTH - 1) / NTH;
@@ -106,10 +116,11 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (
     if constexpr (PL == 3) pl[2] = __builtin_bit_cast(f32x4, p2);
 }
 
-template <int MT, int NT, int PL, int KS>
+template <int MT, int NT, int PL, int KS, int MODE>
 __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
-    using C = SCfg<MT, NT, PL, KS>;
-    constexpr int HP = C::HP, BN = C::BN;
+    using C = SCfg<MT, NT, PL, KS, MODE>;
+    constexpr int HP = C::HP, BN = C::BN, HWD = C::HWD, NTAP = C::NTAP, NSTEP = C::NSTEP;
+    static_assert(MODE != 1 || KS == 2, "MODE 1: a stage = the two column positions of a block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sA = reinterpret_cast<f32x4*>(smem);              // [KS][PL][HP]
     f32x4* sB = sA + KS * PL * C::A_SLOTS;                   // [KS][PL][10][BN]
@@ -141,18 +152,38 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     // ---- loaders: per-thread byte offsets that never change across chunks ----------------------------------
     const int limA = (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL);
     const int limB = a.inB ? (int)min((long long)a.N * a.H * a.W * a.ldB * 4, 0x7fffffffLL) : 0;
-    const int wChunk = PL * NTAP * a.CoutPad * 16;           // bytes of packed weights per K chunk
+    const int wChunk = PL * NTAP * a.CoutPad * 16;           // bytes of packed weights per 8-channel sub-chunk
+    const int nsub = cdiv_dev(a.Ctot, KC) * (MODE == 1 ? 4 : 1);      // sub-chunks of the whole K
+    const int cls = (MODE == 2) ? blockIdx.y : 0;            // MODE 2: output parity class (py, px)
+    const int py = cls >> 1, px = cls & 1;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), 0, (int)min((long long)cdiv_dev(a.Ctot, KC) * wChunk, 0x7fffffffLL), 0x00020000);
-    int voA[C::A_ITEMS], voB[C::A_ITEMS];
+        reinterpret_cast<char*>(const_cast<float*>(a.w)) + (long long)cls * nsub * wChunk, 0,
+        (int)min((long long)nsub * wChunk, 0x7fffffffLL), 0x00020000);
+    // MODE 0 / 2: voA / voB[it] = the halo pixel of item `it` in source A / B.  MODE 1: voA[it] / voB[it] = the pixel at
+    // ROW position sy = 0 / 1 of halo block `it`, column position 0; vo1x[sy][it] = column position 1 (validity differs)
+    int voA[C::A_ITEMS], voB[C::A_ITEMS], vo1x[2][MODE == 1 ? C::A_ITEMS : 1];
 #pragma unroll
     for (int it = 0; it < C::A_ITEMS; ++it) {
         const int hp = tid + it * NTH;
-        const int iy = oy0 - a.pad + hp / HWD, ix = ox0 - a.pad + hp % HWD;
-        const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const int pix = (n * a.H + iy) * a.W + ix;
-        voA[it] = ok ? pix * a.ldA * 4 : OOB;
-        voB[it] = ok ? pix * a.ldB * 4 : OOB;
+        if constexpr (MODE == 1) {
+            const int r0 = 2 * (oy0 + hp / HWD) - 1, c0 = 2 * (ox0 + hp % HWD) - 1;
+#pragma unroll
+            for (int sy = 0; sy < 2; ++sy)
+#pragma unroll
+                for (int sx = 0; sx < 2; ++sx) {
+                    const int iy = r0 + sy, ix = c0 + sx;
+                    const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    const int vo = ok ? ((n * a.H + iy) * a.W + ix) * a.ldA * 4 : OOB;
+                    if (sx == 0) (sy ? voB[it] : voA[it]) = vo;
+                    else vo1x[sy][it] = vo;
+                }
+        } else {
+            const int iy = oy0 - 1 + hp / HWD, ix = ox0 - 1 + hp % HWD;
+            const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const int pix = (n * a.H + iy) * a.W + ix;
+            voA[it] = ok ? pix * a.ldA * 4 : OOB;
+            voB[it] = ok ? pix * a.ldB * 4 : OOB;
+        }
     }
     int voW[C::B_ITEMS];
 #pragma unroll
@@ -164,24 +195,29 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     }
 
     f32x4 ra[KS][C::A_ITEMS][2], rb[KS][C::B_ITEMS];
-    // the KS * (2*A_ITEMS + B_ITEMS) loads of a stage are issued in 5*KS parts, one per MFMA step of the previous stage
+    // the KS * (2*A_ITEMS + B_ITEMS) loads of a stage are issued in NSTEP*KS parts, one per MFMA step of the previous stage
     // (a wave that issues them back to back sits in the vector-memory issue queue: tools/probes/split_trace.py)
     constexpr int NLD = 2 * C::A_ITEMS + C::B_ITEMS;
     auto load_part = [&](int ch, int part) {
 #pragma unroll
         for (int sub = 0; sub < KS; ++sub) {
-            const int c0 = (ch * KS + sub) * KC;             // sub-chunk-uniform source: Ca % 8 == 0 for two sources
-            const bool fromA = c0 < a.Ca;
+            // MODE 1: stage ch = (8-channel group ch >> 1, row position ch & 1), sub = column position
+            const int c0 = (MODE == 1 ? (ch >> 1) : (ch * KS + sub)) * KC;   // sub-chunk-uniform source (Ca % 8 == 0)
+            const bool fromA = MODE != 0 || c0 < a.Ca;
             const bool cok = c0 < a.Ctot;                    // past the last channel: zeros (weights: buffer range check)
             const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
+            const bool sy1 = MODE == 1 && (ch & 1);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) {
-                if ((sub * NLD + i) * 5 / NLD != part && part >= 0) continue;
+                if ((sub * NLD + i) * NSTEP / NLD != part && part >= 0) continue;
                 if (i < 2 * C::A_ITEMS) {
                     const int it = i >> 1;
-                    const int vo = cok ? (fromA ? voA[it] : voB[it]) : OOB;
+                    int vo;
+                    if constexpr (MODE == 1) vo = sub == 0 ? (sy1 ? voB[it] : voA[it]) : (sy1 ? vo1x[1][it] : vo1x[0][it]);
+                    else vo = fromA ? voA[it] : voB[it];
+                    if (!cok) vo = OOB;
                     ra[sub][it][i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16 * (i & 1), 0));
                 } else {
                     const int it = i - 2 * C::A_ITEMS;
@@ -226,12 +262,20 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     constexpr int TA[6] = {0, 0, 1, 0, 2, 1};
     constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
 
-    // MFMA step j of a chunk: K = {tap 2j (lanes 0-31), tap 2j+1 (lanes 32-63)} x 8 channels
-    int aoff[5];
+    // MFMA step j of a sub-chunk: K = {tap 2j (lanes 0-31), tap 2j+1 (lanes 32-63)} x 8 channels
+    int aoff[NSTEP];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const int t = min(2 * j + kh, 8);                    // the tenth tap has zero weights: any valid address
-        aoff[j] = (wave * MT + t / 3) * HWD + (t % 3) + li;
+    for (int j = 0; j < NSTEP; ++j) {
+        if (MODE == 0) {
+            const int t = min(2 * j + kh, 8);                // the tenth tap has zero weights: any valid address
+            aoff[j] = (wave * MT + t / 3) * HWD + (t % 3) + li;
+        } else if (MODE == 1) {                              // block taps (ty = j, tx = kh)
+            aoff[j] = (wave * MT + j) * HWD + kh + li;
+        } else {                                             // tap (ta = j, tb = kh) of class (py, px): conv_igemm.hip mode 2
+            const int dy = (j == 0) ? 1 : (py ? 2 : 0);
+            const int dx = (kh == 0) ? 1 : (px ? 2 : 0);
+            aoff[j] = (wave * MT + dy) * HWD + dx + li;
+        }
     }
     const f32x4* pB = sB + kh * BN + li;
 
@@ -245,8 +289,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
         SPLIT_KSTAMP(ch, 0);
         SPLIT_KSTAMP(ch, 1);
 #pragma unroll
-        for (int sj = 0; sj < 5 * KS; ++sj) {
-            const int sub = sj / 5, j = sj % 5;
+        for (int sj = 0; sj < NSTEP * KS; ++sj) {
+            const int sub = sj / NSTEP, j = sj % NSTEP;
             if (more) load_part(ch + 1, sj);
             f32x4 af[PL][MT], bf[PL][NT];
 #pragma unroll
@@ -289,6 +333,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     // C4 + 1 slots: conflict free both ways) and reads it back as thread -> (pixel, channel quad) in memory order.
     constexpr int C4 = C::C4, XS = C::XS;
     constexpr int EIT = (32 * C4) / 64;
+    auto opix = [&](int oy, int ox) -> long long {           // pixel index in the output tensor
+        if (MODE == 2) return (long long)(n * 2 * a.Ho + 2 * oy + py) * (2 * a.Wo) + 2 * ox + px;
+        return (long long)(n * a.Ho + oy) * a.Wo + ox;
+    };
     f32x4* ex = reinterpret_cast<f32x4*>(smem) + wave * (32 * XS);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -303,7 +351,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
                 const int c4 = f % C4, px = f / C4;
                 const int ox = ox0 + px, j0 = n0 + c4 * 4;
                 const bool ok = oy < a.Ho && ox < a.Wo && j0 + 3 < a.Cout;
-                const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+                const long long op = opix(oy, ox);
                 pres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 pmask[it] = f32x4{1.f, 1.f, 1.f, 1.f};
                 if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
@@ -326,7 +374,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
             const int ox = ox0 + px, j0 = n0 + c4 * 4;
             f32x4 v = ex[px * XS + c4];
             if (oy >= a.Ho || ox >= a.Wo || j0 >= a.Cout) continue;
-            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+            const long long op = opix(oy, ox);
             const bool vec = a.vecOK && (j0 + 3 < a.Cout);
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
             if (a.bias) {
@@ -363,30 +411,31 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     SPLIT_STAMP(3);
 }
 
-template <int MT, int NT, int PL, int KS>
+template <int MT, int NT, int PL, int KS, int MODE>
 int launch_split(const ConvKArgs& ka, hipStream_t st) {
-    using C = SCfg<MT, NT, PL, KS>;
+    using C = SCfg<MT, NT, PL, KS, MODE>;
     static std::atomic<unsigned long long> attr_done{0};
-    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL, KS>, C::LDS_BYTES, "conv_split")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL, KS, MODE>, C::LDS_BYTES, "conv_split")) return rc;
     ConvKArgs a = ka;
     a.tilesX = cdiv(a.Wo, TW);
     a.tilesY = cdiv(a.Ho, C::TH);
-    a.nchunks = cdiv(a.Ctot, KC * KS);
+    a.nchunks = (MODE == 1) ? 2 * cdiv(a.Ctot, KC) : cdiv(a.Ctot, KC * KS);     // stages
     a.ncot = cdiv(a.Cout, C::BN);
     const int tiles = a.tilesX * a.tilesY * a.N;
-    dim3 grid(cdiv(tiles, 8) * 8 * a.ncot);
-    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL, KS>), grid, dim3(NTH), C::LDS_BYTES, st, a);
+    dim3 grid(cdiv(tiles, 8) * 8 * a.ncot, MODE == 2 ? 4 : 1);
+    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL, KS, MODE>), grid, dim3(NTH), C::LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_split");
     return 0;
 }
 
-// stage depth KS = 1: deeper stages (2 sub-chunks for two planes, 4 for one: fewer barriers, same LDS as three planes)
-// measured 4-8 % SLOWER on every shape -- the barrier pair is not what the short stages wait for
-template <int PL>
+// stage depth of the 3x3 tile KS = 1: deeper stages (2 sub-chunks for two planes, 4 for one: fewer barriers, same LDS as
+// three planes) measured 4-8 % SLOWER on every shape -- the barrier pair is not what the short stages wait for.  The
+// 2x2-tap modes have two MFMA steps per sub-chunk and always stage two.
+template <int PL, int MODE>
 int launch_split_pl(const ConvKArgs& a, bool wide, bool tall, hipStream_t st) {
-    constexpr int KS = 1;
-    if (wide) return tall ? launch_split<2, 2, PL, KS>(a, st) : launch_split<1, 2, PL, KS>(a, st);
-    return tall ? launch_split<2, 1, PL, KS>(a, st) : launch_split<1, 1, PL, KS>(a, st);
+    constexpr int KS = (MODE == 0) ? 1 : 2;
+    if (wide) return tall ? launch_split<2, 2, PL, KS, MODE>(a, st) : launch_split<1, 2, PL, KS, MODE>(a, st);
+    return tall ? launch_split<2, 1, PL, KS, MODE>(a, st) : launch_split<1, 1, PL, KS, MODE>(a, st);
 }
 
 }  // namespace
@@ -406,16 +455,22 @@ bool refid_split3x3_eligible(const ConvKArgs& a) {
            a.ldA % 4 == 0 && (!a.inB || a.ldB % 4 == 0);
 }
 
-// terms: 6 (three planes per operand: fp32-class products) or 3 (two planes: 2^-16 relative)
-int refid_launch_split3x3(const ConvKArgs& a, int terms, int cus, hipStream_t st) {
+// terms: 6 (three planes per operand: fp32-class products), 3 (two planes: 2^-16 relative) or 1 (plain bf16 operands)
+// mode: 0 = 3x3 stride 1; 1 = 4x4 stride 2 pad 1 forward; 2 = its input gradient (a.Ho / a.Wo = the gradient's grid)
+int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipStream_t st) {
     REFID_CHECK(terms == 1 || terms == 3 || terms == 6, "conv2d: split tile takes 1, 3 or 6 product terms (got %d)", terms);
-    REFID_CHECK(refid_split3x3_eligible(a),
-                "conv2d: split tile needs channel counts that are multiples of 8 and tensors below 2 GiB");
+    REFID_CHECK(refid_split3x3_eligible(a) && (mode == 0 || a.inB == nullptr),
+                "conv2d: split tile needs channel counts that are multiples of 8, tensors below 2 GiB and, for the stride-2 "
+                "modes, a single source");
     const bool wide = a.Cout > 32;
     // 8-row tiles when they still give every CU its two workgroups, 4-row tiles otherwise
-    const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * a.N * cdiv(a.Cout, wide ? 64 : 32);
+    const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * a.N * cdiv(a.Cout, wide ? 64 : 32) * (mode == 2 ? 4 : 1);
     const bool tall = wg8 >= 2 * cus;
-    if (terms == 6) return launch_split_pl<3>(a, wide, tall, st);
-    if (terms == 3) return launch_split_pl<2>(a, wide, tall, st);
-    return launch_split_pl<1>(a, wide, tall, st);
+#define SPLIT_DISPATCH(PLN)                                                          \
+    (mode == 0 ? launch_split_pl<PLN, 0>(a, wide, tall, st)                          \
+               : (mode == 1 ? launch_split_pl<PLN, 1>(a, wide, tall, st) : launch_split_pl<PLN, 2>(a, wide, tall, st)))
+    if (terms == 6) return SPLIT_DISPATCH(3);
+    if (terms == 3) return SPLIT_DISPATCH(2);
+    return SPLIT_DISPATCH(1);
+#undef SPLIT_DISPATCH
 }

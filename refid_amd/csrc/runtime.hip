@@ -162,22 +162,31 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackArgs p) {
     }
 }
 
-// split-bf16 planes for conv_split.hip: [chunk of 8 channels][plane][tap 0..9][rowsPad][8]; the tenth tap is zero (the
-// tile fills the bf16 MFMA's K = 16 with two taps x 8 channels)
-__global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes) {
-    const int ntp = p.ntaps + 1;
-    const long long total = (long long)p.nchunks * planes * ntp * p.rowsPad * 8;
+// split-bf16 planes for conv_split.hip (8-channel sub-chunks, `planes` bf16 numbers per weight):
+//   mode 0 (3x3 s1):        [chunk8][plane][tap 0..9][rowsPad][8]            the tenth tap is zero (tap pairs fill K = 16)
+//   mode 1 (4x4 s2 forward): [chunk8][sy][sx][plane][tap (ty,tx)][rowsPad][8]  = W[row][k][2ty+sy][2tx+sx]  (2x2 input blocks)
+//   mode 2 (its dgrad):      [class][chunk8][plane][tap (ta,tb)][rowsPad][8]   (REFID_ROLE_DOWN_DGRAD's classes / taps)
+__global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes, int mode) {
+    const int ntp = mode == 0 ? p.ntaps + 1 : 4;
+    const int nsub = mode == 1 ? 4 : 1;
+    const long long total = (long long)p.ncls * p.nchunks * nsub * planes * ntp * p.rowsPad * 8;
     __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
     for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         long long r = e;
         const int k8 = r % 8; r /= 8;
         const int row = r % p.rowsPad; r /= p.rowsPad;
         const int tap = r % ntp; r /= ntp;
-        const int plane = r % planes;
-        const int chunk = r / planes;
+        const int plane = r % planes; r /= planes;
+        const int sub = r % nsub; r /= nsub;
+        const int chunk = r % p.nchunks;
+        const int cls = r / p.nchunks;
         const int k = chunk * 8 + k8;
         float v = 0.f;
-        if (tap < p.ntaps && row < p.rows && k < p.K) v = pack_fetch(p, 0, tap, row, k);
+        if (row < p.rows && k < p.K) {
+            if (mode == 0) { if (tap < p.ntaps) v = pack_fetch(p, 0, tap, row, k); }
+            else if (mode == 1) v = pack_fetch(p, 0, (2 * (tap >> 1) + (sub >> 1)) * 4 + 2 * (tap & 1) + (sub & 1), row, k);
+            else v = pack_fetch(p, cls, tap, row, k);
+        }
         const __bf16 h = (__bf16)v;
         const float r1 = v - (float)h;
         const __bf16 m = (__bf16)r1;
@@ -239,24 +248,36 @@ extern "C" int refid_pack_conv_weights_bf16(const float* w, const float* oscale,
     return 0;
 }
 
+static int split_pack_mode(int role, int kh, int kw) {
+    if ((role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD) && kh == 3 && kw == 3) return 0;
+    if (role == REFID_ROLE_FWD && kh == 4 && kw == 4) return 1;
+    if (role == REFID_ROLE_DOWN_DGRAD && kh == 4 && kw == 4) return 2;
+    return -1;
+}
+
+static long long split_pack_elems(const PackArgs& p, int planes, int mode) {
+    return (long long)p.ncls * p.nchunks * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? p.ntaps + 1 : 4) * p.rowsPad * 8;
+}
+
 extern "C" size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes) {
     PackArgs p;
-    if ((role != REFID_ROLE_FWD && role != REFID_ROLE_DGRAD) || planes < 1 || planes > 3) return 0;
-    if (kh != 3 || kw != 3 || pack_geometry(role, o, i, kh, kw, 8, bn, &p)) return 0;
-    return (size_t)p.nchunks * planes * (p.ntaps + 1) * p.rowsPad * 8 * 2;
+    const int mode = split_pack_mode(role, kh, kw);
+    if (mode < 0 || planes < 1 || planes > 3) return 0;
+    if (pack_geometry(role, o, i, kh, kw, 8, bn, &p)) return 0;
+    return (size_t)split_pack_elems(p, planes, mode) * 2;
 }
 
 extern "C" int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,
                                              int kh, int kw, int bn, int planes, void* stream) {
     PackArgs p;
     REFID_CHECK(w && packed, "pack_split: null pointer");
-    REFID_CHECK(role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD, "pack_split: FWD / DGRAD roles only");
+    const int mode = split_pack_mode(role, kh, kw);
+    REFID_CHECK(mode >= 0, "pack_split: FWD / DGRAD of a 3x3 kernel, FWD / DOWN_DGRAD of a 4x4 (stride 2) kernel");
     REFID_CHECK(planes >= 1 && planes <= 3, "pack_split: 1, 2 or 3 planes (got %d)", planes);
-    REFID_CHECK(kh == 3 && kw == 3, "pack_split: 3x3 kernels only");
     REFID_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_split: unknown role %d", role);
     p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
-    const long long total = (long long)p.nchunks * planes * (p.ntaps + 1) * p.rowsPad * 8;
-    hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes);
+    const long long total = split_pack_elems(p, planes, mode);
+    hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes, mode);
     REFID_LAUNCH_CHECK("pack_conv_weights_split");
     return 0;
 }

@@ -186,6 +186,10 @@ WGRAD_BATCH = int(os.environ.get("REFID_WGRAD_BATCH", "8"))     # deferred launc
 # beats the LDS-staged bf16 tile (single-source convs and every input gradient).  6 is an experiment switch: measured
 # equal to the Winograd tile at best (the bf16 matrix pipe is power limited with real data: DESIGN.md).
 MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
+# conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
+# fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
+# split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
+DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
 WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 
 
@@ -201,6 +205,15 @@ def flush_wgrads(device):
         for op, g, a, b in pend:
             op._wgrad(g, a, b)
     pend.clear()
+
+
+def _fills_gpu(n, ho, wo, cout, classes):
+    """Does the split tile's smallest grid (4 x 32 pixel tiles x 64 channels) give each of the 256 CUs a workgroup?
+    Same policy switch as the split-K of the other tiles (refid_conv_desc.split_k): decided by the total grid under
+    'auto', by the per-sample geometry (as if 8 samples) otherwise, so that a sample's bits do not depend on the batch."""
+    if ops.WINO_SPLIT != 2:
+        n = 8
+    return n * -(-ho // 4) * -(-wo // 32) * -(-cout // 64) * classes >= 256
 
 
 class ConvOp:
@@ -312,6 +325,19 @@ class ConvOp:
                 self.sd_pad = -(-self.ci // self.sd_bn) * self.sd_bn
                 self.wds = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DGRAD, self.sd_bn, 3, 3, self.co, self.ci, planes) // 2,
                                        dtype=torch.bfloat16, device=dev)
+        if kind == "down" and self.ci % 8 == 0 and self.co % 8 == 0 and (bf16 or DOWN_SPLIT or ConvOp.default_split):
+            self.split = terms = 1 if bf16 else (ConvOp.default_split or DOWN_SPLIT)
+            self.s_planes = planes = {1: 1, 3: 2, 6: 3}[terms]
+            if not bf16:                      # (plain bf16 operands: the LDS-staged tile is as fast on the forward conv)
+                self.sf_bn = ops.conv_bn(4, 4, 2, 0, self.co)
+                self.sf_pad = -(-self.co // self.sf_bn) * self.sf_bn
+                self.wps = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, self.sf_bn, 4, 4, self.co, self.ci, planes) // 2,
+                                       dtype=torch.bfloat16, device=dev)
+            if need_dgrad:
+                self.sd_bn = ops.conv_bn(4, 4, 2, 2, self.ci)
+                self.sd_pad = -(-self.ci // self.sd_bn) * self.sd_bn
+                self.wds = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DOWN_DGRAD, self.sd_bn, 4, 4, self.co, self.ci,
+                                                                     planes) // 2, dtype=torch.bfloat16, device=dev)
         self.b_eff = self.b
         if self.scale is not None and self.has_bias:
             self.b_eff = torch.empty_like(self.b)
@@ -332,8 +358,8 @@ class ConvOp:
             ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, planes=self.s_planes,
                                         out=self.wps, oscale=self.scale)
         if self.wds is not None:
-            ops.pack_conv_weights_split(self.w, ops.ROLE_DGRAD, self.sd_bn, k, k, self.co, self.ci, planes=self.s_planes,
-                                        out=self.wds, oscale=self.scale)
+            ops.pack_conv_weights_split(self.w, ops.ROLE_DOWN_DGRAD if self.kind == "down" else ops.ROLE_DGRAD, self.sd_bn,
+                                        k, k, self.co, self.ci, planes=self.s_planes, out=self.wds, oscale=self.scale)
         if self.scale is not None and self.has_bias:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 
@@ -352,9 +378,11 @@ class ConvOp:
                 out.zero_()
                 out = out[..., :oc]
         kh, kw, st, md = self.f_geo
-        if self.wps is not None and (self.split > 1 or b is None) and a.shape[3] % 8 == 0 and pw is None:
-            # (one product = plain bf16 operands: only where this tile beats the LDS-staged one -- single-source convs)
-            ops.conv2d(a, self.wps, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.co, cout_pad=self.sf_pad, in_b=b,
+        if self.wps is not None and (self.split > 1 or b is None) and a.shape[3] % 8 == 0 and pw is None and \
+                (self.kind == "conv" or (b is None and _fills_gpu(n, ho, wo, self.co, 1))):
+            # (one product = plain bf16 operands: only where this tile beats the LDS-staged one -- single-source convs;
+            #  conv_down: only when the grid gives every CU a workgroup -- the fp32 MFMA tile has a split-K form for less)
+            ops.conv2d(a, self.wps, out, kh=kh, kw=kw, stride=st, pad=1, mode=0, cout=self.co, cout_pad=self.sf_pad, in_b=b,
                        bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split)
             return out
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
@@ -380,8 +408,8 @@ class ConvOp:
         pad = self.pad if self.kind == "conv" else (1 if self.kind == "down" else 0)
         if self.kind == "conv":
             pad = self.k - 1 - self.pad
-        if self.wds is not None:
-            ops.conv2d(g, self.wds, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.sd_pad, co_base=base,
+        if self.wds is not None and (self.kind == "conv" or _fills_gpu(n, h, w, cnt, 4)):
+            ops.conv2d(g, self.wds, out, kh=kh, kw=kw, stride=st, pad=1, mode=md, cout=cnt, cout_pad=self.sd_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split)
             return out
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,

@@ -949,3 +949,51 @@ def test_split_tile_rejects_bad_arguments():
         ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=64, cout_pad=64, algo=4, terms=4)
     with pytest.raises(RefidHipError):
         ops.pack_conv_weights_split(torch.randn(64, 32, 5, 5, device="cuda"), ops.ROLE_FWD, 64, 5, 5, 64, 32, planes=3)
+
+
+@pytest.mark.parametrize("terms", [6, 3, 1])
+@pytest.mark.parametrize("cfg", [(2, 16, 64, 64, 64), (1, 24, 40, 128, 128), (1, 8, 8, 256, 256), (1, 18, 66, 32, 48), (3, 64, 64, 64, 64),
+                                 (1, 10, 6, 16, 16)])
+def test_split_tile_conv_down_forward(cfg, terms):
+    """4x4 / stride 2 / pad 1 (`conv_down`, recurrent_sub_modules.py:12-14) on the split tile: a 2x2 conv over 2x2 input
+    blocks that start at odd coordinates; bias / LeakyReLU / residual epilogue as everywhere."""
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 4, 4, seed=2, scale=1.0 / np.sqrt(Ci * 16))
+    b = rnd(Co, seed=3)
+    xr, wr = (x, w) if terms != 1 else (_split_planes(x, 1), _split_planes(w, 1))
+    y = lrelu(F.conv2d(xr, wr, b, 2, 1), 0.2)
+    r = rnd(*y.shape, seed=4)
+    ref = y + r
+    bn = ops.conv_bn(4, 4, 2, 0, Co)
+    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_FWD, bn, 4, 4, Co, Ci, planes={6: 3, 3: 2, 1: 1}[terms])
+    out = torch.full((N, H // 2, W // 2, Co), 7.0, device="cuda")
+    ops.conv2d(nhwc(x), wp, out, kh=4, kw=4, stride=2, pad=1, cout=Co, cout_pad=-(-Co // bn) * bn, bias=b.float().cuda(),
+               res=nhwc(r), slope_pre=0.2, algo=4, terms=terms)
+    rtol, atol = (RTOL, ATOL) if terms != 3 else (2e-4, 6e-5)
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("terms", [6, 3, 1])
+@pytest.mark.parametrize("cfg", [(2, 16, 32, 64), (1, 24, 40, 128), (1, 8, 8, 256), (1, 36, 68, 32), (2, 64, 64, 64)])
+def test_split_tile_conv_down_dgrad(cfg, terms):
+    """Input gradient of conv_down: four output-parity classes of 2x2-tap convs over the output gradient (+ the fused
+    residual / derivative-mask epilogue BPTT uses)."""
+    ops = _ops()
+    N, H, W, C = cfg
+    x = rnd(N, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(C, C, 4, 4, seed=2, scale=0.1)
+    g = rnd(N, C, H // 2, W // 2, seed=3)
+    wr, gr = (w, g) if terms != 1 else (_split_planes(w, 1), _split_planes(g, 1))
+    F.conv2d(x, wr, None, 2, 1).backward(gr)
+    r = rnd(N, C, H, W, seed=4)
+    m = rnd(N, C, H, W, seed=5)
+    ref = (x.grad + r) * torch.where(m > 0, 1.0, 0.3)
+    bn = ops.conv_bn(4, 4, 2, 2, C)
+    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_DOWN_DGRAD, bn, 4, 4, C, C, planes={6: 3, 3: 2, 1: 1}[terms])
+    out = torch.empty(N, H, W, C, device="cuda")
+    ops.conv2d(nhwc(g), wp, out, kh=4, kw=4, stride=2, pad=1, mode=2, cout=C, cout_pad=-(-C // bn) * bn, res=nhwc(r), mask=nhwc(m),
+               slope_mask=0.3, algo=4, terms=terms)
+    rtol, atol = (RTOL, ATOL) if terms != 3 else (2e-4, 2e-4)
+    np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=rtol, atol=atol)

@@ -71,7 +71,46 @@ def one(name, H, Ca, Cb, Co, res=True, mask=False):
     print(f"{name:26s} " + " | ".join(cols), flush=True)
 
 
+def down(name, H, C, dgrad):
+    """conv_down (4x4 / stride 2) forward or input gradient: direct fp32 tile (algo 0) vs the split tile."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    w = torch.randn(C, C, 4, 4, device="cuda", generator=g) * (2.0 / (16 * C)) ** 0.5
+    fl = 2.0 * B * (H // 2) ** 2 * C * C * 16
+    if not dgrad:
+        x = torch.randn(B, H, H, C, device="cuda", generator=g)
+        out = torch.empty(B, H // 2, H // 2, C, device="cuda")
+        ref = F.conv2d(x[:1].permute(0, 3, 1, 2).double(), w.double(), None, 2, 1).permute(0, 2, 3, 1)
+        role, mode = ops.ROLE_FWD, 0
+    else:
+        x = torch.randn(B, H // 2, H // 2, C, device="cuda", generator=g)
+        out = torch.empty(B, H, H, C, device="cuda")
+        ref = F.conv_transpose2d(x[:1].permute(0, 3, 1, 2).double(), w.double(), None, 2, 1).permute(0, 2, 3, 1)
+        role, mode = ops.ROLE_DOWN_DGRAD, 2
+    bn = ops.conv_bn(4, 4, 2, mode, C)
+    pad = -(-C // bn) * bn
+    cols = []
+    for label, algo, terms in (("direct-fp32", 0, 0), ("split x6", 4, 6), ("split x3", 4, 3), ("split x1", 4, 1), ("igemm-bf16", 2, 1)):
+        kc = ops.conv_kc(4, 4, 2, mode)
+        if algo == 0:
+            ww = ops.pack_conv_weights(w, role, bn, kc, 4, 4, C, C)
+        elif algo == 2:
+            ww = ops.pack_conv_weights_bf16(w, role, bn, 2 * kc, 4, 4, C, C)
+        else:
+            ww = ops.pack_conv_weights_split(w, role, bn, 4, 4, C, C, planes={6: 3, 3: 2, 1: 1}[terms])
+        run = lambda: ops.conv2d(x, ww, out, kh=4, kw=4, stride=2, pad=1, mode=mode, cout=C, cout_pad=pad, algo=algo, terms=terms)  # noqa: E731
+        t = timeit(run)
+        err = (out[:1].double() - ref).abs().max().item()
+        peak = 157.3 if algo == 0 else 2500.0
+        cols.append(f"{label} {t*1e6:6.1f} us err {err:.0e} ({fl * max(terms, 1) / t / 1e12 / peak:.2f})")
+    print(f"{name:26s} " + " | ".join(cols), flush=True)
+
+
 if __name__ == "__main__":
+    if os.environ.get("DOWN"):
+        for H, C in ((256, 64), (128, 128), (64, 256)):
+            down(f"down fwd {C}ch @{H}", H, C, False)
+            down(f"down dgrad {C}ch @{H}", H, C, True)
+        sys.exit(0)
     one("L0 first 32->64 @256", 256, 32, 0, 64, res=False)
     one("L0 main.0 128->64 @256", 256, 64, 64, 64, res=False)
     one("L0 res 64->64 @256", 256, 64, 0, 64)

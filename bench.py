@@ -394,6 +394,14 @@ def main(argv=None):
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 tensors/accumulation, 3x3 conv products as 3 bf16 MFMAs (2^-16)",
                                           "bf16": "bf16"}[args.dtype], "data": "synthetic",
             "rccl_ranks": world if (use_dist and args.backend == "nccl") else (0 if not use_dist else None),
+            "arithmetic": {"fp32": "fp32 tensors, operands and accumulation; 3x3: Winograd F(2x2,3x3) on the fp32 MFMA; conv_down "
+                                   "(4x4 stride 2) fwd/dgrad: every fp32 operand split EXACTLY into three bf16 numbers, six bf16 MFMAs "
+                                   "per product, fp32 accumulation (same distance from float64 as the fp32 MFMA tile: "
+                                   "tests/test_hip_conv.py::test_split_tile_conv_down_*; REFID_DOWN_SPLIT=0 turns it off)",
+                           "bf16x3": "fp32 tensors and accumulation; 3x3 / 4x4 forward and input-gradient products as three bf16 MFMAs "
+                                     "(2^-16 per product); weight gradients fp32",
+                           "bf16": "bf16 MFMA operands (forward, input and weight gradients), fp32 tensors / accumulation / "
+                                   "optimizer"}[args.dtype],
             "config": {"workload": f"GoPro 11+1 blur-VFI train step, batch {per_gpu}/GPU"
                                    f"{' (global batch ' + str(gbatch) + ' sharded)' if args.scaling == 'strong' else ''}, "
                                    f"{args.size}x{args.size}, T={args.T}, img_chn={args.img_chn}, {args.dtype}" +

@@ -462,6 +462,11 @@ int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipS
     REFID_CHECK(refid_split3x3_eligible(a) && (mode == 0 || a.inB == nullptr),
                 "conv2d: split tile needs channel counts that are multiples of 8, tensors below 2 GiB and, for the stride-2 "
                 "modes, a single source");
+    {   // the weight fragments are fetched with 32-bit buffer offsets as well
+        const long long planes = terms == 6 ? 3 : (terms == 3 ? 2 : 1);
+        const long long wbytes = (long long)cdiv(a.Ctot, KC) * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? 10 : 4) * a.CoutPad * 16;
+        REFID_CHECK(wbytes < 0x7fffffffLL, "conv2d: packed weights too large for the split tile's 32-bit offsets");
+    }
     const bool wide = a.Cout > 32;
     // 8-row tiles when they still give every CU its two workgroups, 4-row tiles otherwise
     const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * a.N * cdiv(a.Cout, wide ? 64 : 32) * (mode == 2 ? 4 : 1);

@@ -225,9 +225,12 @@ int refid_pack_conv_weights_scaled(const float* w, const float* oscale, float* p
 /* bf16 copy of the same packed layout (RNE), kc = 2 * refid_conv_kc(...); oscale may be NULL. */
 int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* packed_bf16, int role, int o, int i,
                                  int kh, int kw, int kc, int bn, void* stream);
-/* Split-bf16 packing for refid_conv2d algo 4 (3x3, REFID_ROLE_FWD / REFID_ROLE_DGRAD): every weight (times
- * oscale[row] when given) is written as `planes` bf16 numbers h = rne(v), m = rne(v - h), l = v - h - m (planes = 3:
- * exact; planes = 2: h, m only), layout [chunk of 8 channels][plane][tap 0..9][rows padded to bn][8] (tap 9 = zeros).
+/* Split-bf16 packing for refid_conv2d algo 4: every weight (times oscale[row] when given) is written as `planes` bf16
+ * numbers h = rne(v), m = rne(v - h), l = v - h - m (planes = 3: exact; 2: h, m; 1: h), in 8-channel sub-chunks:
+ *   3x3 (REFID_ROLE_FWD / REFID_ROLE_DGRAD):     [chunk8][plane][tap 0..9][rows padded to bn][8]   (tap 9 = zeros)
+ *   4x4 stride 2, REFID_ROLE_FWD (conv_down):     [chunk8][in-block row sy][in-block column sx][plane][block tap (ty,tx)]
+ *                                                 [rows][8] = W[row][k][2ty+sy][2tx+sx]
+ *   4x4 stride 2, REFID_ROLE_DOWN_DGRAD:          [parity class][chunk8][plane][tap (ta,tb)][rows][8]
  * refid_packed_weight_split_bytes gives the buffer size. */
 size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes);
 int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,

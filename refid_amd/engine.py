@@ -588,6 +588,7 @@ class Engine:
             self.dec.append(dict(t2=ConvOp(A, p + ".transposed_conv2d", kind="convT", bf16=bf),
                                  trunk=_Trunk(A, p + ".forward_trunk.main", bf16=bf)))
         self.pred = ConvOp(A, "pred.conv2d", bf16=bf)
+        ConvOp.default_split = 0                   # (a construction-time context, not a setting other engines inherit)
         self.all_ops = [self.head_ev, self.head_img, self.pred]
         for lv in self.enc_b + self.enc_f:
             self.all_ops += lv.ops()

@@ -9,13 +9,16 @@
 // numbers (8 + 8 + 8 significand bits: h = rne(v), m = rne(v - h), l = v - h - m), so
 //     a*b = ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)  + O(2^-24 |ab|)
 // -- six bf16 MFMAs reproduce the fp32 product to one fp32 rounding (the three dropped cross terms are below
-// 2^-24 relative), at 6/16 of the fp32 MFMA's pipe time.  The direct 3x3 conv issues 2.25x the multiplies of
-// Winograd F(2x2,3x3): 2.25 * 6/16 = 0.84 of the Winograd tile's matrix-pipe time, but WITHOUT its per-chunk
-// transforms (VALU + LDS work that does not hide under MFMAs on this chip), without its 16-way weight-fragment
-// traffic, and without the transforms' error amplification -- this tile is closer to the fp64 result than the
-// fp32 Winograd tile is (tests/test_hip_conv.py::test_split_tile_accuracy).  TERMS = 3 keeps the first three
-// products only (two planes per operand, 2^-16 relative: better than TF32, which is what the reference's own GPU
-// path multiplies with by default); it is an explicit opt-in.
+// 2^-24 relative), at 6/16 of the fp32 MFMA's pipe time.  Measured (tools/bench_split.py):
+//   * against the fp32-MFMA DIRECT tiles (convolutions with no Winograd form: conv_down 4x4 stride 2 and its input
+//     gradient) six products are 1.6-2x faster at the same distance from the float64 result -- the default there;
+//   * against the fp32 Winograd F(2x2,3x3) tile (2.25x fewer multiplies) they only tie: 2.25 * 6/16 = 0.84 of its
+//     matrix-pipe time on paper, but the bf16 pipe with real operands is power limited (0.68 of nominal), and the
+//     accumulated rounding is 2-3x Winograd's (8e-6 vs 3e-6 on O(1) sums: the fp32 class either way,
+//     tests/test_hip_conv.py::test_split_tile_accuracy_classes) -- an experiment switch for 3x3;
+//   * TERMS = 3 keeps the first three products (two planes per operand, 2^-16 relative: finer than TF32, which is
+//     what the reference's own GPU path multiplies with by default): 1.4-1.55x faster than the Winograd tile, an
+//     explicit opt-in (compute_dtype bf16x3);  TERMS = 1 is plain bf16 operands (compute_dtype bf16).
 //
 // Mapping (one workgroup = 256 threads = 4 waves, one per SIMD; two workgroups per CU cover each other's staging,
 // barriers, prologue and epilogue -- the regime the trace of the Winograd tile showed to work on this chip):

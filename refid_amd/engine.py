@@ -190,6 +190,8 @@ MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
 # fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
 # split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
 DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
+# smallest output-channel count whose 3x3 weight gradient goes to the Winograd tile (64 x 32 channel tiles)
+WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
 WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 
 
@@ -441,7 +443,7 @@ class ConvOp:
             if self.has_bias:
                 ops.colsum(g, self.gb)
             return
-        algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci >= 32) else 0
+        algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         if WGRAD_GROUP > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):

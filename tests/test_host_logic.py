@@ -241,3 +241,20 @@ def test_schedulers_match_reference_sequences(golden_dir):
         np.testing.assert_allclose(np.array(seq), z["lr/" + name], rtol=1e-9, atol=1e-15, err_msg=name)
     with pytest.raises(NotImplementedError):
         train.scheduler_lr("CosineAnnealingLR", {}, 1, 2e-4, 2e-4)     # the reference rejects this spelling too
+
+
+def test_split_tile_grid_policy_follows_the_split_k_policy():
+    """engine._fills_gpu: conv_down goes to the split tile only when its smallest grid gives each of the 256 CUs a
+    workgroup -- by the real batch under the 'auto' split-K policy, as if 8 samples otherwise (batch invariance)."""
+    from refid_amd import engine, ops
+    old = ops.WINO_SPLIT
+    try:
+        ops.WINO_SPLIT = 2
+        assert engine._fills_gpu(8, 128, 128, 64, 1) and engine._fills_gpu(2, 128, 128, 64, 1)
+        assert not engine._fills_gpu(1, 128, 128, 64, 1)            # 128 workgroups: the fp32 tile's split-K form instead
+        assert engine._fills_gpu(1, 128, 128, 64, 4)                # input gradient: four parity classes
+        ops.WINO_SPLIT = 1
+        assert engine._fills_gpu(1, 128, 128, 64, 1) == engine._fills_gpu(8, 128, 128, 64, 1)
+        assert engine._fills_gpu(1, 16, 32, 64, 1) == engine._fills_gpu(5, 16, 32, 64, 1)
+    finally:
+        ops.WINO_SPLIT = old

@@ -267,6 +267,72 @@ def run_host_logic(arch, out_dir):
     print("host_logic: init moments of", len(keys), "tensors;", len(cases), "lr sequences")
 
 
+def run_metrics(out_dir):
+    """the validation tail as the reference computes it -- utils/img_util.py:59-121 (tensor2img) and
+    metrics/psnr_ssim.py:9-63 (calculate_psnr), :135-182,225-303 (calculate_ssim -> _ssim_3d) -- imported from
+    /root/reference.  The image lacks cv2 / skimage / torchvision.utils and a GPU, so: cv2 is a stub holding the two
+    functions those line ranges call (getGaussianKernel = OpenCV's closed form for ksize > 7 / sigma > 0:
+    exp(-(i-(n-1)/2)^2 / (2 sigma^2)) normalised to sum 1, as an (n,1) float64 column; cvtColor(RGB2BGR) = channel
+    flip), skimage is an empty stub (only referenced in comments), and Tensor.cuda()/Module.cuda() are identity for the
+    duration of the call (the reference runs the same fp32 Conv3d on its GPU).  No reference source is edited or copied."""
+    cv2 = types.ModuleType("cv2")
+    cv2.COLOR_RGB2BGR = 4
+
+    def get_gaussian_kernel(ksize, sigma):
+        assert ksize > 7 and sigma > 0            # below that OpenCV switches to fixed tables / derived sigma
+        x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        k = np.exp(-(x * x) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(ksize, 1)
+
+    def cvt_color(img, code):
+        assert code == cv2.COLOR_RGB2BGR and img.shape[2] == 3
+        return np.ascontiguousarray(img[:, :, ::-1])
+
+    cv2.getGaussianKernel, cv2.cvtColor = get_gaussian_kernel, cvt_color
+    sys.modules["cv2"] = cv2
+    for nm in ("skimage", "skimage.metrics"):
+        sys.modules.setdefault(nm, types.ModuleType(nm))
+    sys.modules["skimage"].metrics = sys.modules["skimage.metrics"]
+    tvu = types.ModuleType("torchvision.utils")
+    tvu.make_grid = None                          # only reached for 4-D mini-batches
+    sys.modules["torchvision.utils"] = tvu
+    sys.modules["torchvision"].utils = tvu
+    utils = sys.modules["basicsr.utils"]
+    utils.__path__ = [f"{REF}/basicsr/utils"]      # submodules (matlab_functions, img_util) load from the reference
+    m = types.ModuleType("basicsr.metrics")
+    m.__path__ = [f"{REF}/basicsr/metrics"]
+    sys.modules["basicsr.metrics"] = m
+    img_util = importlib.import_module("basicsr.utils.img_util")
+    ps = importlib.import_module("basicsr.metrics.psnr_ssim")
+
+    rec = {}
+    cases = {"a": (40, 48, 21), "b": (32, 56, 22), "c": (24, 24, 23)}
+    saved = (torch.Tensor.cuda, torch.nn.Module.cuda)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    try:
+        for name, (h, w, salt) in cases.items():
+            gt = (O.hash_fill((3, h, w), salt) * 0.5 + 0.5).float()
+            noise = O.hash_fill((3, h, w), salt + 100)
+            pred = (gt + (0.35 if name == "c" else 0.06) * noise).float()     # leaves [0,1]: exercises the clamp
+            if name == "c":
+                pred[:, :4] = gt[:, :4]                                        # a band of identical rows
+            sr_img = img_util.tensor2img([pred.clone()])                       # the call of :429 (uint8, BGR)
+            gt_img = img_util.tensor2img([gt.clone()])                         # :432
+            rec[f"{name}/pred"], rec[f"{name}/gt"] = pred.numpy(), gt.numpy()
+            rec[f"{name}/pred_u8_bgr"], rec[f"{name}/gt_u8_bgr"] = sr_img, gt_img
+            rec[f"{name}/psnr"] = np.float64(ps.calculate_psnr(sr_img, gt_img, crop_border=0))
+            rec[f"{name}/ssim"] = np.float64(ps.calculate_ssim(sr_img, gt_img, crop_border=0))
+            print(f"metrics {name}: psnr {float(rec[f'{name}/psnr']):.4f} ssim {float(rec[f'{name}/ssim']):.6f}")
+        same = img_util.tensor2img([gt.clone()])
+        rec["same/psnr"] = np.float64(ps.calculate_psnr(same, same, crop_border=0))      # inf
+        rec["same/ssim"] = np.float64(ps.calculate_ssim(same, same, crop_border=0))
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = saved
+    rec["names"] = np.array(list(cases))
+    np.savez_compressed(os.path.join(out_dir, "metrics.npz"), **rec)
+
+
 def main():
     out_dir = os.path.join(REPO, "tests", "golden")
     os.makedirs(out_dir, exist_ok=True)
@@ -274,6 +340,9 @@ def main():
     arch, losses = import_reference()
     run_host_logic(arch, out_dir)
     if os.environ.get("ONLY") == "host":
+        return
+    if os.environ.get("ONLY") == "metrics":
+        run_metrics(out_dir)
         return
     if os.environ.get("ONLY") != "refid":
         run_evhinet(losses, "evhinet_tiny_train", 8, 2, 32, 32, 1, True, out_dir)
@@ -318,6 +387,7 @@ def main():
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), events=ev, voxel=vox.astype(np.float32),
                             meta=np.array([bins, hh, ww]))
         print(name, "voxel sum", float(vox.sum()))
+    run_metrics(out_dir)
 
 
 if __name__ == "__main__":

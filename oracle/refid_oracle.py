@@ -9,8 +9,11 @@ Parity status: PINNED.  ``oracle/make_golden.py`` imports the reference's own
 three hot-path files from ``/root/reference`` (with import stubs only, no
 source edits), runs them on closed-form inputs/weights and commits the outputs
 as ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks this
-restatement against those vectors.  The reference itself ships no tests or
-golden vectors for this path.
+restatement against those vectors.  The neighbours of the path are pinned the
+same way: event voxelisation (``voxel_*.npz``) and the validation tail --
+``tensor2img`` + ``calculate_psnr`` + ``calculate_ssim`` (``metrics.npz``,
+``tests/test_oracle_io.py``).  The reference itself ships no tests or golden
+vectors for this path.
 
 Every function cites the reference lines it follows (paths relative to
 ``/root/reference/basicsr/models``):
@@ -452,12 +455,13 @@ def train_step(P: Params, state: TrainState, x, event, gt, lr=2e-4, betas=(0.9, 
 def tensor2img_u8(frame: torch.Tensor) -> torch.Tensor:
     """tensor2img quantisation: clamp [0,1], x255, round -> uint8.  utils/img_util.py:90-117.
 
-    (The RGB->BGR flip there is PSNR-invariant and omitted.)  frame: (3,H,W)."""
+    (The RGB->BGR flip there is PSNR-invariant and omitted.)  frame: (3,H,W).  Pinned: tests/golden/metrics.npz."""
     return (frame.detach().float().clamp(0, 1) * 255.0).round().to(torch.uint8)
 
 
 def psnr_u8(a: torch.Tensor, b: torch.Tensor) -> float:
-    """calculate_psnr on uint8 images, crop_border 0, float64 MSE.  metrics/psnr_ssim.py:48-63."""
+    """calculate_psnr on uint8 images, crop_border 0, float64 MSE.  metrics/psnr_ssim.py:48-63.
+    Pinned against the reference function's own output: tests/golden/metrics.npz."""
     mse = ((a.double() - b.double()) ** 2).mean().item()
     if mse == 0:
         return float("inf")
@@ -526,7 +530,8 @@ def tile_grid(h, w, crop):
 def ssim3d_u8(a: torch.Tensor, b: torch.Tensor) -> float:
     """calculate_ssim -> _ssim_3d restated: metrics/psnr_ssim.py:135-182 (+ :283-290 max_value) on
     tensor2img-quantised frames.  a, b: (3,H,W) float in [0,1].  (cv2.getGaussianKernel(11,1.5) =
-    normalised exp(-(i-5)^2/(2*1.5^2)); the reference runs the conv3d in fp32 on the GPU.)"""
+    normalised exp(-(i-5)^2/(2*1.5^2)); the reference runs the conv3d in fp32 on the GPU.)
+    Pinned against the reference function's own output (run on the CPU): tests/golden/metrics.npz."""
     import numpy as np
     g = np.exp(-((np.arange(11) - 5) ** 2) / (2 * 1.5 ** 2)); g = g / g.sum()
     window = np.outer(g, g)

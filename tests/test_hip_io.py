@@ -52,6 +52,19 @@ def test_ssim_tail():
     np.testing.assert_allclose(same, [1.0] * 3, rtol=0, atol=1e-6)
 
 
+def test_validation_tail_matches_reference_fixture(golden_dir):
+    """The HIP PSNR / SSIM kernels against what the reference's own tensor2img + calculate_psnr + calculate_ssim
+    returned for the same frames (tests/golden/metrics.npz, oracle/make_golden.py::run_metrics)."""
+    from refid_amd.metrics import calculate_psnr_frames, calculate_ssim_frames
+    z = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for n in z["names"]:
+        pred, gt = torch.from_numpy(z[f"{n}/pred"]).cuda(), torch.from_numpy(z[f"{n}/gt"]).cuda()
+        assert abs(calculate_psnr_frames(pred, gt)[0] - float(z[f"{n}/psnr"])) < 1e-9
+        assert abs(calculate_ssim_frames(pred, gt)[0] - float(z[f"{n}/ssim"])) < 2e-5
+    gt = torch.from_numpy(z["c/gt"]).cuda()
+    assert calculate_psnr_frames(gt, gt) == [float("inf")] and abs(calculate_ssim_frames(gt, gt)[0] - 1.0) < 1e-6
+
+
 def _net(img_chn, base=8, seed=3):
     from refid_amd.archs import define_network
     P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)

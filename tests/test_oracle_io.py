@@ -1,5 +1,5 @@
 """CPU-only: the oracle's restatements of the path's neighbours against reference-generated vectors
-(event voxelisation) and hand-computed answers (tile geometry)."""
+(event voxelisation, the tensor2img / PSNR / SSIM validation tail) and hand-computed answers (tile geometry)."""
 import os
 
 import numpy as np
@@ -47,9 +47,26 @@ def test_tile_geometry_known_answers():
     assert cover.min() >= 1
 
 
+def test_validation_tail_matches_reference(golden_dir):
+    """tests/golden/metrics.npz holds what the reference's own tensor2img (utils/img_util.py:59-121), calculate_psnr
+    (metrics/psnr_ssim.py:9-63) and calculate_ssim (:135-182,225-303) return for three frame pairs
+    (oracle/make_golden.py::run_metrics): the restatement must agree."""
+    import torch
+    z = np.load(os.path.join(golden_dir, "metrics.npz"))
+    for n in z["names"]:
+        pred, gt = torch.from_numpy(z[f"{n}/pred"]), torch.from_numpy(z[f"{n}/gt"])
+        for t, key in ((pred, "pred_u8_bgr"), (gt, "gt_u8_bgr")):
+            ref = torch.from_numpy(z[f"{n}/{key}"].copy()).permute(2, 0, 1).flip(0)      # HWC BGR -> CHW RGB
+            assert torch.equal(O.tensor2img_u8(t), ref)                                    # quantisation: bit exact
+        assert abs(O.psnr_u8(O.tensor2img_u8(pred), O.tensor2img_u8(gt)) - float(z[f"{n}/psnr"])) < 1e-10
+        assert abs(O.ssim3d_u8(pred, gt) - float(z[f"{n}/ssim"])) < 1e-6                   # fp32 conv3d, summation order
+    gt = torch.from_numpy(z["c/gt"])
+    assert float(z["same/psnr"]) == float("inf") and O.psnr_u8(O.tensor2img_u8(gt), O.tensor2img_u8(gt)) == float("inf")
+    assert abs(O.ssim3d_u8(gt, gt) - float(z["same/ssim"])) < 1e-6
+
+
 def test_ssim_known_answers():
-    """No reference test pins calculate_ssim and it cannot be imported here (cv2 + CUDA): pin the
-    restatement with closed-form cases of the SSIM definition."""
+    """Closed-form cases of the SSIM definition (next to the reference-generated vectors above)."""
     import torch
     a = torch.rand(3, 24, 24, generator=torch.Generator().manual_seed(0))
     assert abs(O.ssim3d_u8(a, a) - 1.0) < 1e-6                           # identical images

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 4
+#define REFID_ABI_VERSION 5
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -119,12 +119,18 @@ typedef struct refid_conv_desc {
                                                    refid_pack_conv_weights_split with the same number of
                                                    planes): every fp32 operand is the exact sum of three bf16
                                                    numbers, six bf16 MFMAs give the fp32 product to one
-                                                   rounding (see `mfma_terms`)                     */
+                                                   rounding (see `mfma_terms`);
+                                                   5 = Winograd F(2x2,3x3) with the transform-domain products on the bf16
+                                                   matrix cores, six bf16 MFMAs per fp32 product on exactly split
+                                                   operands (3x3, stride 1, mode 0, more than 32 output channels, two
+                                                   sources: c_a a multiple of 16; w_packed from
+                                                   refid_pack_conv_weights_wino6): the fp32 Winograd tile's result to
+                                                   fp32 rounding at 2.67x fewer matrix-pipe cycles            */
     int split_k;                                /* small problems (few output tiles, long K): split K over the grid into
                                                    `ws` partial sums + a finishing pass.  0 = never; 1 = decided by the
                                                    per-sample geometry (a sample's bits do not depend on the batch
                                                    size); 2 = decided by the total grid size (best at 1-2 samples per
-                                                   GPU).  Used by algo 1 and by algo 0's 4x4/s2 tiles (mode 0 and 2).  */
+                                                   GPU).  Used by algo 1 / 5 and by algo 0's 4x4/s2 tiles (mode 0 and 2).  */
     int wino_tile;                              /* algo 1 only: 0 / 1 = the 2-waves-per-SIMD tile (4x32 px x 64 ch
                                                    workgroups; the default); 2 = the persistent one-wave-per-SIMD tile
                                                    (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
@@ -235,6 +241,12 @@ int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* pack
 size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes);
 int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,
                                   int kh, int kw, int bn, int planes, void* stream);
+/* Winograd-domain weights U = G g G^T (times oscale[row] when given) for refid_conv2d algo 5: computed in fp32 like
+ * REFID_ROLE_WINO_FWD / REFID_ROLE_WINO_DGRAD, then written as three bf16 planes that sum to U exactly:
+ *   [chunk of 16 input channels][xi = 0..15][plane][rows padded to bn = 64][16]  (bf16). */
+size_t refid_packed_weight_wino6_bytes(int role, int o, int i, int bn);
+int refid_pack_conv_weights_wino6(const float* w, const float* oscale, void* packed, int role, int o, int i, int bn,
+                                  void* stream);
 int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
 /* After BPTT, turn the gradient of the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r]) of THIS backward pass
  * (gw_folded, gb_folded: private buffers, zero before BPTT) into gradients of (W, b, scale) and ACCUMULATE them:

@@ -66,7 +66,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 4          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 5          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 
@@ -117,6 +117,9 @@ def _bind_extra(L):
     vp, i, f, ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
     L.refid_pack_conv_weights_scaled.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
     L.refid_pack_conv_weights_bf16.argtypes = [vp, vp, vp] + [i] * 7 + [vp]
+    L.refid_packed_weight_wino6_bytes.argtypes = [i] * 4
+    L.refid_packed_weight_wino6_bytes.restype = C.c_size_t
+    L.refid_pack_conv_weights_wino6.argtypes = [vp, vp, vp] + [i] * 4 + [vp]
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
     L.refid_fold_back.argtypes = [vp] * 8 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]

@@ -444,6 +444,7 @@ extern "C" size_t refid_conv_workspace_bytes(const refid_conv_desc* d) {
     a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
     a.vecOK = 1;
     if (d->algo == 1) return refid_wino3x3_workspace_bytes(a, d->split_k);
+    if (d->algo == 5) return refid_wino6_workspace_bytes(a, d->split_k);
     if (d->algo != 0 && d->algo != 2) return 0;
     const bool bf = d->algo == 2;
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
@@ -470,10 +471,10 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
     REFID_CHECK(d->pw == nullptr || d->algo == 3, "conv2d: pw fusions belong to the pointwise tile (algo 3)");
-    REFID_CHECK(d->algo == 0 || d->algo == 2 || (d->algo == 1 && f == F_3x3) || (d->algo == 3 && f == F_1x1) ||
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 5) && f == F_3x3) || (d->algo == 3 && f == F_1x1) ||
                     (d->algo == 4 && (f == F_3x3 || f == F_4x4s2 || f == F_downDgrad)),
-                "conv2d: algo %d does not fit this geometry (1 = 3x3 stride 1, 3 = 1x1, 4 = 3x3 stride 1 / 4x4 stride 2 and its "
-                "input gradient)", d->algo);
+                "conv2d: algo %d does not fit this geometry (1 / 5 = 3x3 stride 1, 3 = 1x1, 4 = 3x3 stride 1 / 4x4 stride 2 and "
+                "its input gradient)", d->algo);
     REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
     REFID_CHECK(d->co_base >= 0 && d->co_base + d->cout <= d->cout_pad,
@@ -538,6 +539,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         return refid_launch_split3x3(a, d->mfma_terms ? d->mfma_terms : 6, f == F_3x3 ? 0 : (f == F_4x4s2 ? 1 : 2),
                                      cus > 0 ? cus : 256, st);
     }
+    if (d->algo == 5) return refid_launch_wino6(a, d->ws, d->ws_bytes, d->split_k, st);
     if (d->algo == 1) {
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");
         const long long lim = 0x7fffffffLL;      // buffer-load byte offsets are 32-bit

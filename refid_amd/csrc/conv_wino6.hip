@@ -1,0 +1,381 @@
+// Winograd F(2x2, 3x3) convolution tile with the transform-domain GEMMs on the gfx950 bf16 matrix cores:
+// every fp32 operand of  M_xi[cout][tile] += U_xi[cout][c] * V_xi[c][tile]  is the EXACT sum of three bf16 numbers
+// (h = rne(v), m = rne(v - h), l = v - h - m: 8 + 8 + 8 significand bits), and six bf16 MFMAs
+//     u*v = uh*vh + (uh*vm + um*vh) + (uh*vl + ul*vh + um*vm)   + O(2^-24 |uv|)
+// reproduce the fp32 product to one rounding with the same fp32 accumulator.
+//
+// Why both at once ("Winograd x six products"): the fp32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles for
+// K = 2) runs at 1/16 of the bf16 one (v_mfma_f32_32x32x16_bf16, 32 cycles for K = 16).  Per 16 input channels and
+// wave the fp32 Winograd tile issues 64 fp32 MFMAs = 4096 matrix-pipe cycles; six bf16 products on the DIRECT conv
+// (conv_split.hip) need 6 * 10/9 * 36/16 as many bf16 MFMAs as Winograd does and only tie it; six products in the
+// WINOGRAD domain are 48 bf16 MFMAs = 1536 cycles -- 2.67x fewer matrix-pipe cycles than either, in the same error
+// class (the transforms B^T d B and G g G^T stay exact +-1 / 0.5 arithmetic in fp32; only the products change).
+// The price is VALU: V is split on the fly (44 VALU per 8 values, ~5 VALU per MFMA) -- tools/probes/wino6_loop.hip
+// measured that two waves per SIMD hide it (0.52 of the bf16 peak with the split, 0.58 without, random data).
+//
+//   out = mask( post( pre(conv3x3(src) + bias) + res ) ),  src = in_a or [in_a | in_b]
+// (same contract, epilogue, split-K form and XCD-aware work mapping as conv_wino.hip; serves the forward conv and,
+// on the flipped/transposed weights, the input gradient.)
+//
+// Mapping (one workgroup = 256 threads = 4 waves, 2 workgroups per CU):
+//   * workgroup tile = 4x32 output pixels = 32 Winograd tiles x 64 output channels; K walks input channels in
+//     chunks of 16 (the bf16 MFMA's K): lane (li, kh) holds channels 8kh .. 8kh+7 of tile / output channel li.
+//   * wave w owns transform ROW i = w (xi = 4i .. 4i+3) for both 32-channel column tiles: 8 accumulators.
+//   * per chunk a wave reads its two rows of the raw 6x34 halo (16 ds_read_b128, conflict-free image: even / odd
+//     pixel columns de-interleaved, row pitch 40 slots), forms t = row transform (32 VALU) and then, per column j:
+//     v_j (8 VALU) -> three bf16 planes (44 VALU) -> 12 MFMAs against the U fragments of (xi = 4i+j, 3 planes, 2 tiles).
+//   * U = G g G^T comes pre-split from the pack kernel ([chunk16][xi][plane][cout][16] bf16); a lane's fragment is ONE
+//     16-byte buffer load, a wave reads 1 KB contiguous; fragments of column j+1 are requested before column j's MFMAs
+//     (two register sets), never through LDS.
+//   * the raw halo of chunk c+2 is requested at the top of chunk c (global -> VGPR -> LDS, double buffered).
+#include "common.h"
+#include "conv_args.h"
+
+namespace {
+
+constexpr int TW = 32;                  // output pixels per workgroup row
+constexpr int KC = 16;                  // input channels per chunk = K of one bf16 MFMA
+constexpr int HWD = TW + 2;             // halo pixels per row
+constexpr int TH = 4, BN = 64;
+constexpr int ROWP = 40;                // LDS slots per halo row: even columns at 0..16, odd columns at 20..36
+constexpr int PLANE = 6 * ROWP + 5;     // slots per channel-quad plane (245: plane pitch 980 dwords = 20 mod 32)
+constexpr int R_F4 = 4 * PLANE;         // one raw halo buffer: [quad][row][slot] float4
+constexpr int HP = (TH + 2) * HWD;      // 204 halo pixels
+constexpr int R_ITEMS = (4 * HP + 255) / 256;
+constexpr int LDS_BYTES = 64 * 66 * 16; // 2 raw buffers (31 KB) in the K loop; 66 KB row exchange afterwards
+constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// v (8 fp32 channels) -> three bf16 planes that sum to v exactly
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (&pl)[3]) {
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = k < 4 ? v0[k] : v1[k - 4];
+        const __bf16 h = (__bf16)v;
+        p0[k] = h;
+        const float r = v - (float)h;
+        const __bf16 m = (__bf16)r;
+        p1[k] = m;
+        p2[k] = (__bf16)(r - (float)m);
+    }
+    pl[0] = __builtin_bit_cast(f32x4, p0);
+    pl[1] = __builtin_bit_cast(f32x4, p1);
+    pl[2] = __builtin_bit_cast(f32x4, p2);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4* sR = reinterpret_cast<f32x4*>(smem);            // two raw halo buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = lane >> 5;
+    const int ti = wave;                                   // transform row i owned by this wave (xi = 4i .. 4i+3)
+
+    // XCD-aware work mapping (as conv_wino.hip): the channel tiles of one pixel tile are consecutive on one XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    int bt = (slot / a.ncot) * 8 + xcd;                    // pixel-tile index
+    if (bt >= a.tilesX * a.tilesY * a.N) return;
+    const int n0 = (slot % a.ncot) * BN;
+    const int tx = bt % a.tilesX; bt /= a.tilesX;
+    const int ty = bt % a.tilesY;
+    const int n = bt / a.tilesY;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+
+    // ---- loaders -----------------------------------------------------------------------------------------------
+    const int limA = (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL);
+    const int limB = a.inB ? (int)min((long long)a.N * a.H * a.W * a.ldB * 4, 0x7fffffffLL) : 0;
+    const int uPlane = a.CoutPad * KC * 2;                 // bytes between two planes of one xi
+    const int uXi = 3 * uPlane;                            // bytes between xi and xi+1
+    const int uChunk = 16 * uXi;                           // bytes per K chunk
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * uChunk, 0x7fffffffLL), 0x00020000);
+    // raw halo: thread -> (pixel, channel quad); four lanes read one pixel's 64 contiguous bytes
+    const int q = tid & 3;
+    int pixo[R_ITEMS], sdst[R_ITEMS];
+#pragma unroll
+    for (int it = 0; it < R_ITEMS; ++it) {
+        const int hp = (tid >> 2) + it * 64;
+        const int row = hp / HWD, col = hp % HWD;
+        const int iy = oy0 - a.pad + row, ix = ox0 - a.pad + col;
+        const bool ok = hp < HP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        pixo[it] = ok ? (n * a.H + iy) * a.W + ix : OOB;                       // pixel index; bytes = pixo * ld * 4 + q * 16
+        // (threads past the halo store their zeros into the plane's padding slots: no branch around the store)
+        sdst[it] = hp < HP ? q * PLANE + row * ROWP + (col >> 1) + (col & 1) * 20 : q * PLANE + 6 * ROWP + (tid & 3);
+    }
+    // U fragments of this lane: rows (cout) n0 + nt*32 + li, channels 8kh .. 8kh+7
+    int voU[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int urow = a.coBase + n0 + nt * 32 + li;
+        voU[nt] = (urow < a.CoutPad) ? (urow * KC + kh * 8) * 2 + ti * 4 * uXi : OOB;
+    }
+    // split-K (small grids only): this workgroup reduces chunks [kc0, kc1) and writes a raw partial output
+    const int kper = (a.nchunks + a.ksplit - 1) / a.ksplit;
+    const int kc0 = blockIdx.y * kper, kc1 = min(a.nchunks, kc0 + kper);
+
+    f32x4 rr[R_ITEMS];
+    // chunks past kc1 are requested with out-of-range offsets (zeros, no memory traffic): no branches around loads,
+    // so the compiler's vmcnt bookkeeping stays exact
+    auto load_raw = [&](int ch, f32x4 (&dst)[R_ITEMS]) {
+        const int c0 = ch * KC;                            // chunk-uniform source: Ca % 16 == 0 for two sources
+        const bool fromA = c0 < a.Ca;
+        const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
+        const bool qok = ch < kc1 && c0 + q * 4 < a.Ctot;  // partial last chunk: upper quads are zeros
+        const int ld4 = (fromA ? a.ldA : a.ldB) * 4;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < R_ITEMS; ++it) {
+            // pixo = -1 (outside the image): 2^32 - ld4 + q*16 is beyond any buffer, no compare needed
+            const int vo = qok ? pixo[it] * ld4 + q * 16 : OOB;
+            dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
+        }
+    };
+    auto store_raw = [&](int buf, const f32x4 (&src)[R_ITEMS]) {
+#pragma unroll
+        for (int it = 0; it < R_ITEMS; ++it) sR[buf * R_F4 + sdst[it]] = src[it];
+    };
+    // fragments of column j of chunk ch: [plane][nt]
+    auto load_u = [&](int ch, int j, f32x4 (&dst)[3][2]) {
+        // (the hardware range check covers the vector offset only: a chunk past the range must not travel as a scalar offset)
+        const bool in = ch < kc1;
+        const int so = ch * uChunk + j * uXi;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                dst[p][nt] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, in ? voU[nt] : OOB, in ? so + p * uPlane : 0, 0));
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+    // B^T row i of the 4x4 input patch of this lane's tile: t = d[P] + sgn * d[M]
+    //   i=0: d0 - d2   i=1: d1 + d2   i=2: d2 - d1   i=3: d1 - d3
+    const int rowP = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
+    const int rowM = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
+    const float sgn = (ti == 1) ? 1.f : -1.f;
+    // patch columns b = 0..3 of tile column k = li & 15 are pixels 2k+b: slots k, 20+k, k+1, 21+k of the row
+    const int tbase = 2 * kh * PLANE + (2 * (li >> 4)) * ROWP + (li & 15);
+    const int offP = tbase + rowP * ROWP, offM = tbase + rowM * ROWP;
+    constexpr int BOFF[4] = {0, 20, 1, 21};
+
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1};              // products kept: (V plane, U plane), largest first
+    constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
+
+    f32x4 uA[3][2], uB[3][2];
+    auto phase = [&](int ch) {
+        const int lc = ch - kc0;
+        store_raw((lc + 1) & 1, rr);                       // raw(ch+1): requested one chunk ago
+        load_raw(ch + 2, rr);
+        const f32x4* r = sR + (lc & 1) * R_F4;
+        f32x4 t[2][4];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t[qq][b] = r[qq * PLANE + offP + BOFF[b]] + r[qq * PLANE + offM + BOFF[b]] * sgn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 (&cur)[3][2] = (j & 1) ? uB : uA;
+            f32x4 (&nxt)[3][2] = (j & 1) ? uA : uB;
+            load_u(j == 3 ? ch + 1 : ch, (j + 1) & 3, nxt);
+            f32x4 v[2], pl[3];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+                v[qq] = (j == 0) ? t[qq][0] - t[qq][2] : (j == 1) ? t[qq][1] + t[qq][2]
+                      : (j == 2) ? t[qq][2] - t[qq][1] : t[qq][1] - t[qq][3];
+            split8(v[0], v[1], pl);
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)             // consecutive MFMAs hit different accumulators
+                    acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        __builtin_bit_cast(bf16x8, cur[TB[e]][nt]), __builtin_bit_cast(bf16x8, pl[TA[e]]), acc[j][nt], 0, 0, 0);
+        }
+        __syncthreads();                                   // raw(ch) consumed by every wave; raw(ch+1) visible
+    };
+
+    // prologue: raw(kc0) -> LDS; raw(kc0+1) and U(kc0, column 0) in flight
+    {
+        f32x4 rr0[R_ITEMS];
+        load_raw(kc0, rr0);
+        load_raw(kc0 + 1, rr);
+        load_u(kc0, 0, uA);
+        store_raw(0, rr0);
+    }
+    __syncthreads();
+
+    for (int ch = kc0; ch < kc1; ++ch) phase(ch);
+
+    // ---- output transform (as conv_wino.hip) -----------------------------------------------------------------
+    // lane: tile li, channels (r&3)+8(r>>2)+4kh of a 32-channel tile;  acc[j][t] = M[i][j]
+    //   R_i[b] = sum_j M[i][j] A[j][b] :  b=0: M0+M1+M2   b=1: M1-M2-M3          (in registers)
+    //   Y[a][b] = sum_i A^T[a][i] R_i[b]:  a=0: R0+R1+R2   a=1: R1-R2-R3          (across the 4 waves, through LDS)
+    constexpr int XL = 66;
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            f32x4 r0, r1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = 4 * rq + k;
+                r0[k] = acc[0][t][r] + acc[1][t][r] + acc[2][t][r];
+                r1[k] = acc[1][t][r] - acc[2][t][r] - acc[3][t][r];
+            }
+            xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r0;
+            xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r1;
+        }
+    constexpr int NIT = (TH * TW * (BN / 4)) / 256;
+    const bool pre = a.vecOK && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
+    f32x4 pres[NIT], pmask[NIT];
+    if (pre) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int f = it * 256 + tid;
+            const int c4 = f % (BN / 4), pr = f / (BN / 4);
+            const int oy = oy0 + pr / TW, ox = ox0 + pr % TW, j0 = n0 + c4 * 4;
+            const bool ok = oy < a.Ho && ox < a.Wo && j0 + 3 < a.Cout;
+            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+            pres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            pmask[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+            if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+        }
+    }
+    __syncthreads();
+
+    constexpr int C4 = BN / 4;                              // float4 per pixel
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int f = it * 256 + tid;
+        const int c4 = f % C4, pr = f / C4;
+        const int row = pr / TW, col = pr % TW;
+        const int c = c4 * 4;
+        const int nt = c >> 5, rq = (c & 31) >> 3, ckh = (c & 7) >> 2;
+        const int oa = row & 1, tile = ((row & 3) >> 1) * 16 + (col >> 1), ob = col & 1;
+        const int oy = oy0 + row, ox = ox0 + col;
+        const int j0 = n0 + c;
+        if (oy >= a.Ho || ox >= a.Wo || j0 >= a.Cout) continue;
+        const f32x4* xp = xch + (((oa * 2 + ob) * 2 + nt) * 4 + rq) * XL + ckh * 33 + tile;   // row i0 = oa
+        const float sg = oa ? -1.f : 1.f;                   // a=0: R0+R1+R2 ; a=1: R1-R2-R3
+        f32x4 v = xp[0] + (xp[16 * XL] + xp[32 * XL]) * sg;
+        const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+        if (a.ksplit > 1) {                                 // raw partial sums; the finishing pass applies the epilogue
+            *reinterpret_cast<f32x4*>(a.out + blockIdx.y * a.wsStride + op * a.ldO + j0) = v;
+            continue;
+        }
+        const bool vec = a.vecOK && (j0 + 3 < a.Cout);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const float* bp = a.bias + a.coBase + j0;
+            if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
+            else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+        if (vec) {
+            if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+            if (a.mask) {
+                const f32x4 mv = pre ? pmask[it] : *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+            }
+            *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (j0 + k >= a.Cout) break;
+                float tv = v[k];
+                if (a.res) tv += a.res[op * a.ldR + j0 + k];
+                tv = lrelu(tv, a.slopePost);
+                if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                a.out[op * a.ldO + j0 + k] = tv;
+            }
+        }
+    }
+}
+
+struct Wino6Plan { int ks; dim3 grid; };
+
+// same small-grid policy as the fp32 tile (conv_wino.hip::wino_plan), in chunks of 16 channels
+Wino6Plan wino6_plan(ConvKArgs& a, int split_mode) {
+    Wino6Plan p;
+    a.tilesX = cdiv(a.Wo, TW);
+    a.tilesY = cdiv(a.Ho, TH);
+    a.nchunks = cdiv(a.Ctot, KC);
+    a.ncot = cdiv(a.Cout, BN);
+    p.grid = dim3(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
+    const int nwg = (split_mode == 2) ? (int)p.grid.x : a.tilesX * a.tilesY * a.ncot * 8;   // "sample": as if N = 8
+    int ks = 1;
+    if (split_mode && nwg <= 256 && a.nchunks >= 8) {
+        ks = 512 / nwg;
+        if (ks > a.nchunks / 4) ks = a.nchunks / 4;
+        if (ks > 8) ks = 8;
+        if (ks < 1) ks = 1;
+    }
+    p.ks = ks;
+    return p;
+}
+
+}  // namespace
+
+bool refid_wino6_eligible(const ConvKArgs& a) {
+    const long long lim = 0x7fffffffLL;
+    return a.Cout > 32 && a.Ctot % 4 == 0 && (a.inB == nullptr || a.Ca % KC == 0) &&
+           (long long)a.N * a.H * a.W * a.ldA * 4 < lim && (!a.inB || (long long)a.N * a.H * a.W * a.ldB * 4 < lim) &&
+           (long long)cdiv(a.Ctot, KC) * 16 * 3 * a.CoutPad * KC * 2 < lim;
+}
+
+size_t refid_wino6_workspace_bytes(const ConvKArgs& ka, int split_mode) {
+    ConvKArgs a = ka;
+    const Wino6Plan p = wino6_plan(a, split_mode);
+    if (p.ks == 1) return 0;
+    return (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float);
+}
+
+int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, hipStream_t st) {
+    ConvKArgs a = ka;
+    REFID_CHECK(refid_wino6_eligible(a),
+                "conv2d: the Winograd six-product tile needs more than 32 output channels, channel counts that are multiples "
+                "of 4 (two sources: c_a a multiple of 16) and tensors below 2 GiB");
+    const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0);
+    dim3 grid = pl.grid;
+    static std::atomic<unsigned long long> done{0};
+    if (int rc = refid_lds_attr_once(done, &conv_wino6_kernel, LDS_BYTES, "conv_wino6")) return rc;
+    const int ks = pl.ks;
+    if (ks == 1) {
+        hipLaunchKernelGGL(conv_wino6_kernel, grid, dim3(256), LDS_BYTES, st, a);
+        REFID_LAUNCH_CHECK("conv_wino6");
+        return 0;
+    }
+    const long long npix = (long long)a.N * a.Ho * a.Wo;
+    const int ldW = round_up(a.Cout, 4);
+    const size_t need = (size_t)ks * npix * ldW * sizeof(float);
+    if (need > ws_bytes || (reinterpret_cast<uintptr_t>(ws) & 15)) {
+        refid_set_error("conv_wino6: split-K workspace too small or misaligned (%zu bytes given, %zu needed: "
+                        "refid_conv_workspace_bytes)", ws_bytes, need);
+        return 1;
+    }
+    ConvKArgs p = a;                       // partial pass: raw sums into the workspace
+    p.ksplit = ks; p.wsStride = npix * ldW; p.out = ws; p.ldO = ldW;
+    grid.y = ks;
+    hipLaunchKernelGGL(conv_wino6_kernel, grid, dim3(256), LDS_BYTES, st, p);
+    REFID_LAUNCH_CHECK("conv_wino6/splitk");
+    ConvKArgs f = a;
+    f.ksplit = ks; f.wsStride = npix * ldW;
+    return refid_launch_splitk_finish(f, ws, ldW, npix, st);
+}

@@ -195,6 +195,28 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int p
     }
 }
 
+// Winograd-domain weights U = G g G^T as three bf16 planes for conv_wino6.hip: [chunk16][xi][plane][rowsPad][16]
+__global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
+    const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+    __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long r = e;
+        const int k16 = r % 16; r /= 16;
+        const int row = r % p.rowsPad; r /= p.rowsPad;
+        const int plane = r % 3; r /= 3;
+        const int xi = r % 16;
+        const int chunk = r / 16;
+        const int k = chunk * 16 + k16;
+        float v = 0.f;
+        if (row < p.rows && k < p.K) v = pack_fetch(p, 0, xi, row, k);
+        const __bf16 h = (__bf16)v;
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        dst[e] = plane == 0 ? h : (plane == 1 ? m : l);
+    }
+}
+
 int pack_geometry(int role, int o, int i, int kh, int kw, int kc, int bn, PackArgs* p) {
     p->role = role; p->O = o; p->I = i; p->KH = kh; p->KW = kw; p->KC = kc;
     p->ncls = 1;
@@ -279,6 +301,26 @@ extern "C" int refid_pack_conv_weights_split(const float* w, const float* oscale
     const long long total = split_pack_elems(p, planes, mode);
     hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes, mode);
     REFID_LAUNCH_CHECK("pack_conv_weights_split");
+    return 0;
+}
+
+extern "C" size_t refid_packed_weight_wino6_bytes(int role, int o, int i, int bn) {
+    PackArgs p;
+    if (role != REFID_ROLE_WINO_FWD && role != REFID_ROLE_WINO_DGRAD) return 0;
+    if (pack_geometry(role, o, i, 3, 3, 16, bn, &p)) return 0;
+    return (size_t)p.nchunks * 16 * 3 * p.rowsPad * 16 * 2;
+}
+
+extern "C" int refid_pack_conv_weights_wino6(const float* w, const float* oscale, void* packed, int role, int o, int i,
+                                             int bn, void* stream) {
+    PackArgs p;
+    REFID_CHECK(w && packed, "pack_wino6: null pointer");
+    REFID_CHECK(role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD, "pack_wino6: Winograd roles only");
+    REFID_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_wino6: bad geometry");
+    p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
+    const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+    hipLaunchKernelGGL(pack_wino6_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    REFID_LAUNCH_CHECK("pack_conv_weights_wino6");
     return 0;
 }
 

@@ -120,6 +120,23 @@ def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscal
     return out
 
 
+def pack_conv_weights_wino6(w, role, o, i, out=None, oscale=None):
+    """Winograd-domain weights as three bf16 planes for conv2d(algo=5); role = ROLE_WINO_FWD / ROLE_WINO_DGRAD."""
+    L = lib()
+    nb = L.refid_packed_weight_wino6_bytes(role, o, i, 64)
+    if nb == 0:
+        raise _lib.RefidHipError("pack_conv_weights_wino6: bad geometry")
+    if not w.is_contiguous():
+        raise _lib.RefidHipError("pack_conv_weights_wino6: weight must be contiguous")
+    if out is None:
+        out = torch.empty(nb // 2, dtype=torch.bfloat16, device=w.device)
+    elif out.numel() * out.element_size() != nb:
+        raise _lib.RefidHipError("pack_conv_weights_wino6: out has the wrong size")
+    check(L.refid_pack_conv_weights_wino6(w.data_ptr(), oscale.data_ptr() if oscale is not None else None, out.data_ptr(),
+                                          role, o, i, 64, _stream()), "refid_pack_conv_weights_wino6")
+    return out
+
+
 def _pw_extras(pw, out):
     """refid_pw_extras from a dict of tensors / scalars (see include/refid_hip.h); returns (struct, keep-alive list)."""
     x = _lib.PwExtras()
@@ -191,7 +208,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
     d.algo = algo
     d.wino_tile = WINO_TILE
-    if WINO_SPLIT and algo in (0, 1, 2):
+    if WINO_SPLIT and algo in (0, 1, 2, 5):
         d.split_k = WINO_SPLIT
         need = lib().refid_conv_workspace_bytes(C.byref(d))
         if need:
@@ -210,6 +227,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
         (", true> [bf16 operands]" if algo == 2 else ">")
     if algo == 1:
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
+    if algo == 5:
+        name = "conv_wino6_kernel"
     if algo == 4:
         name = "conv_split_kernel<%d>" % (terms or 6)
     if algo == 3:

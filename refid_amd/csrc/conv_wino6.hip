@@ -73,6 +73,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     const int li = lane & 31, kh = lane >> 5;
     const int ti = wave;                                   // transform row i owned by this wave (xi = 4i .. 4i+3)
 
+#if defined(REFID_WINO6_ABLATE) && (REFID_WINO6_ABLATE == 9 || REFID_WINO6_ABLATE == 11)
+    {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        if ((hw & 1) && blockIdx.x < 512 * 2) {          // first generation only: later workgroups inherit the phase
+            const unsigned long long t0 = wall_clock64();
+            while (wall_clock64() - t0 < (REFID_WINO6_ABLATE == 9 ? 400 : 800)) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#endif
     // XCD-aware work mapping (as conv_wino.hip): the channel tiles of one pixel tile are consecutive on one XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     int bt = (slot / a.ncot) * 8 + xcd;                    // pixel-tile index
@@ -118,18 +128,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     f32x4 rr[R_ITEMS];
     // chunks past kc1 are requested with out-of-range offsets (zeros, no memory traffic): no branches around loads,
     // so the compiler's vmcnt bookkeeping stays exact
+    // tools/probes/wino6_ablate.py builds this file with -DREFID_WINO6_ABLATE=n (one piece of the kernel removed, results
+    // wrong) to price the pieces: 1 = U fragments always from chunk 0 (cache resident), 2 = no three-plane split,
+    // 3 = no K loop, 4 = no residual / mask loads and no stores, 5 = raw halo always from chunk 0, 6 = no U loads in the K loop,
+    // 7 = no raw loads / LDS stores in the K loop, 8 = 6 + 7, 9 / 11 = the workgroup in the odd wave slot of its SIMD starts
+    // 4 / 8 us late (anti-phased pair per CU), 10 = 3 + 4.  Never in the product.
+#ifndef REFID_WINO6_ABLATE
+#define REFID_WINO6_ABLATE 0
+#endif
     auto load_raw = [&](int ch, f32x4 (&dst)[R_ITEMS]) {
-        const int c0 = ch * KC;                            // chunk-uniform source: Ca % 16 == 0 for two sources
+        const int c0 = (REFID_WINO6_ABLATE == 5 ? 0 : ch) * KC;   // chunk-uniform source: Ca % 16 == 0 for two sources
         const bool fromA = c0 < a.Ca;
         const int soff = (fromA ? c0 : c0 - a.Ca) * 4;
-        const bool qok = ch < kc1 && c0 + q * 4 < a.Ctot;  // partial last chunk: upper quads are zeros
+        const int qmask = (ch < kc1 && c0 + q * 4 < a.Ctot) ? 0 : OOB;   // partial last chunk: upper quads are zeros
         const int ld4 = (fromA ? a.ldA : a.ldB) * 4;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(fromA ? a.inA : a.inB), 0, fromA ? limA : limB, 0x00020000);
 #pragma unroll
         for (int it = 0; it < R_ITEMS; ++it) {
-            // pixo = -1 (outside the image): 2^32 - ld4 + q*16 is beyond any buffer, no compare needed
-            const int vo = qok ? pixo[it] * ld4 + q * 16 : OOB;
+            // pixo = -1 (outside the image): 2^32 - ld4 + q*16 is beyond any buffer, no compare needed; quads past the last
+            // channel are forced out of range with an OR (a select here becomes a branch around the load + vmcnt(0))
+            const int vo = (pixo[it] * ld4 + q * 16) | qmask;
             dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
         }
     };
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     auto load_u = [&](int ch, int j, f32x4 (&dst)[3][2]) {
         // (the hardware range check covers the vector offset only: a chunk past the range must not travel as a scalar offset)
         const bool in = ch < kc1;
-        const int so = ch * uChunk + j * uXi;
+        const int so = (REFID_WINO6_ABLATE == 1 ? 0 : ch) * uChunk + j * uXi;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -174,8 +193,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     f32x4 uA[3][2], uB[3][2];
     auto phase = [&](int ch) {
         const int lc = ch - kc0;
-        store_raw((lc + 1) & 1, rr);                       // raw(ch+1): requested one chunk ago
-        load_raw(ch + 2, rr);
+        if (REFID_WINO6_ABLATE != 7 && REFID_WINO6_ABLATE != 8) {
+            store_raw((lc + 1) & 1, rr);                   // raw(ch+1): requested one chunk ago
+            load_raw(ch + 2, rr);
+#ifdef REFID_WINO6_PIN
+            __builtin_amdgcn_sched_barrier(0x38F);
+#endif
+        }
         const f32x4* r = sR + (lc & 1) * R_F4;
         f32x4 t[2][4];
 #pragma unroll
@@ -186,13 +210,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
         for (int j = 0; j < 4; ++j) {
             f32x4 (&cur)[3][2] = (j & 1) ? uB : uA;
             f32x4 (&nxt)[3][2] = (j & 1) ? uA : uB;
-            load_u(j == 3 ? ch + 1 : ch, (j + 1) & 3, nxt);
+            if (REFID_WINO6_ABLATE != 6 && REFID_WINO6_ABLATE != 8) load_u(j == 3 ? ch + 1 : ch, (j + 1) & 3, nxt);
+#ifdef REFID_WINO6_PIN
+            __builtin_amdgcn_sched_barrier(0x38F);         // vector-memory instructions stay where they are written
+#endif
             f32x4 v[2], pl[3];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
                 v[qq] = (j == 0) ? t[qq][0] - t[qq][2] : (j == 1) ? t[qq][1] + t[qq][2]
                       : (j == 2) ? t[qq][2] - t[qq][1] : t[qq][1] - t[qq][3];
-            split8(v[0], v[1], pl);
+            if (REFID_WINO6_ABLATE == 2) { pl[0] = v[0]; pl[1] = v[1]; pl[2] = t[0][j]; }
+            else split8(v[0], v[1], pl);
 #pragma unroll
             for (int e = 0; e < 6; ++e)
 #pragma unroll
@@ -209,11 +237,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
         load_raw(kc0, rr0);
         load_raw(kc0 + 1, rr);
         load_u(kc0, 0, uA);
+        if (REFID_WINO6_ABLATE == 6 || REFID_WINO6_ABLATE == 8) load_u(kc0, 1, uB);
         store_raw(0, rr0);
     }
     __syncthreads();
 
-    for (int ch = kc0; ch < kc1; ++ch) phase(ch);
+    if (REFID_WINO6_ABLATE != 3 && REFID_WINO6_ABLATE != 10)
+        for (int ch = kc0; ch < kc1; ++ch) phase(ch);
 
     // ---- output transform (as conv_wino.hip) -----------------------------------------------------------------
     // lane: tile li, channels (r&3)+8(r>>2)+4kh of a 32-channel tile;  acc[j][t] = M[i][j]
@@ -236,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
             xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r1;
         }
     constexpr int NIT = (TH * TW * (BN / 4)) / 256;
-    const bool pre = a.vecOK && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
+    const bool pre = REFID_WINO6_ABLATE != 4 && REFID_WINO6_ABLATE != 10 && a.vecOK && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
     f32x4 pres[NIT], pmask[NIT];
     if (pre) {
 #pragma unroll
@@ -285,6 +315,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+        if (REFID_WINO6_ABLATE == 4 || REFID_WINO6_ABLATE == 10) {
+            if (v[0] == 12345.678f) a.out[op * a.ldO + j0] = v[1];
+            continue;
+        }
         if (vec) {
             if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
 #pragma unroll

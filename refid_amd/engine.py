@@ -186,6 +186,10 @@ WGRAD_BATCH = int(os.environ.get("REFID_WGRAD_BATCH", "8"))     # deferred launc
 # beats the LDS-staged bf16 tile (single-source convs and every input gradient).  6 is an experiment switch: measured
 # equal to the Winograd tile at best (the bf16 matrix pipe is power limited with real data: DESIGN.md).
 MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
+# Winograd-domain GEMMs of the 3x3 convs with more than 32 output channels on the bf16 matrix cores, six exact-split
+# bf16 products per fp32 product (refid_conv2d algo 5, csrc/conv_wino6.hip): same error class as the fp32 Winograd tile at
+# 2.67x fewer matrix-pipe cycles.  0 = fp32 Winograd tile everywhere.
+WINO6 = os.environ.get("REFID_WINO6", "1") != "0"
 # conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
 # fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
 # split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
@@ -309,6 +313,14 @@ class ConvOp:
             self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
             self.wd = torch.empty(ops.packed_weight_floats(self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci),
                                   dtype=pdt, device=dev)
+        # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T
+        self.wp6 = self.wd6 = None
+        if WINO6 and not bf16 and self.f_algo == 1 and self.co > 32 and self.ci % 4 == 0:
+            self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) // 2,
+                                   dtype=torch.bfloat16, device=dev)
+        if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci > 32 and self.co % 4 == 0:
+            self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) // 2,
+                                   dtype=torch.bfloat16, device=dev)
         # split-bf16 direct tile (algo 4): second packing next to the default one
         terms = 1 if bf16 else (split or ConvOp.default_split or MFMA_SPLIT)
         self.wps = self.wds = None
@@ -356,6 +368,10 @@ class ConvOp:
         pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp, oscale=self.scale)
         if self.wd is not None:
             pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd, oscale=self.scale)
+        if self.wp6 is not None:
+            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, out=self.wp6, oscale=self.scale)
+        if self.wd6 is not None:
+            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, out=self.wd6, oscale=self.scale)
         if self.wps is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, planes=self.s_planes,
                                         out=self.wps, oscale=self.scale)
@@ -387,6 +403,10 @@ class ConvOp:
             ops.conv2d(a, self.wps, out, kh=kh, kw=kw, stride=st, pad=1, mode=0, cout=self.co, cout_pad=self.sf_pad, in_b=b,
                        bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split)
             return out
+        if self.wp6 is not None and self.split == 0 and (b is None or a.shape[3] % 16 == 0):
+            ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
+                       bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5)
+            return out
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
                    cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post,
                    algo=self.f_algo, pw=pw)
@@ -413,6 +433,10 @@ class ConvOp:
         if self.wds is not None and (self.kind == "conv" or _fills_gpu(n, h, w, cnt, 4)):
             ops.conv2d(g, self.wds, out, kh=kh, kw=kw, stride=st, pad=1, mode=md, cout=cnt, cout_pad=self.sd_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split)
+            return out
+        if self.wd6 is not None and self.split == 0 and cnt > 32:
+            ops.conv2d(g, self.wd6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
+                       res=res, mask=mask, slope_mask=slope_mask, algo=5)
             return out
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
                    co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo)

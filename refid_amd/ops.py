@@ -120,6 +120,10 @@ def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscal
     return out
 
 
+def packed_weight_wino6_bytes(role, o, i):
+    return lib().refid_packed_weight_wino6_bytes(role, o, i, 64)
+
+
 def pack_conv_weights_wino6(w, role, o, i, out=None, oscale=None):
     """Winograd-domain weights as three bf16 planes for conv2d(algo=5); role = ROLE_WINO_FWD / ROLE_WINO_DGRAD."""
     L = lib()

@@ -273,7 +273,7 @@ def test_errors_are_loud():
 # ---------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) tile (algo=1): same contract as the direct tile
 # ---------------------------------------------------------------------------------------------
-def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_post=1.0, mask=False):
+def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_post=1.0, mask=False, algo=1):
     ops = _ops()
     Ci = Ca + Cb
     xa = rnd(N, Ca, H, W, seed=1)
@@ -289,12 +289,15 @@ def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_pos
     m = rnd(N, Co, H, W, seed=6) if mask else None
     if mask:
         ref = ref * torch.where(m > 0, 1.0, 0.3)
-    wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+    if algo == 5:
+        wp = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_FWD, Co, Ci)
+    else:
+        wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
     copad = -(-Co // 64) * 64
     Cop = -(-Co // 4) * 4
     outbuf = torch.full((N, H, W, Cop), 7.0, device="cuda")
     out = outbuf[..., :Co]
-    ops.conv2d(nhwc(xa), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=copad, algo=1,
+    ops.conv2d(nhwc(xa), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=copad, algo=algo,
                in_b=nhwc(xb) if Cb else None, bias=b.float().cuda() if bias else None,
                res=nhwc(r) if res else None, mask=nhwc(m) if mask else None,
                slope_pre=slope_pre, slope_post=slope_post, slope_mask=0.3)
@@ -317,6 +320,90 @@ def test_winograd_fused_epilogues():
     run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0)
     run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1)
     run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True)
+
+
+# ---------------------------------------------------------------------------------------------
+# Winograd x six bf16 products (algo=5, csrc/conv_wino6.hip): same contract, more than 32 output channels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    (2, 16, 32, 32, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 128, 128, 128), (1, 12, 20, 64, 0, 256),
+    (1, 5, 3, 64, 0, 64), (1, 7, 33, 32, 0, 96), (1, 9, 17, 36, 0, 64), (1, 8, 32, 16, 16, 64), (1, 6, 10, 8, 0, 40),
+    (3, 4, 64, 48, 0, 128), (1, 8, 8, 256, 256, 256),
+])
+def test_wino6_forward_geometries(cfg):
+    """Ragged tiles, a partial last 16-channel chunk (36, 8, 48 channels), a partial channel tile (96, 40), two sources,
+    and a small grid that takes the split-K form (512 -> 256 at 8x8)."""
+    run_wino(*cfg, algo=5)
+
+
+def test_wino6_fused_epilogues():
+    run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04, algo=5)
+    run_wino(1, 16, 32, 64, 0, 64, res=True, algo=5)
+    run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0, algo=5)
+    run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1, algo=5)
+    run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True, algo=5)
+
+
+@pytest.mark.parametrize("cfg", [(1, 16, 32, 64, 64), (1, 9, 24, 128, 64), (1, 8, 16, 256, 128), (1, 8, 8, 96, 40)])
+def test_wino6_dgrad(cfg):
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
+    g = rnd(N, Co, H, W, seed=3)
+    F.conv2d(x, w, None, 1, 1).backward(g)
+    wd = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_DGRAD, Co, Ci)
+    rp = -(-Ci // 64) * 64
+    gd = nhwc(g)
+    out = torch.empty(N, H, W, Ci, device="cuda")
+    ops.conv2d(gd, wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=rp, algo=5)
+    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+    if Ci >= 128:       # row-range issue (two-source convs): second half of the rows
+        half = Ci // 2
+        o2 = torch.empty(N, H, W, half, device="cuda")
+        ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=rp, co_base=half, algo=5)
+        np.testing.assert_allclose(nchw(o2).numpy(), x.grad[:, half:].numpy(), rtol=RTOL, atol=ATOL)
+
+
+def test_wino6_accuracy_class_and_tiny_gradients():
+    """Six exact-split bf16 products per fp32 product keep the fp32 class: largest deviation from the float64
+    convolution at K = 9 x 256 within 4e-6 of the output scale (the fp32 Winograd tile's class), and unchanged in RELATIVE
+    terms for operands of magnitude 1e-8 (input gradients of a mean loss are that small; bf16 keeps fp32's exponent)."""
+    ops = _ops()
+    N, H, W, Ci, Co = 1, 32, 64, 256, 64
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=3.0 / np.sqrt(Ci * 9))
+    ref = F.conv2d(x, w, None, 1, 1)
+    scale = float(ref.abs().max())
+    w6 = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_FWD, Co, Ci)
+    w1 = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+    errs = {}
+    for algo, wp in ((5, w6), (1, w1)):
+        out = torch.empty(N, H, W, Co, device="cuda")
+        ops.conv2d(nhwc(x), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=64, algo=algo)
+        errs[algo] = float((nchw(out) - ref).abs().max())
+    assert errs[5] < 4e-6 * scale and errs[1] < 4e-6 * scale, errs
+    assert errs[5] < 2.0 * errs[1], errs
+    out = torch.empty(N, H, W, Co, device="cuda")
+    ops.conv2d(nhwc(x * 1e-8), w6, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=64, algo=5)
+    assert float((nchw(out) * 1e8 - ref).abs().max()) < 4e-6 * scale
+
+
+def test_wino6_rejects_bad_arguments():
+    ops = _ops()
+    from refid_amd._lib import RefidHipError
+    x = torch.randn(1, 8, 32, 64, device="cuda")
+    w = torch.randn(32, 64, 3, 3, device="cuda")
+    with pytest.raises(RefidHipError, match="more than 32 output channels"):
+        ops.conv2d(x, ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, 32, 64), torch.empty(1, 8, 32, 32, device="cuda"),
+                   kh=3, kw=3, pad=1, cout=32, cout_pad=64, algo=5)
+    w = torch.randn(64, 48, 3, 3, device="cuda")
+    xa, xb = torch.randn(1, 8, 32, 24, device="cuda"), torch.randn(1, 8, 32, 24, device="cuda")
+    with pytest.raises(RefidHipError, match="multiple of 16"):
+        ops.conv2d(xa, ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, 64, 48), torch.empty(1, 8, 32, 64, device="cuda"),
+                   kh=3, kw=3, pad=1, cout=64, cout_pad=64, in_b=xb, algo=5)
+    with pytest.raises(RefidHipError):
+        ops.pack_conv_weights_wino6(w, ops.ROLE_FWD, 64, 48)
 
 
 @pytest.mark.parametrize("cfg", [(1, 16, 32, 32, 64), (1, 9, 24, 128, 64), (1, 8, 16, 256, 128)])

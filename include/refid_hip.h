@@ -35,6 +35,9 @@ extern "C" {
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
+/* 1 when the library was built with REFID_EXPERIMENTAL_TILES=1 (tiles that were measured and are never selected by
+ * default, e.g. refid_conv_desc.wino_tile = 2); the product build returns 0 and ignores such hints. */
+int refid_experimental_tiles(void);
 
 /* Device facts used by the host-side scheduler (CU count etc.); -1 on failure. */
 int refid_device_cu_count(void);
@@ -134,7 +137,10 @@ typedef struct refid_conv_desc {
     int wino_tile;                              /* algo 1 only: 0 / 1 = the 2-waves-per-SIMD tile (4x32 px x 64 ch
                                                    workgroups; the default); 2 = the persistent one-wave-per-SIMD tile
                                                    (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
-                                                   geometry allows.  Same results bit for bit; 2 measured slower.     */
+                                                   geometry allows -- ONLY in libraries built with
+                                                   REFID_EXPERIMENTAL_TILES=1 (refid_experimental_tiles()); the product
+                                                   build runs the default tile.  Same results bit for bit; 2 measured
+                                                   10-30 % slower.                                                    */
     const refid_pw_extras* pw;                  /* algo 3 only: fusions around the pointwise conv, or NULL               */
     int mfma_terms;                             /* algo 4 only: 0 / 6 = three bf16 planes per operand, six products
                                                    (error <= 2^-23 per product: fp32 class, closer to the fp64 result

@@ -15,6 +15,9 @@ LIB = os.path.join(HERE, "librefid_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed"]
+# Tiles that were measured and lost (csrc/experimental/: the persistent one-wave-per-SIMD Winograd tile) stay out of the
+# product library; REFID_EXPERIMENTAL_TILES=1 builds them in (tools/bench_wino2.py, the tile's own tests).
+EXPERIMENTAL = os.environ.get("REFID_EXPERIMENTAL_TILES", "0") == "1"
 
 
 def _newer(src_list, target):
@@ -26,6 +29,16 @@ def _newer(src_list, target):
 
 def build(verbose=False, force=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    flags = list(FLAGS)
+    stamp = os.path.join(CSRC, ".experimental")          # a change of the switch rebuilds everything
+    was = os.path.exists(stamp)
+    if EXPERIMENTAL:
+        srcs += sorted(glob.glob(os.path.join(CSRC, "experimental", "*.hip")))
+        flags.append("-DREFID_EXPERIMENTAL_TILES")
+        open(stamp, "w").close()
+    elif was:
+        os.remove(stamp)
+    force = force or (was != EXPERIMENTAL)
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "refid_hip.h")]
     objs = []
     jobs = []
@@ -37,7 +50,7 @@ def build(verbose=False, force=False):
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + flags + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -20,8 +20,8 @@
 //     exchange through LDS (one barrier) and the epilogue's LDS reads are serial with the matrix pipe;
 //   * LDS halo image stored with even / odd pixel columns split and a row pitch of 40 float4, so the four patch
 //     columns of the 32 tiles of a wave are conflict-free ds_read_b128 (the 2-waves tile had 2-way conflicts).
-#include "common.h"
-#include "conv_args.h"
+#include "../common.h"
+#include "../conv_args.h"
 
 namespace {
 

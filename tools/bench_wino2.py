@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""2-waves-per-SIMD Winograd tile vs the persistent one-wave-per-SIMD tile at the config-2 shapes (B=8)."""
+"""(Needs a library built with REFID_EXPERIMENTAL_TILES=1 python -m refid_amd.build.)
+2-waves-per-SIMD Winograd tile vs the persistent one-wave-per-SIMD tile at the config-2 shapes (B=8)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

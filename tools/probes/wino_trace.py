@@ -25,9 +25,10 @@ def build():
     build_main()
     os.makedirs(BIN, exist_ok=True)
     traced = []
-    for src in ("conv_wino", "conv_wino2"):
-        obj = os.path.join(BIN, src + "_trace.o")
-        subprocess.check_call([HIPCC] + FLAGS + ["-DREFID_WINO_TRACE", "-I", os.path.join(ROOT, "refid_amd", "csrc"),
+    for src in ("conv_wino", "experimental/conv_wino2"):
+        obj = os.path.join(BIN, os.path.basename(src) + "_trace.o")
+        subprocess.check_call([HIPCC] + FLAGS + ["-DREFID_WINO_TRACE", "-DREFID_EXPERIMENTAL_TILES", "-I",
+                                                 os.path.join(ROOT, "refid_amd", "csrc"),
                                                  "-c", os.path.join(ROOT, "refid_amd", "csrc", src + ".hip"), "-o", obj])
         traced.append(obj)
     objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "refid_amd", "csrc", "*.o")))

@@ -269,8 +269,11 @@ int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float*
                           int ld_out, long long npix, int c, float eps, void* stream);
 /* LayerNormFunction.backward, fusion_modules.py:110-122; gx = (res ? res : 0) + dL/dx.  res may be
  * NULL or alias gx (in-place accumulate); pass a distinct gx when another stream still reads res. */
+/* parts: scratch of refid_layernorm2d_bwd_parts(npix, c) * 2c floats (per-workgroup partial sums of dw / db, added in a
+ * fixed order: the parameter gradients are deterministic, no floating-point atomics). */
+int refid_layernorm2d_bwd_parts(long long npix, int c);
 int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
-                          int ld_gx, const float* res, int ld_res, float* dw, float* db, long long npix,
+                          int ld_gx, const float* res, int ld_res, float* dw, float* db, float* parts, long long npix,
                           int c, float eps, void* stream);
 /* ------------------------------------------------------------------------------------
  * SingleMultiConnectEVHINet non-GEMM pieces (SURVEY.md 8f row 4;
@@ -302,29 +305,34 @@ int refid_dwconv_pool_parts(int h, int wd, int c);
 int refid_dwconv3x3_gelu_fwd(const float* in, int ld_in, const float* w, const float* b, float* pre,
                              float* act, float* pool, int n, int h, int wd, int c, void* stream);
 /* gd = gradient w.r.t. `pre`; gin = input gradient; dw/db accumulate.  parts: scratch of
- * n * refid_dwconv3x3_bwd_parts(h,wd,c) * 10c floats (deterministic two-stage reduction) or NULL (atomics). */
+ * n * refid_dwconv3x3_bwd_parts(h,wd,c) * 10c floats (deterministic two-stage reduction; required). */
 int refid_dwconv3x3_bwd_parts(int h, int wd, int c);
 int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
                         float* dw, float* db, float* parts, int n, int h, int wd, int c, void* stream);
 /* se_1 (fm:253-260): m = (sum_parts pool)*inv_hw ; z1 = relu(W1 m + b1) ; s = sigmoid(W2 z1 + b2) */
 int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const float* w1, const float* b1, const float* w2,
                  const float* b2, float* m, float* z1, float* s, int n, int c, void* stream);
+/* scratch: n * (c + c/2) floats; the samples' contributions to dw1 / db1 / dw2 / db2 are added in sample order */
 int refid_se_bwd(const float* gs, const float* s, const float* z1, const float* m, const float* w1,
-                 const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, int n, int c,
-                 void* stream);
+                 const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, float* scratch, int n,
+                 int c, void* stream);
 /* out[n,p,0:c] = xi*s[n] ; out[n,p,c:2c] = xe*s[n]   (fm:312-315, no cat temporary) */
 int refid_scale_cat(const float* xi, const float* xe, const float* s, float* out, int n, int hw, int c,
                     void* stream);
 /* gs[n][c] = sum_p gxs[n,p,c]*xi + gxs[n,p,c+C]*xe  (dL/ds of the two products) */
-int refid_egaca_gs_reduce(const float* gxs, const float* xi, const float* xe, float* gs, int n, int hw,
+/* parts: scratch of n * refid_egaca_gs_reduce_parts(hw, c) * c floats (fixed-order two-stage reduction) */
+int refid_egaca_gs_reduce_parts(int hw, int c);
+int refid_egaca_gs_reduce(const float* gxs, const float* xi, const float* xe, float* gs, float* parts, int n, int hw,
                           int c, void* stream);
 /* gdwe = (gxs_e*s + gm*inv_hw) * GELU'(dwe) ; gxi (+)= gxs_i*s */
 int refid_egaca_bwd_elem(const float* gxs, const float* s, const float* gm, float inv_hw, const float* dwe,
                          float* gdwe, float* gxi, int accumulate_xi, int n, int hw, int c, void* stream);
 int refid_gelu_fwd(const float* in, float* out, long long count, void* stream);
 int refid_gelu_bwd(const float* g, const float* in, float* out, long long count, void* stream);
-/* db[c] += sum_p g[p][c]   (bias gradient where the wgrad call does not carry it) */
-int refid_colsum(const float* g, int ld_g, float* db, long long npix, int c, void* stream);
+/* db[c] += sum_p g[p][c]   (bias gradient where the wgrad call does not carry it); parts: scratch of
+ * refid_colsum_parts(npix, c) * c floats (fixed-order two-stage reduction) */
+int refid_colsum_parts(long long npix, int c);
+int refid_colsum(const float* g, int ld_g, float* db, float* parts, long long npix, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Train-step tail (twoImage_event_recurrent_model.py:273-310; losses/losses.py:28-30,143-173).

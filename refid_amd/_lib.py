@@ -123,19 +123,22 @@ def _bind_extra(L):
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
     L.refid_fold_back.argtypes = [vp] * 8 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
-    L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, ll, i, f, vp]
+    L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, vp, ll, i, f, vp]
+    L.refid_layernorm2d_bwd_parts.argtypes = [ll, i]
+    L.refid_colsum_parts.argtypes = [ll, i]
+    L.refid_egaca_gs_reduce_parts.argtypes = [i, i]
     L.refid_dwconv3x3_gelu_fwd.argtypes = [vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
     L.refid_dwconv3x3_bwd.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, i, i, i, i, vp]
     L.refid_dwconv3x3_bwd_parts.argtypes = [i, i, i]
     L.refid_se_fwd.argtypes = [vp, i, f, vp, vp, vp, vp, vp, vp, vp, i, i, vp]
     L.refid_dwconv_pool_parts.argtypes = [i, i, i]
-    L.refid_se_bwd.argtypes = [vp] * 11 + [i, i, vp]
+    L.refid_se_bwd.argtypes = [vp] * 12 + [i, i, vp]
     L.refid_scale_cat.argtypes = [vp, vp, vp, vp, i, i, i, vp]
-    L.refid_egaca_gs_reduce.argtypes = [vp, vp, vp, vp, i, i, i, vp]
+    L.refid_egaca_gs_reduce.argtypes = [vp, vp, vp, vp, vp, i, i, i, vp]
     L.refid_egaca_bwd_elem.argtypes = [vp, vp, vp, f, vp, vp, vp, i, i, i, i, vp]
     L.refid_gelu_fwd.argtypes = [vp, vp, ll, vp]
     L.refid_gelu_bwd.argtypes = [vp, vp, vp, ll, vp]
-    L.refid_colsum.argtypes = [vp, i, vp, ll, i, vp]
+    L.refid_colsum.argtypes = [vp, i, vp, vp, ll, i, vp]
     L.refid_charbonnier.argtypes = [vp, vp, vp, vp, ll, f, f, vp]
     L.refid_grad_sqnorm.argtypes = [vp, vp, ll, vp]
     L.refid_psnr_loss.argtypes = [vp, vp, vp, vp, vp, i, ll, f, vp]

@@ -31,6 +31,16 @@ void refid_set_error(const char* fmt, ...);
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 
+// Deterministic sum over the threads of a wave that share q = lane % LPP (LPP a power of two): fixed xor-shuffle tree;
+// the total ends up in every lane.  (Reductions of parameter gradients never use floating-point atomics: a step's
+// bits do not depend on arrival order.)
+template <int LPP>
+__device__ __forceinline__ float refid_wave_rows_sum(float v) {
+#pragma unroll
+    for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

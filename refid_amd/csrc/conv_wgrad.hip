@@ -210,14 +210,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgKArgs a) {
     }
     // ---- bias partial: only the first input-channel tile column owns it -------------------
     if (a.bslabs != nullptr && blockIdx.y == 0) {
-        if (tid < C::COT) sBias[tid] = 0.f;
+        // fixed order (no LDS atomics): xor-shuffle tree over the wave's threads that share gq, then the four waves
+        // in sequence; the operand tiles at the start of the LDS are dead here (every wave is past its last read)
+        float* sred = reinterpret_cast<float*>(smem);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
+        for (int k = 0; k < 4; ++k) {
+            const float v = refid_wave_rows_sum<C::G4>(bsum[k]);
+            if ((tid & 63) < C::G4) sred[(tid >> 6) * C::COT + gq * 4 + k] = v;
+        }
         __syncthreads();
         if (tid < C::COT) {
+            const float tot = ((sred[tid] + sred[C::COT + tid]) + sred[2 * C::COT + tid]) + sred[3 * C::COT + tid];
             float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
-            *dst = a.accum ? *dst + sBias[tid] : sBias[tid];
+            *dst = a.accum ? *dst + tot : tot;
         }
     }
 }
@@ -563,8 +569,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (ci + j >= a.Ci) break;
-                if (gridDim.y > 1) atomicAdd(d + (long long)j * a.ntaps, sum[j]);
-                else d[(long long)j * a.ntaps] += sum[j];       // single group: this thread owns the element
+                d[(long long)j * a.ntaps] += sum[j];            // one group: this thread owns the element (deterministic)
             }
         }
     }
@@ -572,8 +577,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
         for (int co = threadIdx.x; co < a.Co; co += 256) {
             float s = 0.f;
             for (int k = s0; k < s1; ++k) s += a.bslabs[(long long)k * a.CoP + co];
-            if (gridDim.y > 1) atomicAdd(a.db + co, s);
-            else a.db[co] += s;
+            a.db[co] += s;
         }
     }
 }
@@ -777,13 +781,10 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total4 = (long long)p.ntaps * g.CoP * (g.CiP / 4);
     const int nb = (int)((total4 + 255) / 256);
-    // split groups only where one thread per float4 would leave the chip idle (small weight tensors)
-    int groups = (int)(65536 / total4);
-    if (groups > 8) groups = 8;
-    if (groups > g.nsplit) groups = g.nsplit;
-    if (groups < 1) groups = 1;
-    r.perGroup = cdiv(g.nsplit, groups);
-    groups = cdiv(g.nsplit, r.perGroup);
+    // ONE group: every element of dw is owned by one thread that adds the slabs in slab order -- deterministic (splitting
+    // the slabs over grid.y needed floating-point atomics into dw)
+    int groups = 1;
+    r.perGroup = g.nsplit;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb, groups), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_reduce");
     return 0;

@@ -10,8 +10,9 @@
 //
 // All of these are bandwidth-bound: every thread moves 16 bytes per access (float4 over 4
 // consecutive NHWC channels), a pixel's C channels are read by C/4 adjacent lanes (fully
-// coalesced 4*C-byte runs), reductions go wave-shuffle -> LDS -> one atomic per channel per
-// block.
+// coalesced 4*C-byte runs).  Parameter-gradient reductions are DETERMINISTIC: fixed xor-shuffle tree over
+// the pixel rows of a wave -> the four waves in order through LDS -> one partial row per workgroup in the
+// caller's scratch -> a second tiny kernel adds the rows in a fixed order.  No floating-point atomics.
 #include "common.h"
 
 namespace {
@@ -29,6 +30,34 @@ __device__ __forceinline__ float group_sum(float v) {
 #pragma unroll
     for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Sum over the workgroup's pixel rows (threads that share q = tid % LPP) in a FIXED order: xor-shuffle tree over the
+// rows of a wave (the value ends up in every lane), then lanes < LPP of each wave put it into sh[wave][col].
+template <int LPP>
+__device__ __forceinline__ float wave_rows_sum(float v) {
+#pragma unroll
+    for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// out[i] += sum_rows parts[row][i] for i < n_a (into dst_a) and n_a <= i < ncols (into dst_b; dst_b may be NULL when
+// n_a == ncols); accumulate = 0 overwrites.  One wave per column: lanes stride over the partial rows, then a fixed
+// xor-shuffle tree -- deterministic.
+__global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ parts, int nrows, int ncols,
+                                                      float* __restrict__ dst_a, int n_a, float* __restrict__ dst_b,
+                                                      int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= ncols) return;
+    float a = 0.f;
+    for (int b = lane; b < nrows; b += 64) a += parts[(long long)b * ncols + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) {
+        float* d = i < n_a ? dst_a + i : dst_b + (i - n_a);
+        *d = accumulate ? *d + a : a;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -52,18 +81,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // LayerNorm2d backward: fm:110-122.  gx = rstd * (g*w - y*mean(g*w*y) - mean(g*w)),
-// dw += sum g*y, db += sum g.   gx accumulates into `gx` when acc != 0.
+// parts[block][0:C] = sum g*y, parts[block][C:2C] = sum g over the block's pixels (rows_sum_kernel adds them into dw / db).
 template <int LPP>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g, int ldg,
                                                     const float* __restrict__ x, int ldx,
                                                     const float* __restrict__ w, float* gx, int ldgx,
-                                                    const float* res, int ldr, float* __restrict__ dw,
-                                                    float* __restrict__ db, long long npix, float eps) {
+                                                    const float* res, int ldr, float* __restrict__ parts,
+                                                    long long npix, float eps) {
     constexpr int C = LPP * 4, PPB = 256 / LPP;
-    __shared__ float sdw[C], sdb[C];
+    __shared__ float sred[4][2 * C];
     const int q = threadIdx.x % LPP;
-    if (threadIdx.x < C) { sdw[threadIdx.x] = 0.f; sdb[threadIdx.x] = 0.f; }
-    __syncthreads();
     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + q * 4);
     f32x4 pdw = {0.f, 0.f, 0.f, 0.f}, pdb = {0.f, 0.f, 0.f, 0.f};
     // U pixels per thread per iteration: their 2-3 loads each are issued together (the four lane-group reductions per
@@ -100,10 +127,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ g
             }
         }
     }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { atomicAdd(&sdw[q * 4 + k], pdw[k]); atomicAdd(&sdb[q * 4 + k], pdb[k]); }
+    for (int k = 0; k < 4; ++k) {
+        const float a = wave_rows_sum<LPP>(pdw[k]), b = wave_rows_sum<LPP>(pdb[k]);
+        if (lane < LPP) { sred[wave][q * 4 + k] = a; sred[wave][C + q * 4 + k] = b; }
+    }
     __syncthreads();
-    if (threadIdx.x < C) { atomicAdd(dw + threadIdx.x, sdw[threadIdx.x]); atomicAdd(db + threadIdx.x, sdb[threadIdx.x]); }
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+        parts[(long long)blockIdx.x * (2 * C) + i] = ((sred[0][i] + sred[1][i]) + sred[2][i]) + sred[3][i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -171,14 +203,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ i
 template <int LPP>
 __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ in,
                                                     int ldi, const float* __restrict__ w, float* __restrict__ gin,
-                                                    float* __restrict__ dw, float* __restrict__ db,
                                                     float* __restrict__ parts, int H, int W) {
     constexpr int C = LPP * 4, PPB = 256 / LPP;
-    __shared__ float sdw[C * 9], sdb[C];
+    __shared__ float sred[4][C * 10];
     const int q = threadIdx.x % LPP, n = blockIdx.y;
-    for (int i = threadIdx.x; i < C * 9; i += 256) sdw[i] = 0.f;
-    if (threadIdx.x < C) sdb[threadIdx.x] = 0.f;
-    __syncthreads();
     float wr[4][9], pw[4][9];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -218,35 +246,21 @@ __global__ __launch_bounds__(256) void dw_bwd_kernel(const float* __restrict__ g
         *reinterpret_cast<f32x4*>(gin + ((long long)n * HW + p) * C + q * 4) = a;
         pb += g0;
     }
+    // per-workgroup partials [block][C*10] (9 taps per channel, then the bias sums), fixed order; rows_sum_kernel adds them
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) atomicAdd(&sdw[(q * 4 + k) * 9 + t], pw[k][t]);
-        atomicAdd(&sdb[q * 4 + k], pb[k]);
+        for (int t = 0; t < 9; ++t) {
+            const float a = wave_rows_sum<LPP>(pw[k][t]);
+            if (lane < LPP) sred[wave][(q * 4 + k) * 9 + t] = a;
+        }
+        const float b = wave_rows_sum<LPP>(pb[k]);
+        if (lane < LPP) sred[wave][C * 9 + q * 4 + k] = b;
     }
     __syncthreads();
-    if (parts) {            // per-workgroup partials [block][C*10]; summed in fixed order by dw_bwd_sum_kernel
-        float* dst = parts + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (C * 10);
-        for (int i = threadIdx.x; i < C * 9; i += 256) dst[i] = sdw[i];
-        if (threadIdx.x < C) dst[C * 9 + threadIdx.x] = sdb[threadIdx.x];
-        return;
-    }
-    for (int i = threadIdx.x; i < C * 9; i += 256) atomicAdd(dw + i, sdw[i]);
-    if (threadIdx.x < C) atomicAdd(db + threadIdx.x, sdb[threadIdx.x]);
-}
-
-// dw[i] += sum_blocks parts[b][i] ; db likewise.  One wave per column i: lanes stride over the partial rows, then a
-// fixed xor-shuffle tree -- deterministic.
-__global__ __launch_bounds__(256) void dw_bwd_sum_kernel(const float* __restrict__ parts, int nblk, int C,
-                                                        float* __restrict__ dw, float* __restrict__ db) {
-    const int row = C * 10, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= row) return;
-    float a = 0.f;
-    for (int b = lane; b < nblk; b += 64) a += parts[(long long)b * row + i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-    if (lane == 0) { if (i < C * 9) dw[i] += a; else db[i - C * 9] += a; }
+    float* dst = parts + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * (C * 10);
+    for (int i = threadIdx.x; i < C * 10; i += 256) dst[i] = ((sred[0][i] + sred[1][i]) + sred[2][i]) + sred[3][i];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -307,14 +321,12 @@ __global__ __launch_bounds__(256) void se_fwd_kernel(const float* __restrict__ p
     }
 }
 
-// SE backward, one block per sample; parameter gradients accumulate with atomics:
-// given gs = dL/ds: gm = dL/dm ; dW1,db1,dW2,db2 += ...
+// SE backward, one block per sample: given gs = dL/ds: gm = dL/dm, and the per-sample vectors d2 (C) / d1 (C/2) go to
+// `scratch` (n, C + C/2); se_bwd_params_kernel then adds the samples' outer products in sample order (deterministic).
 __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ gs, const float* __restrict__ s,
                                                     const float* __restrict__ z1, const float* __restrict__ m,
                                                     const float* __restrict__ W1, const float* __restrict__ W2,
-                                                    float* __restrict__ gm, float* __restrict__ dW1,
-                                                    float* __restrict__ db1, float* __restrict__ dW2,
-                                                    float* __restrict__ db2, int N, int C) {
+                                                    float* __restrict__ gm, float* __restrict__ scratch, int N, int C) {
     __shared__ float d2[256], d1[128], sz[128], sm[256];
     const int Ch = C / 2;
     const int n = blockIdx.x;
@@ -335,13 +347,28 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ g
         float a = 0.f;
         for (int j = 0; j < Ch; ++j) a += W1[j * C + c] * d1[j];
         gm[n * C + c] = a;
-        atomicAdd(db2 + c, d2[c]);
+        scratch[n * (C + Ch) + c] = d2[c];
     }
-    for (int j = threadIdx.x; j < Ch; j += 256) atomicAdd(db1 + j, d1[j]);
-    for (int e = threadIdx.x; e < C * Ch; e += 256) {
-        atomicAdd(dW2 + e, d2[e / Ch] * sz[e % Ch]);          // W2: (C, Ch)
-        atomicAdd(dW1 + e, d1[e / C] * sm[e % C]);            // W1: (Ch, C)
+    for (int j = threadIdx.x; j < Ch; j += 256) scratch[n * (C + Ch) + C + j] = d1[j];
+}
+
+__global__ __launch_bounds__(256) void se_bwd_params_kernel(const float* __restrict__ scratch, const float* __restrict__ z1,
+                                                           const float* __restrict__ m, float* __restrict__ dW1,
+                                                           float* __restrict__ db1, float* __restrict__ dW2,
+                                                           float* __restrict__ db2, int N, int C) {
+    const int Ch = C / 2, S = C + Ch;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < C * Ch) {
+        float a2 = 0.f, a1 = 0.f;
+        for (int n = 0; n < N; ++n) {
+            a2 += scratch[n * S + e / Ch] * z1[n * Ch + e % Ch];          // W2: (C, Ch)
+            a1 += scratch[n * S + C + e / C] * m[n * C + e % C];          // W1: (Ch, C)
+        }
+        dW2[e] += a2;
+        dW1[e] += a1;
     }
+    if (e < C) { float a = 0.f; for (int n = 0; n < N; ++n) a += scratch[n * S + e]; db2[e] += a; }
+    if (e < Ch) { float a = 0.f; for (int n = 0; n < N; ++n) a += scratch[n * S + C + e]; db1[e] += a; }
 }
 
 // out[n,p,0:C] = xi*s[n] ; out[n,p,C:2C] = xe*s[n]      (fm:312-315 without the cat temp)
@@ -361,15 +388,13 @@ __global__ __launch_bounds__(256) void scale_cat_kernel(const float* __restrict_
     }
 }
 
-// gs[n][c] += sum_p gxs[n,p,c]*xi[n,p,c] + gxs[n,p,C+c]*xe[n,p,c]   ; grid = (chunks, N)
+// parts[n][block][c] = sum_p(block) gxs[n,p,c]*xi[n,p,c] + gxs[n,p,C+c]*xe[n,p,c]   ; grid = (chunks, N)
 template <int LPP>
 __global__ __launch_bounds__(256) void gs_reduce_kernel(const float* __restrict__ gxs, const float* __restrict__ xi,
-                                                       const float* __restrict__ xe, float* __restrict__ gs, int HW) {
+                                                       const float* __restrict__ xe, float* __restrict__ parts, int HW) {
     constexpr int C = LPP * 4, PPB = 256 / LPP;
-    __shared__ float sg[C];
+    __shared__ float sred[4][C];
     const int q = threadIdx.x % LPP, n = blockIdx.y;
-    if (threadIdx.x < C) sg[threadIdx.x] = 0.f;
-    __syncthreads();
     f32x4 ps = {0.f, 0.f, 0.f, 0.f};
     for (int p = blockIdx.x * PPB + threadIdx.x / LPP; p < HW; p += gridDim.x * PPB) {
         const long long pix = (long long)n * HW + p;
@@ -379,10 +404,27 @@ __global__ __launch_bounds__(256) void gs_reduce_kernel(const float* __restrict_
         const f32x4 b = *reinterpret_cast<const f32x4*>(xe + pix * C + q * 4);
         ps += gi * a + ge * b;
     }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(&sg[q * 4 + k], ps[k]);
+    for (int k = 0; k < 4; ++k) {
+        const float a = wave_rows_sum<LPP>(ps[k]);
+        if (lane < LPP) sred[wave][q * 4 + k] = a;
+    }
     __syncthreads();
-    if (threadIdx.x < C) atomicAdd(gs + n * C + threadIdx.x, sg[threadIdx.x]);
+    if (threadIdx.x < C)
+        parts[((long long)n * gridDim.x + blockIdx.x) * C + threadIdx.x] =
+            ((sred[0][threadIdx.x] + sred[1][threadIdx.x]) + sred[2][threadIdx.x]) + sred[3][threadIdx.x];
+}
+
+// gs[n][c] = sum_blocks parts[n][block][c], blocks in order (one thread per (n, c))
+__global__ __launch_bounds__(256) void gs_sum_kernel(const float* __restrict__ parts, int nblk, int C, int total,
+                                                    float* __restrict__ gs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int n = i / C, c = i % C;
+    float a = 0.f;
+    for (int b = 0; b < nblk; ++b) a += parts[((long long)n * nblk + b) * C + c];
+    gs[i] = a;
 }
 
 // gdwe = (gxs_e*s + gm/HW) * gelu'(dwe) ;  gxi_acc (+)= gxs_i*s
@@ -432,21 +474,23 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const f32x4* __restrict__
     }
 }
 
-// db[c] += sum_p g[p][c]  (bias gradient of ConvTranspose2d); C/4 must divide 256
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int ldg, float* __restrict__ db,
+// parts[block][c] = sum_p(block) g[p][c]  (bias gradient of ConvTranspose2d); C/4 a power of two <= 256.
+// Fixed order: every thread's pixels in sequence, the block's pixel rows in sequence, rows_sum_kernel over the blocks.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ g, int ldg, float* __restrict__ parts,
                                                     int C, long long npix) {
-    __shared__ float sb[1024];
+    __shared__ f32x4 sb[256];
     const int Q = C / 4, PPB = 256 / Q;
     const int q = threadIdx.x % Q;
-    for (int i = threadIdx.x; i < C; i += 256) sb[i] = 0.f;
-    __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (long long p = blockIdx.x * (long long)PPB + threadIdx.x / Q; p < npix; p += (long long)gridDim.x * PPB)
         acc += *reinterpret_cast<const f32x4*>(g + p * ldg + q * 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) atomicAdd(&sb[q * 4 + k], acc[k]);
+    sb[threadIdx.x] = acc;
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(db + i, sb[i]);
+    if (threadIdx.x < Q) {
+        f32x4 a = sb[threadIdx.x];
+        for (int r = 1; r < PPB; ++r) a += sb[r * Q + threadIdx.x];
+        *reinterpret_cast<f32x4*>(parts + (long long)blockIdx.x * C + threadIdx.x * 4) = a;
+    }
 }
 
 // beta/gamma fold-back (see refid_hip.h): per row r, Gf / gbf = gradient of the FOLDED weights of this backward:
@@ -502,14 +546,22 @@ extern "C" int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, c
     return 0;
 }
 
+extern "C" int refid_layernorm2d_bwd_parts(long long npix, int c) {
+    if (c != 16 && c != 32 && c != 64 && c != 128) return -1;
+    return blocks_for(npix, 256 / (c / 4), 512);
+}
+
 extern "C" int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, int ld_x, const float* w, float* gx,
-                                     int ld_gx, const float* res, int ld_res, float* dw, float* db, long long npix,
-                                     int c, float eps, void* stream) {
-    REFID_CHECK(g && x && w && gx && dw && db && npix > 0, "layernorm2d_bwd: bad arguments");
+                                     int ld_gx, const float* res, int ld_res, float* dw, float* db, float* parts,
+                                     long long npix, int c, float eps, void* stream) {
+    REFID_CHECK(g && x && w && gx && dw && db && parts && npix > 0, "layernorm2d_bwd: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    LPP_DISPATCH(c, hipLaunchKernelGGL(ln_bwd_kernel<LPP>, dim3(blocks_for(npix, 256 / LPP, 512)), dim3(256), 0, st,
-                                       g, ld_g, x, ld_x, w, gx, ld_gx, res, ld_res, dw, db, npix, eps));
+    const int nb = refid_layernorm2d_bwd_parts(npix, c);
+    LPP_DISPATCH(c, hipLaunchKernelGGL(ln_bwd_kernel<LPP>, dim3(nb), dim3(256), 0, st,
+                                       g, ld_g, x, ld_x, w, gx, ld_gx, res, ld_res, parts, npix, eps));
     REFID_LAUNCH_CHECK("layernorm2d_bwd");
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(2 * c, 4)), dim3(256), 0, st, parts, nb, 2 * c, dw, c, db, 1);
+    REFID_LAUNCH_CHECK("layernorm2d_bwd/sum");
     return 0;
 }
 
@@ -535,18 +587,15 @@ extern "C" int refid_dwconv3x3_bwd_parts(int h, int wd, int c) {
 
 extern "C" int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, const float* w, float* gin,
                                    float* dw, float* db, float* parts, int n, int h, int wd, int c, void* stream) {
-    REFID_CHECK(gd && in && w && gin && dw && db && n > 0, "dwconv3x3_bwd: bad arguments");
+    REFID_CHECK(gd && in && w && gin && dw && db && parts && n > 0, "dwconv3x3_bwd: bad arguments (parts is required)");
     hipStream_t st = (hipStream_t)stream;
-    // with a scratch buffer (n * refid_dwconv3x3_bwd_parts() * 10c floats) the parameter gradients are reduced
-    // deterministically in two stages; without one they fall back to fp32 atomics on fewer, longer workgroups
-    const int nb = parts ? refid_dwconv3x3_bwd_parts(h, wd, c) : blocks_for((long long)h * wd, 256 / (c / 4 > 0 ? c / 4 : 1), 64);
-    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_bwd_kernel<LPP>, dim3(nb, n), dim3(256), 0, st, gd, in, ld_in, w, gin, dw, db,
-                                       parts, h, wd));
+    // the parameter gradients are reduced deterministically in two stages through the caller's scratch buffer
+    // (n * refid_dwconv3x3_bwd_parts() * 10c floats)
+    const int nb = refid_dwconv3x3_bwd_parts(h, wd, c);
+    LPP_DISPATCH(c, hipLaunchKernelGGL(dw_bwd_kernel<LPP>, dim3(nb, n), dim3(256), 0, st, gd, in, ld_in, w, gin, parts, h, wd));
     REFID_LAUNCH_CHECK("dwconv3x3_bwd");
-    if (parts) {
-        hipLaunchKernelGGL(dw_bwd_sum_kernel, dim3(cdiv(c * 10, 4)), dim3(256), 0, st, parts, nb * n, c, dw, db);
-        REFID_LAUNCH_CHECK("dwconv3x3_bwd/sum");
-    }
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(c * 10, 4)), dim3(256), 0, st, parts, nb * n, c * 10, dw, c * 9, db, 1);
+    REFID_LAUNCH_CHECK("dwconv3x3_bwd/sum");
     return 0;
 }
 
@@ -562,13 +611,15 @@ extern "C" int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const 
 }
 
 extern "C" int refid_se_bwd(const float* gs, const float* s, const float* z1, const float* m, const float* w1,
-                            const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, int n, int c,
-                            void* stream) {
-    REFID_CHECK(gs && s && z1 && m && w1 && w2 && gm && dw1 && db1 && dw2 && db2 && n > 0 && c <= 256,
+                            const float* w2, float* gm, float* dw1, float* db1, float* dw2, float* db2, float* scratch,
+                            int n, int c, void* stream) {
+    REFID_CHECK(gs && s && z1 && m && w1 && w2 && gm && dw1 && db1 && dw2 && db2 && scratch && n > 0 && c <= 256,
                 "se_bwd: bad arguments");
-    hipLaunchKernelGGL(se_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, gs, s, z1, m, w1, w2, gm, dw1, db1,
-                       dw2, db2, n, c);
+    hipLaunchKernelGGL(se_bwd_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, gs, s, z1, m, w1, w2, gm, scratch, n, c);
     REFID_LAUNCH_CHECK("se_bwd");
+    hipLaunchKernelGGL(se_bwd_params_kernel, dim3(cdiv(c * (c / 2), 256)), dim3(256), 0, (hipStream_t)stream, scratch, z1, m,
+                       dw1, db1, dw2, db2, n, c);
+    REFID_LAUNCH_CHECK("se_bwd/params");
     return 0;
 }
 
@@ -583,15 +634,20 @@ extern "C" int refid_scale_cat(const float* xi, const float* xe, const float* s,
     return 0;
 }
 
-extern "C" int refid_egaca_gs_reduce(const float* gxs, const float* xi, const float* xe, float* gs, int n, int hw,
-                                     int c, void* stream) {
-    REFID_CHECK(gxs && xi && xe && gs && n > 0 && hw > 0, "egaca_gs_reduce: bad arguments");
+extern "C" int refid_egaca_gs_reduce_parts(int hw, int c) {
+    if (c != 16 && c != 32 && c != 64 && c != 128) return -1;
+    return blocks_for(hw, 256 / (c / 4), 128);
+}
+
+extern "C" int refid_egaca_gs_reduce(const float* gxs, const float* xi, const float* xe, float* gs, float* parts, int n,
+                                     int hw, int c, void* stream) {
+    REFID_CHECK(gxs && xi && xe && gs && parts && n > 0 && hw > 0, "egaca_gs_reduce: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(gs, 0, sizeof(float) * n * c, st);
-    REFID_CHECK(e == hipSuccess, "egaca_gs_reduce: memset failed: %s", hipGetErrorString(e));
-    LPP_DISPATCH(c, hipLaunchKernelGGL(gs_reduce_kernel<LPP>, dim3(blocks_for(hw, 256 / LPP, 128), n), dim3(256), 0,
-                                       st, gxs, xi, xe, gs, hw));
+    const int nb = refid_egaca_gs_reduce_parts(hw, c);
+    LPP_DISPATCH(c, hipLaunchKernelGGL(gs_reduce_kernel<LPP>, dim3(nb, n), dim3(256), 0, st, gxs, xi, xe, parts, hw));
     REFID_LAUNCH_CHECK("egaca_gs_reduce");
+    hipLaunchKernelGGL(gs_sum_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, parts, nb, c, n * c, gs);
+    REFID_LAUNCH_CHECK("egaca_gs_reduce/sum");
     return 0;
 }
 
@@ -622,12 +678,20 @@ extern "C" int refid_gelu_bwd(const float* g, const float* in, float* out, long 
     return 0;
 }
 
-extern "C" int refid_colsum(const float* g, int ld_g, float* db, long long npix, int c, void* stream) {
-    REFID_CHECK(g && db && npix > 0 && c >= 4 && c <= 1024 && c % 4 == 0 && 256 % (c / 4) == 0,
+extern "C" int refid_colsum_parts(long long npix, int c) {
+    if (c < 4 || c > 1024 || c % 4 != 0 || 256 % (c / 4) != 0) return -1;
+    return blocks_for(npix, 256 / (c / 4), 256);
+}
+
+extern "C" int refid_colsum(const float* g, int ld_g, float* db, float* parts, long long npix, int c, void* stream) {
+    REFID_CHECK(g && db && parts && npix > 0 && c >= 4 && c <= 1024 && c % 4 == 0 && 256 % (c / 4) == 0,
                 "colsum: bad arguments (c=%d; c/4 must divide 256)", c);
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks_for(npix, 256 / (c / 4), 256)), dim3(256), 0, (hipStream_t)stream, g,
-                       ld_g, db, c, npix);
+    const int nb = refid_colsum_parts(npix, c);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ld_g, parts, c, npix);
     REFID_LAUNCH_CHECK("colsum");
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(c, 4)), dim3(256), 0, (hipStream_t)stream, parts, nb, c, db, c,
+                       (float*)nullptr, 1);
+    REFID_LAUNCH_CHECK("colsum/sum");
     return 0;
 }
 

@@ -181,14 +181,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgKArgs a) {
         }
     }
     if (a.bslabs != nullptr && blockIdx.y == 0) {
-        if (tid < COT) sBias[tid] = 0.f;
+        // fixed order (no LDS atomics): xor-shuffle tree over the wave's threads that share gq, then the four waves
+        // in sequence; the operand tiles at the start of the LDS are dead here (every wave is past its last read)
+        float* sred = reinterpret_cast<float*>(smem);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
+        for (int k = 0; k < 4; ++k) {
+            const float v = refid_wave_rows_sum<16>(bsum[k]);
+            if ((tid & 63) < 16) sred[(tid >> 6) * COT + gq * 4 + k] = v;
+        }
         __syncthreads();
         if (tid < COT) {
+            const float tot = ((sred[tid] + sred[COT + tid]) + sred[2 * COT + tid]) + sred[3 * COT + tid];
             float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
-            *dst = a.accum ? *dst + sBias[tid] : sBias[tid];
+            *dst = a.accum ? *dst + tot : tot;
         }
     }
 }

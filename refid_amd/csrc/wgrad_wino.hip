@@ -220,14 +220,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         }
     }
     if (a.bslabs != nullptr && blockIdx.y == 0) {
-        if (tid < COT) sBias[tid] = 0.f;
+        // fixed order (no LDS atomics): xor-shuffle tree over the wave's threads that share gq, then the four waves
+        // in sequence; the operand tiles at the start of the LDS are dead here (every wave is past its last read)
+        float* sred = reinterpret_cast<float*>(smem);
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(&sBias[gq * 4 + k], bsum[k]);
+        for (int k = 0; k < 4; ++k) {
+            const float v = refid_wave_rows_sum<G4>(bsum[k]);
+            if ((tid & 63) < G4) sred[(tid >> 6) * COT + gq * 4 + k] = v;
+        }
         __syncthreads();
         if (tid < COT) {
+            const float tot = ((sred[tid] + sred[COT + tid]) + sred[2 * COT + tid]) + sred[3 * COT + tid];
             float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
-            *dst = a.accum ? *dst + sBias[tid] : sBias[tid];
+            *dst = a.accum ? *dst + tot : tot;
         }
     }
 }
@@ -272,16 +278,14 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WrArgs a) 
         float* dst = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * 9;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            if (gridDim.y > 1) atomicAdd(dst + k, dg[k]);
-            else dst[k] += dg[k];
+            dst[k] += dg[k];                                // one group: this thread owns the element (deterministic)
         }
     }
     if (a.db != nullptr && blockIdx.x == 0) {
         for (int co = threadIdx.x; co < a.Co; co += 256) {
             float s = 0.f;
             for (int k = s0; k < s1; ++k) s += a.bslabs[(long long)k * a.CoP + co];
-            if (gridDim.y > 1) atomicAdd(a.db + co, s);
-            else a.db[co] += s;
+            a.db[co] += s;
         }
     }
 }
@@ -354,12 +358,8 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
     r.Ci = (d->phase == 0 && a.Ctot < d->i_total - d->i_base) ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP; r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total = (long long)r.Co * r.Ci;
-    int groups = (int)(65536 / (total > 0 ? total : 1));
-    if (groups > 16) groups = 16;
-    if (groups > g.nsplit) groups = g.nsplit;
-    if (groups < 1) groups = 1;
-    r.perGroup = cdiv(g.nsplit, groups);
-    groups = cdiv(g.nsplit, r.perGroup);
+    int groups = 1;                        // one thread owns an element and adds the slabs in order: deterministic
+    r.perGroup = g.nsplit;
     hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((int)((total + 255) / 256), groups), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_wino_reduce");
     return 0;

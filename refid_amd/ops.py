@@ -413,8 +413,13 @@ def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, res=None, eps=1e-6):
         res = gx
     pr, ldr = _nhwc(res, "res") if res is not None else (None, 0)
     npix = x.shape[0] * x.shape[1] * x.shape[2]
+    c = x.shape[3]
+    nb = lib().refid_layernorm2d_bwd_parts(npix, c)
+    if nb <= 0:
+        raise _lib.RefidHipError(f"layernorm2d_bwd: unsupported channel count {c}")
+    parts = torch.empty((nb, 2 * c), dtype=torch.float32, device=x.device)      # fixed-order partial sums of dw / db
     check(lib().refid_layernorm2d_bwd(pg, ldg, px, ldx, _c(w, "w"), pgx, ldgx, pr, ldr, _c(dw, "dw"),
-                                      _c(db, "db"), npix, x.shape[3], eps, _stream()), "refid_layernorm2d_bwd")
+                                      _c(db, "db"), parts.data_ptr(), npix, c, eps, _stream()), "refid_layernorm2d_bwd")
     return gx
 
 
@@ -469,9 +474,10 @@ def se_fwd(pool, inv_hw, w1, b1, w2, b2):
 def se_bwd(gs, s, z1, m, w1, w2, dw1, db1, dw2, db2):
     n, c = gs.shape
     gm = torch.empty_like(gs)
+    scratch = torch.empty((n, c + c // 2), dtype=torch.float32, device=gs.device)
     check(lib().refid_se_bwd(_c(gs, "gs"), _c(s, "s"), _c(z1, "z1"), _c(m, "m"), _c(w1, "w1"), _c(w2, "w2"),
-                             gm.data_ptr(), _c(dw1, "dw1"), _c(db1, "db1"), _c(dw2, "dw2"), _c(db2, "db2"), n, c,
-                             _stream()), "refid_se_bwd")
+                             gm.data_ptr(), _c(dw1, "dw1"), _c(db1, "db1"), _c(dw2, "dw2"), _c(db2, "db2"),
+                             scratch.data_ptr(), n, c, _stream()), "refid_se_bwd")
     return gm
 
 
@@ -486,8 +492,12 @@ def scale_cat(xi, xe, s):
 def egaca_gs_reduce(gxs, xi, xe):
     n, h, w, c = xi.shape
     gs = torch.empty((n, c), dtype=torch.float32, device=xi.device)
-    check(lib().refid_egaca_gs_reduce(_c(gxs, "gxs"), _c(xi, "xi"), _c(xe, "xe"), gs.data_ptr(), n, h * w, c,
-                                      _stream()), "refid_egaca_gs_reduce")
+    nb = lib().refid_egaca_gs_reduce_parts(h * w, c)
+    if nb <= 0:
+        raise _lib.RefidHipError(f"egaca_gs_reduce: unsupported channel count {c}")
+    parts = torch.empty((n, nb, c), dtype=torch.float32, device=xi.device)
+    check(lib().refid_egaca_gs_reduce(_c(gxs, "gxs"), _c(xi, "xi"), _c(xe, "xe"), gs.data_ptr(), parts.data_ptr(), n,
+                                      h * w, c, _stream()), "refid_egaca_gs_reduce")
     return gs
 
 
@@ -516,7 +526,11 @@ def gelu_bwd(g, x, out=None):
 def colsum(g, db):
     pg, ld = _nhwc(g, "g")
     npix = g.shape[0] * g.shape[1] * g.shape[2]
-    check(lib().refid_colsum(pg, ld, _c(db, "db"), npix, g.shape[3], _stream()), "refid_colsum")
+    nb = lib().refid_colsum_parts(npix, g.shape[3])
+    if nb <= 0:
+        raise _lib.RefidHipError(f"colsum: unsupported channel count {g.shape[3]}")
+    parts = torch.empty((nb, g.shape[3]), dtype=torch.float32, device=g.device)
+    check(lib().refid_colsum(pg, ld, _c(db, "db"), parts.data_ptr(), npix, g.shape[3], _stream()), "refid_colsum")
 
 
 def mul_vec(a, b, out=None):

@@ -119,17 +119,37 @@ def test_config2_train_step_gradient_properties():
         assert e3 <= tol, (policy, e3, k3)
 
 
-def test_config2_oracle_crop_gradients():
+_CROP_REF = {}
+
+
+def _crop_reference():
+    if not _CROP_REF:
+        P = _params(26, 12)
+        x, ev, gt = O.make_inputs(1, 3, 256, 256, 26, seed=3, mode="rng")
+        Pc = {k: v.clone() for k, v in P.items()}
+        _CROP_REF["v"] = (P, x, ev, gt) + tuple(O.train_step(Pc, O.TrainState(Pc), x, ev, gt))
+    return _CROP_REF["v"]
+
+
+@pytest.mark.parametrize("policy", ["auto", "bench_tiles"])
+def test_config2_oracle_crop_gradients(policy):
     """One sample of the config-2 workload at full resolution and width, first 3 time steps: output and ALL 183
-    parameter gradients against the oracle (per-tensor max-normalised)."""
-    P = _params(26, 12)
+    parameter gradients against the oracle (per-tensor max-normalised).
+    policy "auto": tile choice by the total grid of this 1-sample launch (split-K forms, conv_down on the fp32 MFMA tile);
+    policy "bench_tiles": the per-sample policy (`REFID_SPLITK=sample`: decided as if 8 samples were in the batch), i.e.
+    exactly the kernels the B=8 bench runs -- conv_down forward / input gradient on the six-product split tile, the
+    Winograd x six-product tile without split-K at the upper levels."""
+    from refid_amd import ops
+    P, x, ev, gt, loss_ref, gnorm_ref, grads_ref, pred_ref = _crop_reference()
     net = _net(26, P)
-    x, ev, gt = O.make_inputs(1, 3, 256, 256, 26, seed=3, mode="rng")
-    Pc = {k: v.clone() for k, v in P.items()}
-    loss_ref, gnorm_ref, grads_ref, pred_ref = O.train_step(Pc, O.TrainState(Pc), x, ev, gt)
-    pred = net(x=x.cuda(), event=ev.cuda())
-    loss = torch.sqrt((pred - gt.cuda()) ** 2 + 1e-12).mean()
-    loss.backward()
+    olds, ops.WINO_SPLIT = ops.WINO_SPLIT, (1 if policy == "bench_tiles" else ops.WINO_SPLIT)
+    try:
+        pred = net(x=x.cuda(), event=ev.cuda())
+        loss = torch.sqrt((pred - gt.cuda()) ** 2 + 1e-12).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.WINO_SPLIT = olds
     np.testing.assert_allclose(pred.detach().cpu().numpy(), pred_ref.numpy(), rtol=1e-3, atol=1e-4)
     assert abs(loss.item() - float(loss_ref)) < 1e-5 * float(loss_ref)
     worst = []

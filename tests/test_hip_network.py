@@ -47,6 +47,27 @@ def test_forward_config1(golden_dir):
     np.testing.assert_allclose(out[..., ::4, ::4].cpu().numpy(), z["out_sub"], rtol=RTOL, atol=ATOL)
 
 
+def test_outputs_and_gradients_are_bit_deterministic():
+    """No floating-point atomics on the path: parameter-gradient reductions (LayerNorm / depthwise / squeeze-excite /
+    bias sums / weight-gradient slabs) run in a fixed order, so two backward passes over the same inputs give the same
+    BITS for the output and all 183 gradients (weight-gradient kernels on the side stream included)."""
+    P = O.make_params(26, base_num_channels=32, mode="hash", seed=5)
+    net = build(26, 32, P)
+    x, ev, gt = O.make_inputs(2, 3, 64, 64, 26, seed=5, mode="hash")
+    x, ev, gt = x.cuda(), ev.cuda(), gt.cuda()
+    runs = []
+    for _ in range(3):
+        net.zero_grad(set_to_none=False)
+        pred = net(x=x, event=ev)
+        torch.sqrt((pred - gt) ** 2 + 1e-12).mean().backward()
+        torch.cuda.synchronize()
+        runs.append((pred.detach().clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    for pred, grads in runs[1:]:
+        assert torch.equal(pred, runs[0][0])
+        diff = [k for k in grads if not torch.equal(grads[k], runs[0][1][k])]
+        assert not diff, diff[:8]
+
+
 def _grad_check(net, P, grads_ref, rtol=2e-3):
     worst = []
     for k, p in net.named_parameters():

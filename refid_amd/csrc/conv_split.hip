@@ -224,8 +224,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
                     ra[sub][it][i & 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16 * (i & 1), 0));
                 } else {
                     const int it = i - 2 * C::A_ITEMS;
+                    // (the hardware range check covers the vector offset only: a sub-chunk past K -- Ctot % 16 == 8 with
+                    //  two sub-chunks per stage -- must not travel as a scalar offset, it would read past the class's weights)
+                    const bool wok = ch * KS + sub < nsub;
                     rb[sub][it] = __builtin_bit_cast(
-                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[it], (ch * KS + sub) * wChunk, 0));
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wok ? voW[it] : OOB, wok ? (ch * KS + sub) * wChunk : 0, 0));
                 }
             }
         }

@@ -360,7 +360,11 @@ class ConvOp:
         self.wslab = None
         self.w_calls = 0
         self.w_last = None
-        self.w_pend = []                      # Winograd weight-gradient calls waiting for their group (WGRAD_GROUP)
+        self.w_pend = []                      # weight-gradient calls waiting for their group
+        # time steps per weight-gradient launch: 1 = launch immediately (every op by default: an op called once per
+        # backward -- the image branch, every EvhinetEngine op -- must not wait for finish_wgrad); Engine sets
+        # min(WGRAD_GROUP, T) on the convs the T recurrent steps share (Engine._set_wgrad_groups)
+        self.w_group = 1
 
     def repack(self):
         k = self.k
@@ -468,15 +472,17 @@ class ConvOp:
                 ops.colsum(g, self.gb)
             return
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
+        if algo == 1 and b is not None and a.shape[3] % 32 != 0:
+            algo = 0          # the Winograd weight-gradient tile picks the source per 32-channel tile (base 24, 40, 48 ...)
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
-        if WGRAD_GROUP > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):
+        if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):
             # same source split as the waiting calls (the first recurrent step has no second source yet)?
             if self.w_pend and (self.w_pend[0][2] is None) != (b is None):
                 self._launch_group()
             self.w_pend.append((g, a, b))
             self.w_algo = algo
-            if len(self.w_pend) >= WGRAD_GROUP:
+            if len(self.w_pend) >= self.w_group:
                 self._launch_group()
             return
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
@@ -579,8 +585,10 @@ class Engine:
 
     def __init__(self, img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, device="cuda",
                  compute_dtype="fp32"):
-        if base % 8 != 0:
-            raise ValueError("base_num_channels must be a multiple of 8")
+        if base not in (8, 16, 32, 64):
+            # EGACA's LayerNorm / depthwise / squeeze-excite kernels take 2*base in {16, 32, 64, 128} channels; every
+            # options/*.yml of the reference uses 32
+            raise ValueError("base_num_channels must be 8, 16, 32 or 64 (the reference's configs use 32)")
         if compute_dtype not in ("fp32", "bf16", "bf16x3"):
             raise ValueError(f"compute_dtype must be 'fp32', 'bf16x3' or 'bf16', got {compute_dtype!r}")
         # "bf16x3": fp32 tensors, fp32 accumulation; the 3x3 forward / input-gradient convs multiply on the bf16 matrix
@@ -635,6 +643,16 @@ class Engine:
         self.param_version = 0
         self.ctx = None
         self._bind_fold_scratch()
+        # convs whose weights the T (or 2T) recurrent steps share: their weight gradients may wait for a group of steps
+        img_ops = {id(o) for e in self.img for o in e.values()} | {id(self.head_img), id(self.head_ev)}
+        self.recurrent_ops = [o for o in self.all_ops if id(o) not in img_ops]
+
+    def _set_wgrad_groups(self, T):
+        """Group size of the deferred weight-gradient launches: min(WGRAD_GROUP, T) on the recurrent convs (a group
+        never outlives a sweep), 1 elsewhere."""
+        n = max(1, min(WGRAD_GROUP, T))
+        for o in self.recurrent_ops:
+            o.w_group = n
 
     def _bind_fold_scratch(self):
         self.folded_ops = [o for o in self.all_ops if o.scale is not None]
@@ -978,6 +996,7 @@ class Engine:
         self.fold_scratch.zero_()             # folded-weight gradients of THIS backward only (see ConvOp.__init__)
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
+        self._set_wgrad_groups(T)
         dev = gout.device
         gout = gout.contiguous()
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]

@@ -247,14 +247,20 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
 
 
 _ws_cache = {}
+# Bumped whenever a scratch buffer a captured hipGraph may have baked in (split-K workspaces, persistent weight-gradient
+# slabs) is replaced by a larger one: train.py re-captures its graphs when the epoch moved (the old buffer is freed).
+ALLOC_EPOCH = 0
 
 
 def _workspace(nbytes, device, kind="wgrad"):
     """Grow-only scratch buffer per (device, stream, kind): the C ABI never allocates, the caller lends it
     scratch that is private to the launching stream (stream-ordered re-use)."""
     key = (device.index, torch.cuda.current_stream().cuda_stream, kind)
+    global ALLOC_EPOCH
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
+        if buf is not None:
+            ALLOC_EPOCH += 1
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
         _ws_cache[key] = buf
     return buf
@@ -306,6 +312,9 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     else:
         if slabs is None or (phase == 1 and slabs.numel() * 4 < nbytes):
             # phase 1 overwrites: a larger batch / crop than the first step's simply gets a larger buffer
+            if slabs is not None:
+                global ALLOC_EPOCH
+                ALLOC_EPOCH += 1
             slabs = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=g.device)
         elif slabs.numel() * 4 < nbytes:
             raise _lib.RefidHipError("wgrad: persistent slab buffer too small for this geometry (phase 2/3 must "

@@ -213,12 +213,15 @@ class TwoImageEventRecurrentRestorationModel:
         finally:
             self.gt = saved
         g["graphs"] = graphs
+        g["alloc_epoch"] = ops.ALLOC_EPOCH       # scratch buffers baked into the graphs are the current ones
         return g
 
     def _step_graph(self):
         g = getattr(self, "_graph", None)
         key = (tuple(self.lq.shape), tuple(self.voxel.shape), tuple(self.gt.shape))
-        if g is None or g["key"] != key:
+        if g is None or g["key"] != key or g["alloc_epoch"] != ops.ALLOC_EPOCH:
+            # (an eager call at a larger geometry since the capture replaced a split-K workspace / weight-gradient slab
+            #  buffer whose address the graphs hold: capture again)
             self._graph = None
             g = self._graph = self._graph_capture()
         else:
@@ -343,14 +346,48 @@ class TwoImageEventRecurrentRestorationModel:
         return save_path
 
     def resume_training(self, resume_state):
-        """base_model.py:308-323."""
+        """base_model.py:308-323.  Accepts this class's own `.state` files (flat AdamW arenas) AND the reference's
+        (`torch.optim.AdamW.state_dict()` / `scheduler.state_dict()`, base_model.py:297-303): the per-parameter
+        `exp_avg` / `exp_avg_sq` are laid into the arenas in parameter order (= state-dict order of the network)."""
         assert len(resume_state["optimizers"]) == 1, "Wrong lengths of optimizers"
         assert len(resume_state["schedulers"]) == 1, "Wrong lengths of schedulers"
         o, sc = resume_state["optimizers"][0], resume_state["schedulers"][0]
-        self.step_count = int(o["step"])
-        self.exp_avg.copy_(o["exp_avg"])
-        self.exp_avg_sq.copy_(o["exp_avg_sq"])
-        self.sched_epoch, self.cur_lr = int(sc["last_epoch"]), float(sc["lr"])
+        arena = self.net_g.engine.arena
+        if o.get("type") == "refid_amd.fused_adamw":
+            if o["exp_avg"].numel() != self.exp_avg.numel() or o["exp_avg_sq"].numel() != self.exp_avg_sq.numel():
+                raise ValueError(f"resume_training: the saved AdamW arenas hold {o['exp_avg'].numel()} values, this network's "
+                                 f"{self.exp_avg.numel()} (different img_chn / base_num_channels?)")
+            self.step_count = int(o["step"])
+            self.exp_avg.copy_(o["exp_avg"])
+            self.exp_avg_sq.copy_(o["exp_avg_sq"])
+        elif "state" in o and "param_groups" in o:
+            keys = list(arena.offsets)
+            st = o["state"]
+            if len(st) != len(keys):
+                raise ValueError(f"resume_training: torch optimizer state for {len(st)} parameters, this network has "
+                                 f"{len(keys)}")
+            steps = set()
+            for i, k in enumerate(keys):
+                e = st[i]
+                off, n = arena.offsets[k]
+                if e["exp_avg"].numel() != n:
+                    raise ValueError(f"resume_training: optimizer state {i} has {e['exp_avg'].numel()} values, parameter "
+                                     f"{k} has {n}")
+                self.exp_avg[off:off + n].copy_(e["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
+                steps.add(int(e["step"]))
+            if len(steps) != 1:
+                raise ValueError(f"resume_training: per-parameter step counts differ ({sorted(steps)[:4]} ...)")
+            self.step_count = steps.pop()
+        else:
+            raise ValueError("resume_training: unknown optimizer entry (neither refid_amd.fused_adamw arenas nor a "
+                             "torch.optim.AdamW state_dict)")
+        if "lr" in sc:
+            self.sched_epoch, self.cur_lr = int(sc["last_epoch"]), float(sc["lr"])
+        elif "_last_lr" in sc:                                   # torch scheduler.state_dict()
+            self.sched_epoch, self.cur_lr = int(sc["last_epoch"]), float(sc["_last_lr"][0])
+        else:
+            raise ValueError("resume_training: unknown scheduler entry (no 'lr' / '_last_lr')")
 
     def load_network(self, net, load_path, strict=True, param_key="params"):
         load_net = torch.load(load_path, map_location="cpu")

@@ -456,6 +456,31 @@ def test_winograd_wgrad(cfg):
     np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
 
 
+@pytest.mark.parametrize("ca,cb,group", [(48, 48, 1), (48, 48, 3), (40, 24, 1), (64, 64, 3)])
+def test_convop_two_source_weight_gradient_any_split(ca, cb, group):
+    """engine.ConvOp: a two-source 3x3 conv whose first source is not a multiple of 32 channels (the Winograd
+    weight-gradient tile selects the source per 32-channel tile) falls back to the direct tile; grouped time steps and
+    immediate launches give the same gradient as torch."""
+    from collections import OrderedDict
+    from refid_amd.engine import ConvOp, ParamArena
+    co, ci, N, H, W, T = 64, ca + cb, 1, 16, 32, 3
+    A = ParamArena(OrderedDict([("c.weight", (co, ci, 3, 3)), ("c.bias", (co,))]), torch.device("cuda"))
+    w = rnd(co, ci, 3, 3, seed=1, scale=0.1).requires_grad_(True)
+    bias = rnd(co, seed=2).requires_grad_(True)
+    A.p("c.weight").copy_(w.detach().float()); A.p("c.bias").copy_(bias.detach().float())
+    op = ConvOp(A, "c")
+    op.w_group = group
+    for t in range(T):
+        x = rnd(N, ci, H, W, seed=10 + t)
+        g = rnd(N, co, H, W, seed=20 + t)
+        F.conv2d(x, w, bias, 1, 1).backward(g)
+        op._wgrad(nhwc(g), nhwc(x[:, :ca]), nhwc(x[:, ca:]))
+    op._finish_wgrad()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(A.g("c.weight").cpu().numpy(), w.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(A.g("c.bias").cpu().numpy(), bias.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("algo,cfg", [(0, (1, 16, 32, 64, 64, 64, 3)), (1, (1, 16, 32, 64, 64, 64, 3)),
                                       (0, (2, 8, 16, 128, 0, 128, 1)), (0, (1, 16, 32, 64, 0, 64, 4))])
 def test_wgrad_slab_phases(algo, cfg):
@@ -1073,7 +1098,8 @@ def test_split_tile_conv_down_forward(cfg, terms):
 
 
 @pytest.mark.parametrize("terms", [6, 3, 1])
-@pytest.mark.parametrize("cfg", [(2, 16, 32, 64), (1, 24, 40, 128), (1, 8, 8, 256), (1, 36, 68, 32), (2, 64, 64, 64)])
+@pytest.mark.parametrize("cfg", [(2, 16, 32, 64), (1, 24, 40, 128), (1, 8, 8, 256), (1, 36, 68, 32), (2, 64, 64, 64),
+                                 (1, 16, 32, 24), (1, 8, 16, 40)])       # 24 / 40 channels: K % 16 == 8, half-empty last stage
 def test_split_tile_conv_down_dgrad(cfg, terms):
     """Input gradient of conv_down: four output-parity classes of 2x2-tap convs over the output gradient (+ the fused
     residual / derivative-mask epilogue BPTT uses)."""

@@ -90,8 +90,9 @@ def test_eval_step_chunks_and_checkpoint_roundtrip(tmp_path):
 
 def test_save_and_resume_training_state(tmp_path):
     """save(epoch, iter) (twoImage_event_recurrent_model.py:552-554) + resume_training (base_model.py:308-323): a run
-    resumed from the saved network + state continues on the same trajectory (the LayerNorm / depthwise parameter
-    gradients are accumulated with atomics, so two runs agree to rounding, not bit for bit)."""
+    resumed from the saved network + state continues on the same trajectory; a `.state` in the REFERENCE's format
+    (torch.optim.AdamW.state_dict() + scheduler.state_dict(), base_model.py:297-303) resumes to the same bits as this
+    class's own flat-arena format."""
     from refid_amd.train import TwoImageEventRecurrentRestorationModel
     opt = _opt(6, 8)
     opt["path"].update(models=str(tmp_path), training_states=str(tmp_path))
@@ -120,6 +121,31 @@ def test_save_and_resume_training_state(tmp_path):
     for (k, va), vb in zip(a.net_g.state_dict().items(), b.net_g.state_dict().values()):
         disp = (va.double().cpu() - P[k].double()).abs().max().item()
         assert (va.double() - vb.double()).abs().max().item() <= 0.02 * disp + 1e-9, k
+    # the same state written the way the reference writes it: per-parameter torch AdamW state in parameter order
+    own = torch.load(os.path.join(tmp_path, "2.state"))
+    arena = a.net_g.engine.arena
+    st = {}
+    for i, (k, (off, n)) in enumerate(arena.offsets.items()):
+        st[i] = {"step": torch.tensor(float(own["optimizers"][0]["step"])),
+                 "exp_avg": own["optimizers"][0]["exp_avg"][off:off + n].view(arena.shapes[k]).clone(),
+                 "exp_avg_sq": own["optimizers"][0]["exp_avg_sq"][off:off + n].view(arena.shapes[k]).clone()}
+    ref_state = {"epoch": 0, "iter": 2,
+                 "optimizers": [{"state": st, "param_groups": [{"lr": own["schedulers"][0]["lr"], "params": list(range(len(st)))}]}],
+                 "schedulers": [{"last_epoch": own["schedulers"][0]["last_epoch"], "_last_lr": [own["schedulers"][0]["lr"]]}]}
+    d = TwoImageEventRecurrentRestorationModel(o2)
+    d.resume_training(ref_state)
+    d.feed_data({"lq": x, "voxel": ev, "gt": gt})
+    for it in (3, 4):
+        d.update_learning_rate(it)
+        d.optimize_parameters(it)
+    assert d.step_count == 4
+    for (k, vb), vd in zip(b.net_g.state_dict().items(), d.net_g.state_dict().values()):
+        assert torch.equal(vb, vd), k                       # no atomics on the path: the same bits
+    bad = {"optimizers": [{"state": {0: st[0]}, "param_groups": []}], "schedulers": ref_state["schedulers"]}
+    with pytest.raises(ValueError, match="183|parameters"):
+        d.resume_training(bad)
+    with pytest.raises(ValueError, match="unknown optimizer"):
+        d.resume_training({"optimizers": [{}], "schedulers": ref_state["schedulers"]})
     # a resume that forgets the optimizer state is NOT on that trajectory (the check above has teeth)
     c = TwoImageEventRecurrentRestorationModel(o2)
     c.feed_data({"lq": x, "voxel": ev, "gt": gt})

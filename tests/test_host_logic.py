@@ -258,3 +258,66 @@ def test_split_tile_grid_policy_follows_the_split_k_policy():
         assert engine._fills_gpu(1, 16, 32, 64, 1) == engine._fills_gpu(5, 16, 32, 64, 1)
     finally:
         ops.WINO_SPLIT = old
+
+
+REF_OPTIONS = "/root/reference/options"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_OPTIONS), reason="needs the reference checkout (build container only)")
+def test_every_shipped_yaml_of_the_reference_parses_and_builds(monkeypatch):
+    """The config contract with the REAL files: all options/**/*.yml of the reference go through
+    refid_amd.options.parse (same dict as the reference's own parser, utils/options.py:31-95, up to the root path), the
+    dataset blocks give the (T, img_chn) the network block expects, define_network builds the 183-key
+    module, and the train / test model wrapper accepts the train / val blocks (engine stubbed: no GPU here)."""
+    import glob
+    import importlib.util
+    import types
+    from refid_amd import options, train
+    from refid_amd.archs import define_network
+    from refid_amd.engine import ParamArena, param_shapes
+    spec = importlib.util.spec_from_file_location("ref_options", "/root/reference/basicsr/utils/options.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    files = sorted(glob.glob(os.path.join(REF_OPTIONS, "**", "*.yml"), recursive=True))
+    assert len(files) == 16
+
+    def stubbed(net_opt):
+        net = define_network(net_opt)                      # CPU module: parameters exist, the HIP engine does not
+        arena = ParamArena(param_shapes(net.img_chn, net.ev_chn, net.out_chn, net.base_num_channels,
+                                        net.num_residual_blocks), torch.device("cpu"))
+        net._engine = types.SimpleNamespace(arena=arena, mark_params_changed=lambda: None)
+        net.to = lambda *a, **k: net                       # (.to() would re-bind the engine to the device and drop the stub)
+        return net
+
+    monkeypatch.setattr(train, "define_network", stubbed)
+    expect_T = {"1skip": 23, "1attenfusion.yml": 23, "3skip": 25, "7skip": 7, "15skip": 15}
+    for f in files:
+        is_train = os.sep + "train" + os.sep in f
+        opt = options.parse(f, is_train=is_train)
+        want = ref.parse(f, is_train=is_train)
+        got_path, want_path = opt.pop("path"), want.pop("path")
+        assert opt == want, f
+        assert sorted(got_path) == sorted(want_path), f
+        opt["path"] = got_path
+        ng = opt["network_g"]
+        assert ng["type"] == "FinalBidirectionAttenfusion" and ng["ev_chn"] == 2 and ng["num_encoders"] == 3
+        T = next(v for k, v in expect_T.items() if k in os.path.basename(f))
+        for name, ds in opt["datasets"].items():
+            assert options.shapes_from_dataset_opt(ds) == (T, ng["img_chn"]), (f, name)
+        net = define_network(dict(ng))
+        sd = net.state_dict()
+        assert len(sd) == 183 and sd["head_img.conv2d.weight"].shape == (32, ng["img_chn"], 5, 5), f
+        opt["num_gpu"] = 0                                 # CPU tensors for the optimizer arenas of the stub
+        opt["path"]["pretrain_network_g"] = None           # (the shipped files point at checkpoints that are not here)
+        model = train.TwoImageEventRecurrentRestorationModel(opt)
+        if is_train:
+            tr = opt["train"]
+            assert model.sched_type == tr["scheduler"]["type"] and model.base_lr == float(tr["optim_g"]["lr"])
+            assert model.betas == tuple(tr["optim_g"]["betas"]) and model.weight_decay == float(tr["optim_g"]["weight_decay"])
+            assert model.exp_avg.numel() == model.net_g.engine.arena.total
+            for it in (1, 2, 3):
+                model.update_learning_rate(it, warmup_iter=tr.get("warmup_iter", -1))
+            lr = model.get_current_learning_rate()[0]
+            assert 0 < lr <= model.base_lr
+        else:
+            assert not hasattr(model, "exp_avg") and opt["val"].get("max_minibatch", 1) >= 1

@@ -251,6 +251,12 @@ def main(argv=None):
                              "one GPU per rank is required")
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
+    pinned = []
+    if world > 1 and os.environ.get("REFID_PIN_CORES", "1") != "0":
+        # every rank keeps its enqueue thread (and OMP_NUM_THREADS helpers) on the cores next to its GPU
+        from refid_amd.dist import pin_to_local_cores
+        lw = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        pinned = pin_to_local_cores(local_rank, lw, numa_nodes=[-1] * lw if args.dry_run else None)
     use_dist = world > 1 or os.environ.get("REFID_FORCE_GRADSYNC") == "1"    # 1-rank RCCL dry run of the N>1 path
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -423,6 +429,8 @@ def main(argv=None):
                                    (" (BASELINE configs[1])" if args.dtype == "fp32" and args.T == 23 and gbatch == 8 * (world if args.scaling == "weak" else 1) else ""),
                        "global_batch": gbatch, "parallelism": f"dp{world}", "loss": round(loss, 6)},
         }
+        if pinned:
+            out["rank0_cpu_affinity"] = f"{len(pinned)} cores ({pinned[0]}-{pinned[-1]})"
         if args.dry_run:
             out["dry_run"] = True
             out["backend"] = args.backend

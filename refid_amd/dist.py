@@ -32,6 +32,54 @@ def init_dist(launcher="pytorch", backend="nccl", **kwargs):
     dist.init_process_group(backend=backend, **kwargs)
 
 
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def gpu_numa_node(local_rank):
+    """NUMA node of the GPU this rank drives (sysfs: the PCI function's numa_node), or -1 when unknown."""
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            return int(f.read().strip())
+    except Exception:  # noqa: BLE001  (no GPU, no sysfs, older torch: the caller falls back to an even split)
+        return -1
+
+
+def pin_to_local_cores(local_rank, local_world, numa_nodes=None):
+    """One process per GPU enqueues ~5000 kernel launches per step from Python; with 8 ranks on one host the enqueue
+    threads must not wander over the sockets.  Pins this process to its share of the cores of its GPU's NUMA node
+    (the ranks whose GPUs sit on the same node split that node's cores evenly; unknown topology: an even split of the
+    cores the process may use).  Returns the sorted core list it pinned to ([] when the platform cannot pin)."""
+    if not hasattr(os, "sched_setaffinity") or local_world < 1:
+        return []
+    allowed = sorted(os.sched_getaffinity(0))
+    if numa_nodes is None:
+        numa_nodes = [gpu_numa_node(r) for r in range(local_world)]
+    node = numa_nodes[local_rank] if local_rank < len(numa_nodes) else -1
+    cores, peers = allowed, list(range(local_world))
+    if node >= 0:
+        try:
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                on_node = sorted(_cpulist(f.read()) & set(allowed))
+            if on_node:
+                cores, peers = on_node, [r for r in range(local_world) if numa_nodes[r] == node]
+        except OSError:
+            pass
+    idx, n = peers.index(local_rank), len(peers)
+    per = max(1, len(cores) // n)
+    mine = cores[idx * per:(idx + 1) * per] if idx * per < len(cores) else cores[-per:]
+    os.sched_setaffinity(0, mine)
+    return mine
+
+
 def get_dist_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

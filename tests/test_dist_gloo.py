@@ -49,3 +49,22 @@ def test_grad_sync_two_ranks_gloo():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+def test_rank_core_pinning_splits_the_allowed_cores():
+    """bench.py pins each rank to its share of the cores next to its GPU (here: unknown topology -> even split of the
+    cores this process may use); the shares of all ranks are disjoint and restore cleanly."""
+    import os
+    from refid_amd.dist import _cpulist, pin_to_local_cores
+    assert _cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    before = os.sched_getaffinity(0)
+    try:
+        shares = []
+        for r in range(4):
+            os.sched_setaffinity(0, before)
+            shares.append(pin_to_local_cores(r, 4, numa_nodes=[-1] * 4))
+            assert os.sched_getaffinity(0) == set(shares[-1]) and shares[-1]
+        if len(before) >= 4:
+            assert sum(len(s) for s in shares) == len(set().union(*map(set, shares)))      # disjoint
+    finally:
+        os.sched_setaffinity(0, before)

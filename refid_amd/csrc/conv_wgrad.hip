@@ -537,42 +537,52 @@ struct RedArgs {
     int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
 };
 
-// Slab reduction.  grid = (float4 elements / 256, split groups): every thread sums ONE float4
-// (4 consecutive input channels) over its group's slabs with 8 independent 16-byte loads in
-// flight, then adds into the parameter-layout gradient with fp32 atomics (groups <= 8, so a
-// gradient element sees at most 8 atomics per call).  Bandwidth-bound instead of latency-bound.
+// Slab reduction, deterministic.  `perGroup` = LPE (a power of two <= 8) adjacent lanes share ONE float4 element (4
+// consecutive input channels): lane `sub` adds slabs sub, sub + LPE, ... in order, a fixed xor-shuffle tree combines the
+// LPE partial sums and lane 0 adds the total into the parameter-layout gradient (which it owns: no atomics).  LPE > 1
+// only for small weight tensors, where one thread per element would leave the chip idle.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
     const int Ci4 = a.CiP / 4;
     const long long total4 = (long long)a.ntaps * a.CoP * Ci4;
     const long long slabStride4 = total4;
-    const int s0 = blockIdx.y * a.perGroup;
-    const int s1 = min(a.nsplit, s0 + a.perGroup);
-    const long long e = blockIdx.x * 256ll + threadIdx.x;
-    if (e < total4) {
-        long long r = e;
+    const int lpe = a.perGroup;
+    const long long gid = blockIdx.x * 256ll + threadIdx.x;
+    const long long e = gid / lpe;
+    const int sub = (int)(gid % lpe);
+    {
+        const bool in = e < total4;
+        long long r = in ? e : 0;
         const int ci = (int)(r % Ci4) * 4; r /= Ci4;
         const int co = (int)(r % a.CoP);
         const int tap = (int)(r / a.CoP);
-        if (co < a.Co && ci < a.Ci) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(a.slabs) + e;
-            f32x4 acc[8];
+        const bool live = in && co < a.Co && ci < a.Ci;
+        const f32x4* p = reinterpret_cast<const f32x4*>(a.slabs) + (in ? e : 0);
+        f32x4 acc[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            int k = s0;
-            for (; k + 8 <= s1; k += 8) {
+        for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            int k = sub;
+            for (; k + 3 * lpe < a.nsplit; k += 4 * lpe) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u] += p[(long long)(k + u) * slabStride4];
+                for (int u = 0; u < 4; ++u) acc[u] += p[(long long)(k + u * lpe) * slabStride4];
             }
-            for (; k < s1; ++k) acc[0] += p[(long long)k * slabStride4];
-            const f32x4 sum = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+            for (; k < a.nsplit; k += lpe) acc[0] += p[(long long)k * slabStride4];
+        }
+        f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        for (int o = 1; o < lpe; o <<= 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[j] += __shfl_xor(sum[j], o, 64);
+        }
+        if (live && sub == 0) {
             float* d = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * a.ntaps + tap;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (ci + j >= a.Ci) break;
-                d[(long long)j * a.ntaps] += sum[j];            // one group: this thread owns the element (deterministic)
+                d[(long long)j * a.ntaps] += sum[j];
             }
         }
     }
+    const int s0 = 0, s1 = a.nsplit;
     if (a.db != nullptr && blockIdx.x == 0) {
         for (int co = threadIdx.x; co < a.Co; co += 256) {
             float s = 0.f;
@@ -781,11 +791,11 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total4 = (long long)p.ntaps * g.CoP * (g.CiP / 4);
     const int nb = (int)((total4 + 255) / 256);
-    // ONE group: every element of dw is owned by one thread that adds the slabs in slab order -- deterministic (splitting
-    // the slabs over grid.y needed floating-point atomics into dw)
-    int groups = 1;
-    r.perGroup = g.nsplit;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb, groups), dim3(256), 0, st, r);
+    // lanes per element: only where one thread per float4 would leave the chip idle (small weight tensors)
+    int lpe = 1;
+    while (lpe < 8 && (long long)lpe * 2 * total4 <= 65536 && lpe * 2 <= g.nsplit) lpe *= 2;
+    r.perGroup = lpe;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total4 * lpe + 255) / 256)), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }

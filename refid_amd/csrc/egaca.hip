@@ -416,15 +416,22 @@ __global__ __launch_bounds__(256) void gs_reduce_kernel(const float* __restrict_
             ((sred[0][threadIdx.x] + sred[1][threadIdx.x]) + sred[2][threadIdx.x]) + sred[3][threadIdx.x];
 }
 
-// gs[n][c] = sum_blocks parts[n][block][c], blocks in order (one thread per (n, c))
+// gs[n][c] = sum_blocks parts[n][block][c]: one wave per 64 / C samples' worth of columns -- lane (r, c) adds blocks r, r + R,
+// ... in order, a fixed xor-shuffle tree over r combines them (R = 64 / C rows of lanes; C <= 64) -- deterministic
 __global__ __launch_bounds__(256) void gs_sum_kernel(const float* __restrict__ parts, int nblk, int C, int total,
                                                     float* __restrict__ gs) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int n = i / C, c = i % C;
+    // 256 threads = (256 / C) block-rows x C columns of ONE sample (C in {16, 32, 64, 128}: C <= 256)
+    const int n = blockIdx.x, c = threadIdx.x % C, r = threadIdx.x / C, R = 256 / C;
+    __shared__ float sh[256];
     float a = 0.f;
-    for (int b = 0; b < nblk; ++b) a += parts[((long long)n * nblk + b) * C + c];
-    gs[i] = a;
+    for (int b = r; b < nblk; b += R) a += parts[((long long)n * nblk + b) * C + c];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = sh[threadIdx.x];
+        for (int k = 1; k < R; ++k) t += sh[k * C + threadIdx.x];
+        gs[n * C + threadIdx.x] = t;
+    }
 }
 
 // gdwe = (gxs_e*s + gm/HW) * gelu'(dwe) ;  gxi_acc (+)= gxs_i*s
@@ -646,7 +653,7 @@ extern "C" int refid_egaca_gs_reduce(const float* gxs, const float* xi, const fl
     const int nb = refid_egaca_gs_reduce_parts(hw, c);
     LPP_DISPATCH(c, hipLaunchKernelGGL(gs_reduce_kernel<LPP>, dim3(nb, n), dim3(256), 0, st, gxs, xi, xe, parts, hw));
     REFID_LAUNCH_CHECK("egaca_gs_reduce");
-    hipLaunchKernelGGL(gs_sum_kernel, dim3(cdiv(n * c, 256)), dim3(256), 0, st, parts, nb, c, n * c, gs);
+    hipLaunchKernelGGL(gs_sum_kernel, dim3(n), dim3(256), 0, st, parts, nb, c, n * c, gs);
     REFID_LAUNCH_CHECK("egaca_gs_reduce/sum");
     return 0;
 }

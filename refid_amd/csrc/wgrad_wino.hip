@@ -243,22 +243,32 @@ struct WrArgs {
     int nsplit, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
 };
 
-// slab reduction + inverse weight transform: dg = G^T dU G, accumulated into OIHW (9 contiguous floats)
+// slab reduction + inverse weight transform: dg = G^T dU G, accumulated into OIHW (9 contiguous floats).  Deterministic:
+// `perGroup` = LPE (power of two <= 16) adjacent lanes share one (co, ci) element, lane `sub` adds slabs sub, sub + LPE, ...
+// in order, a fixed xor-shuffle tree combines them, lane 0 owns the gradient element (no atomics).
 __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WrArgs a) {
     const long long plane = (long long)a.CoP * a.CiP;
     const long long slabStride = 16 * plane;
-    const int s0 = blockIdx.y * a.perGroup;
-    const int s1 = min(a.nsplit, s0 + a.perGroup);
-    const long long e = blockIdx.x * 256ll + threadIdx.x;          // (co, ci), ci fastest
-    if (e < (long long)a.Co * a.Ci) {
-        const int ci = (int)(e % a.Ci), co = (int)(e / a.Ci);
+    const int lpe = a.perGroup;
+    const long long gid = blockIdx.x * 256ll + threadIdx.x;
+    const long long e = gid / lpe;                                 // (co, ci), ci fastest
+    const int sub = (int)(gid % lpe);
+    {
+        const bool live = e < (long long)a.Co * a.Ci;
+        const int ci = live ? (int)(e % a.Ci) : 0, co = live ? (int)(e / a.Ci) : 0;
         const float* p = a.slabs + (long long)co * a.CiP + ci;
         float u[16];
 #pragma unroll
         for (int x = 0; x < 16; ++x) u[x] = 0.f;
-        for (int k = s0; k < s1; ++k) {
+        if (live) {
+            for (int k = sub; k < a.nsplit; k += lpe) {
 #pragma unroll
-            for (int x = 0; x < 16; ++x) u[x] += p[k * slabStride + x * plane];
+                for (int x = 0; x < 16; ++x) u[x] += p[k * slabStride + x * plane];
+            }
+        }
+        for (int o = 1; o < lpe; o <<= 1) {
+#pragma unroll
+            for (int x = 0; x < 16; ++x) u[x] += __shfl_xor(u[x], o, 64);
         }
         // t[a][j] = sum_i G[i][a] u[i][j] ;  dg[a][b] = sum_j t[a][j] G[j][b]
         float dg[9];
@@ -275,12 +285,13 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WrArgs a) 
             dg[aa * 3 + 1] = d;
             dg[aa * 3 + 2] = m + t[3];
         }
-        float* dst = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * 9;
+        if (live && sub == 0) {
+            float* dst = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            dst[k] += dg[k];                                // one group: this thread owns the element (deterministic)
+            for (int k = 0; k < 9; ++k) dst[k] += dg[k];
         }
     }
+    const int s0 = 0, s1 = a.nsplit;
     if (a.db != nullptr && blockIdx.x == 0) {
         for (int co = threadIdx.x; co < a.Co; co += 256) {
             float s = 0.f;
@@ -358,9 +369,10 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
     r.Ci = (d->phase == 0 && a.Ctot < d->i_total - d->i_base) ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP; r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total = (long long)r.Co * r.Ci;
-    int groups = 1;                        // one thread owns an element and adds the slabs in order: deterministic
-    r.perGroup = g.nsplit;
-    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((int)((total + 255) / 256), groups), dim3(256), 0, st, r);
+    int lpe = 1;                           // lanes per element (small weight tensors only)
+    while (lpe < 16 && (long long)lpe * 2 * total <= 65536 && lpe * 2 <= g.nsplit) lpe *= 2;
+    r.perGroup = lpe;
+    hipLaunchKernelGGL(wgrad_wino_reduce_kernel, dim3((int)((total * lpe + 255) / 256)), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_wino_reduce");
     return 0;
 }

@@ -134,7 +134,11 @@ typedef struct refid_conv_desc {
                                                    per-sample geometry (a sample's bits do not depend on the batch
                                                    size); 2 = decided by the total grid size (best at 1-2 samples per
                                                    GPU).  Used by algo 1 / 5 and by algo 0's 4x4/s2 tiles (mode 0 and 2).  */
-    int wino_tile;                              /* algo 1 only: 0 / 1 = the 2-waves-per-SIMD tile (4x32 px x 64 ch
+    int wino_tile;                              /* experiments, honoured only by libraries built with
+                                                   REFID_EXPERIMENTAL_TILES=1 (same results bit for bit, measured slower):
+                                                   algo 5: 3 = the wide tile (8x32 px x 64 ch, 8 waves, weight fragments
+                                                   shared through an LDS ring); 
+                                                   algo 1: 0 / 1 = the 2-waves-per-SIMD tile (4x32 px x 64 ch
                                                    workgroups; the default); 2 = the persistent one-wave-per-SIMD tile
                                                    (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
                                                    geometry allows -- ONLY in libraries built with

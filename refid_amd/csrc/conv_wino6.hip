@@ -30,6 +30,11 @@
 //   * the raw halo of chunk c+2 is requested at the top of chunk c (global -> VGPR -> LDS, double buffered).
 #include "common.h"
 #include "conv_args.h"
+#include <cstdlib>
+
+#ifndef REFID_WINO6_ABLATE
+#define REFID_WINO6_ABLATE 0             // tools/probes/wino6_ablate.py only (see the loaders below)
+#endif
 
 namespace {
 
@@ -120,6 +125,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     for (int nt = 0; nt < 2; ++nt) {
         const int urow = a.coBase + n0 + nt * 32 + li;
         voU[nt] = (urow < a.CoutPad) ? (urow * KC + kh * 8) * 2 + ti * 4 * uXi : OOB;
+        if (REFID_WINO6_ABLATE == 12) voU[nt] = ti * 4 * uXi;
     }
     // split-K (small grids only): this workgroup reduces chunks [kc0, kc1) and writes a raw partial output
     const int kper = (a.nchunks + a.ksplit - 1) / a.ksplit;
@@ -132,10 +138,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     // wrong) to price the pieces: 1 = U fragments always from chunk 0 (cache resident), 2 = no three-plane split,
     // 3 = no K loop, 4 = no residual / mask loads and no stores, 5 = raw halo always from chunk 0, 6 = no U loads in the K loop,
     // 7 = no raw loads / LDS stores in the K loop, 8 = 6 + 7, 9 / 11 = the workgroup in the odd wave slot of its SIMD starts
-    // 4 / 8 us late (anti-phased pair per CU), 10 = 3 + 4.  Never in the product.
-#ifndef REFID_WINO6_ABLATE
-#define REFID_WINO6_ABLATE 0
-#endif
+    // 4 / 8 us late (anti-phased pair per CU), 10 = 3 + 4, 12 = every lane of a U load reads the same 16 bytes (same
+    // instruction count, no bandwidth), 13 = half the U loads (column tile 1 reuses tile 0's fragments).  Never in the product.
     auto load_raw = [&](int ch, f32x4 (&dst)[R_ITEMS]) {
         const int c0 = (REFID_WINO6_ABLATE == 5 ? 0 : ch) * KC;   // chunk-uniform source: Ca % 16 == 0 for two sources
         const bool fromA = c0 < a.Ca;
@@ -164,9 +168,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
+            for (int nt = 0; nt < 2; ++nt) {
+                if (REFID_WINO6_ABLATE == 13 && nt == 1) { dst[p][1] = dst[p][0]; continue; }
                 dst[p][nt] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, in ? voU[nt] : OOB, in ? so + p * uPlane : 0, 0));
+            }
     };
 
     f32x16 acc[4][2];
@@ -381,11 +387,17 @@ size_t refid_wino6_workspace_bytes(const ConvKArgs& ka, int split_mode) {
     return (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float);
 }
 
-int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, hipStream_t st) {
+int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
     ConvKArgs a = ka;
     REFID_CHECK(refid_wino6_eligible(a),
                 "conv2d: the Winograd six-product tile needs more than 32 output channels, channel counts that are multiples "
                 "of 4 (two sources: c_a a multiple of 16) and tensors below 2 GiB");
+    // Wide tile (experimental/conv_wino6w.hip: 8x32 pixels, 8 waves, weight fragments shared through an LDS ring, same
+    // bits): measured 0-10 % slower, only in libraries built with REFID_EXPERIMENTAL_TILES=1 and only on request
+    // (refid_conv_desc.wino_tile = 3)
+#ifdef REFID_EXPERIMENTAL_TILES
+    if (tile_hint == 3) return refid_launch_wino6w(a, 1, st);
+#endif
     const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0);
     dim3 grid = pl.grid;
     static std::atomic<unsigned long long> done{0};

@@ -16,6 +16,12 @@ def _ops():
     return ops
 
 
+def _need_experimental():
+    from refid_amd._lib import lib
+    if not lib().refid_experimental_tiles():
+        pytest.skip("product library: built without REFID_EXPERIMENTAL_TILES=1")
+
+
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().float().cuda()
 
@@ -330,18 +336,63 @@ def test_winograd_fused_epilogues():
     (1, 5, 3, 64, 0, 64), (1, 7, 33, 32, 0, 96), (1, 9, 17, 36, 0, 64), (1, 8, 32, 16, 16, 64), (1, 6, 10, 8, 0, 40),
     (3, 4, 64, 48, 0, 128), (1, 8, 8, 256, 256, 256),
 ])
-def test_wino6_forward_geometries(cfg):
+@pytest.mark.parametrize("tile", [1, 3])
+def test_wino6_forward_geometries(cfg, tile):
     """Ragged tiles, a partial last 16-channel chunk (36, 8, 48 channels), a partial channel tile (96, 40), two sources,
-    and a small grid that takes the split-K form (512 -> 256 at 8x8)."""
-    run_wino(*cfg, algo=5)
+    and a small grid that takes the split-K form (512 -> 256 at 8x8); on the 4-wave tile (1) and the wide 8-wave tile with
+    the LDS-shared weight ring (3)."""
+    ops = _ops()
+    if tile == 3:
+        _need_experimental()
+    old, ops.WINO_TILE = ops.WINO_TILE, tile
+    try:
+        run_wino(*cfg, algo=5)
+    finally:
+        ops.WINO_TILE = old
 
 
-def test_wino6_fused_epilogues():
-    run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04, algo=5)
-    run_wino(1, 16, 32, 64, 0, 64, res=True, algo=5)
-    run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0, algo=5)
-    run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1, algo=5)
-    run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True, algo=5)
+def test_wino6_wide_tile_is_bit_identical_to_the_four_wave_tile():
+    """Same chunk order, same products: the wide tile (LDS-DMA weight ring, 8x32 pixels) returns the 4-wave tile's bits, so
+    an experiment that is switched on changes no result.  Two sources, residual + mask epilogue, ragged size."""
+    ops = _ops()
+    _need_experimental()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, H, W, Ca, Cb, Co = 2, 44, 70, 64, 64, 128
+    xa = torch.randn(N, H, W, Ca, device="cuda", generator=g)
+    xb = torch.randn(N, H, W, Cb, device="cuda", generator=g)
+    w = torch.randn(Co, Ca + Cb, 3, 3, device="cuda", generator=g) * 0.05
+    r = torch.randn(N, H, W, Co, device="cuda", generator=g)
+    m = torch.randn(N, H, W, Co, device="cuda", generator=g)
+    b = torch.randn(Co, device="cuda", generator=g)
+    wp = ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, Co, Ca + Cb)
+    outs = []
+    for tile in (1, 3):
+        old, ops.WINO_TILE = ops.WINO_TILE, tile
+        olds, ops.WINO_SPLIT = ops.WINO_SPLIT, 0           # (split-K changes the summation order of the small 4-wave grid)
+        try:
+            out = torch.empty(N, H, W, Co, device="cuda")
+            ops.conv2d(xa, wp, out, kh=3, kw=3, pad=1, cout=Co, cout_pad=128, in_b=xb, bias=b, res=r, mask=m, slope_pre=0.1,
+                       slope_mask=0.2, algo=5)
+            outs.append(out)
+        finally:
+            ops.WINO_TILE, ops.WINO_SPLIT = old, olds
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("tile", [1, 3])
+def test_wino6_fused_epilogues(tile):
+    ops = _ops()
+    if tile == 3:
+        _need_experimental()
+    old, ops.WINO_TILE = ops.WINO_TILE, tile
+    try:
+        run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04, algo=5)
+        run_wino(1, 16, 32, 64, 0, 64, res=True, algo=5)
+        run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0, algo=5)
+        run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1, algo=5)
+        run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True, algo=5)
+    finally:
+        ops.WINO_TILE = old
 
 
 @pytest.mark.parametrize("cfg", [(1, 16, 32, 64, 64), (1, 9, 24, 128, 64), (1, 8, 16, 256, 128), (1, 8, 8, 96, 40)])
@@ -691,12 +742,6 @@ def test_winograd_splitk_two_streams_have_private_workspaces():
 # ---- persistent one-wave-per-SIMD Winograd tile (csrc/experimental/conv_wino2.hip; refid_conv_desc.wino_tile = 2) ----
 # An experiment that lost (10-30 % slower): only in libraries built with REFID_EXPERIMENTAL_TILES=1; these tests skip on
 # the product library.
-def _need_experimental():
-    from refid_amd._lib import lib
-    if not lib().refid_experimental_tiles():
-        pytest.skip("product library: built without REFID_EXPERIMENTAL_TILES=1")
-
-
 @pytest.fixture
 def persistent_tile():
     ops = _ops()

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from refid_amd import ops
+from refid_amd._lib import lib
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_kernels import timeit, B
 
@@ -28,7 +29,12 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
     o1 = torch.empty(B, H, H, Co, device="cuda")
     o6 = torch.empty(B, H, H, Co, device="cuda")
     t1 = timeit(lambda: ops.conv2d(a, w1, o1, algo=1, **kw))
+    ops.WINO_TILE = 1
+    t6n = timeit(lambda: ops.conv2d(a, w6, o6, algo=5, **kw))
+    o6n = o6.clone()
+    ops.WINO_TILE = 3 if lib().refid_experimental_tiles() else 0
     t6 = timeit(lambda: ops.conv2d(a, w6, o6, algo=5, **kw))
+    same = bool(torch.equal(o6, o6n))
     diff = (o1 - o6).abs().max().item()
     # float64 reference on a crop of sample 0 (rows 0..15: includes the top border)
     crop = 18
@@ -41,8 +47,8 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
         ref = ref * torch.where(m[:1, :crop - 2].cpu() > 0, 1.0, 0.2)
     e1 = (o1[:1, :crop - 2].double().cpu() - ref).abs().max().item()
     e6 = (o6[:1, :crop - 2].double().cpu() - ref).abs().max().item()
-    print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us {fl/t1/1e12:6.1f} TF(eff) | wino x6 {t6*1e6:7.1f} us {fl/t6/1e12:6.1f} TF(eff) "
-          f"x{t1/t6:4.2f} | diff {diff:.1e}  err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}", flush=True)
+    print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us | x6 4-wave {t6n*1e6:7.1f} us | x6 auto (wide) {t6*1e6:7.1f} us {fl/t6/1e12:6.1f} TF(eff) "
+          f"x{t1/t6:4.2f} | wide == 4-wave bits: {same} | diff {diff:.1e}  err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}", flush=True)
 
 
 if __name__ == "__main__":

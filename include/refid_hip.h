@@ -195,7 +195,10 @@ typedef struct refid_wgrad_desc {
     int algo;                                   /* 0 = direct; 1 = Winograd F(2x2,3x3) (3x3 stride 1);
                                                    2 = direct with bf16 MFMA operands (3x3 stride 1 pad 1, more than 32
                                                    output and input channels; fp32 accumulation / slabs / dw; slab
-                                                   geometry and phases identical to algo 0)                   */
+                                                   geometry and phases identical to algo 0);
+                                                   3 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured
+                                                   0.75x algo 1): Winograd with the transform-domain products as six
+                                                   bf16 MFMAs on exactly split operands, as refid_conv2d algo 5  */
     int phase;                                  /* 0 = partial products + reduction in one call;
                                                    weights shared over the T recurrent steps can instead
                                                    keep accumulating in their own `slabs`:

@@ -14,10 +14,12 @@
 // ds_read_b32 of 32 consecutive channels) -- no transformed copy is ever stored.  Split-K over pixel
 // tiles into private slabs [split][xi][o][i]; bias gradient rides along as in conv_wgrad.hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int TH = 4, TW = 32;                 // output pixels per K tile (2 x 16 Winograd tiles)
+constexpr int TH_FP32 = TH;
 constexpr int COT = 64, CIT = 32;
 constexpr int PX = TH * TW;
 constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;
@@ -238,6 +240,217 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     }
 }
 
+#ifdef REFID_EXPERIMENTAL_TILES
+// ------------------------------------------------------------------------------------------------------------------
+// The same transform-domain GEMMs on the bf16 matrix cores, six exact-split bf16 products per fp32 product
+// (refid_wgrad_desc.algo = 3; the operand split and the product list of conv_wino6.hip):
+//     dU_xi[i][o] += sum_tiles V_xi[tile][i] * Z_xi[tile][o],   v = vh + vm + vl,  z = zh + zm + zl  (bf16 each, exact)
+// v_mfma_f32_32x32x16_bf16 takes K = 16 TILES per instruction and wants, per lane, eight consecutive K values of one
+// channel: lane (li = channel, kh) owns the tile columns 8kh .. 8kh+7 of one tile row.  A K tile is therefore ONE tile row
+// (2 output rows x 32 columns = 16 Winograd tiles): 6 bf16 MFMAs (192 matrix-pipe cycles) per accumulator and K tile
+// where the fp32 tile needs 8 x 64 = 512.  BOTH operands are transformed and split on the fly -- about 19 VALU per MFMA:
+// the kernel is VALU-bound, so it is built for VALU throughput: a 32(o) x 32(i) channel tile per workgroup (a wave =
+// one transform row, 4 accumulators) keeps a wave under 168 registers, three workgroups = three waves per SIMD.  The raw
+// tiles (gradient 2x32 px x 32 o, input halo 4x34 px x 32 i, fp32 NHWC as in memory) arrive by LDS-DMA
+// (buffer_load ... lds: no staging registers, no ds_write pass, hardware zero fill outside the image), double buffered,
+// one barrier per K tile; fragments are gathered with conflict-free ds_read_b32 (lane = channel).
+//
+// MEASURED (tools/bench_wgrad6.py, B=8, 8 grouped steps; profiles/r03_wgrad6_bench.txt): correct (same tests as the fp32
+// tile, 1e-5 relative to it) and SLOWER -- 0.72-0.81x the fp32 tile at two waves per SIMD (198 registers), 0.40-0.50x at
+// three (168 registers, spills in the loop): ~450 VALU + 36 LDS instructions per 24 MFMAs make it VALU-issue bound at
+// ~9 cycles per VALU instruction and SIMD, far from the matrix pipe's 768 cycles.  The 64(o) x 32(i) form (two sub-tiles
+// per wave, 14 VALU per MFMA) does not fit 256 registers.  Only in libraries built with REFID_EXPERIMENTAL_TILES=1.
+constexpr int TH6 = 2, COT6 = 32, GQ6 = COT6 / 4;
+constexpr int G6_F4 = TH6 * TW * GQ6;                     // 512 float4: [pixel][32 o]
+constexpr int HP6 = (TH6 + 2) * HWD;                      // 136 halo pixels
+constexpr int X6_F4 = HP6 * X4;                           // 1088 float4: [pixel][32 i]
+constexpr int BUF6_F4 = G6_F4 + X6_F4;
+constexpr int LDS6_BYTES = 2 * BUF6_F4 * 16;              // 51,200: three workgroups per CU
+constexpr int G6_PIECES = G6_F4 / 64, X6_PIECES = X6_F4 / 64;     // 8 / 17 one-KB pieces
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr6;
+
+__device__ __forceinline__ void split8f(const float (&v)[8], f32x4 (&pl)[3]) {
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const __bf16 h = (__bf16)v[k];
+        p0[k] = h;
+        const float r = v[k] - (float)h;
+        const __bf16 m = (__bf16)r;
+        p1[k] = m;
+        p2[k] = (__bf16)(r - (float)m);
+    }
+    pl[0] = __builtin_bit_cast(f32x4, p0);
+    pl[1] = __builtin_bit_cast(f32x4, p1);
+    pl[2] = __builtin_bit_cast(f32x4, p2);
+}
+
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void wgrad_wino6_kernel(const WwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kh = lane >> 5;
+    const int ti = wave;                                   // transform row owned by this wave
+    const int co0 = blockIdx.z * COT6, ci0 = blockIdx.y * CIT;
+    const int split = blockIdx.x;
+
+    const int ra = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
+    const int rb = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
+    const float sgn = (ti == 1) ? 1.f : -1.f;
+    const float ca = (ti == 3) ? 0.f : 1.f;
+    const float cb = (ti == 0) ? 0.f : ((ti == 1) ? 1.f : -1.f);
+
+    const bool xFromA = ci0 < a.Ca || ci0 >= a.Ctot;       // workgroup-uniform source (host: c_a % 32 == 0 for two sources)
+    const int xld = xFromA ? a.ldA : a.ldB;
+    const long long gpixAll = (long long)a.N * a.Ho * a.Wo, xpixAll = (long long)a.N * a.H * a.W;
+    const int limG = (int)min(gpixAll * a.ldG * 4, 0x7fffffffLL), limX = (int)min(xpixAll * xld * 4, 0x7fffffffLL);
+    const int ntAll = a.ntiles * a.groups;
+
+    // DMA pieces of this wave: a piece = 64 lanes x 16 bytes = 1 KB of the LDS image, which IS the memory layout
+    // (8 pixels x 32 channels for both tensors); lane -> (pixel, channel quad)
+    constexpr int GPW = G6_PIECES / 4;                     // 2 gradient pieces per wave
+    constexpr int XPW = (X6_PIECES + 3) / 4;               // 5 input pieces per wave (the 20 cover 17: the surplus repeats the last)
+    auto dma_tile = [&](int pt, int buf) {
+        // every per-lane offset is recomputed per tile from an opaque copy of the lane id: hoisted out of the K loop they
+        // would sit in (spilled) registers all along; a few dozen VALU per tile instead
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int cq = ln & 7, prow = ln >> 3;
+        const int gco = co0 + cq * 4, xc = ci0 + cq * 4;
+        const bool gcok = gco < a.Co, xcok = xc < a.Ctot;
+        const int xcc = xFromA ? xc : xc - a.Ca;
+        const int grp = pt / a.ntiles;                     // workgroup-uniform: the time step this tile belongs to
+        const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[grp]), 0, limG, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(xFromA ? a.inA[grp] : a.inB[grp]), 0, limX, 0x00020000);
+        int t = pt - grp * a.ntiles;
+        const int tx = t % a.tilesX; t /= a.tilesX;
+        const int ty = t % a.tilesY;
+        const int n = t / a.tilesY;
+        const int oy0 = ty * TH6, ox0 = tx * TW;
+        const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+        char* gdst = smem + (buf * BUF6_F4 + wave * GPW * 64) * 16;
+        char* xdst = smem + (buf * BUF6_F4 + G6_F4) * 16;
+#pragma unroll
+        for (int k = 0; k < GPW; ++k) {
+            const int p = (wave * GPW + k) * 8 + prow;
+            const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            // out of the image / channel range: the offset is forced out of range with an OR (a select becomes a branch)
+            const int bad = -(int)!(gcok && oy < a.Ho && ox < a.Wo);
+            const int vo = ((((n * a.Ho + oy) * a.Wo + ox) * a.ldG + gco) * 4) | bad;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr6)(gdst + k * 1024), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < XPW; ++k) {
+            const int piece = min(wave * XPW + k, X6_PIECES - 1);
+            const int hp = piece * 8 + prow;
+            const int iy = iy0 + hp / HWD, ix = ix0 + hp % HWD;
+            const int bad = -(int)!(xcok && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W);
+            const int vo = ((((n * a.H + iy) * a.W + ix) * xld + xcc) * 4) | bad;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr6)(xdst + piece * 1024), 16, vo, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[4];                                         // [j]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    float bs = 0.f;                                        // bias partial of channel li: this wave's quarter of the tile columns
+    constexpr int TA[6] = {0, 0, 1, 0, 2, 1};              // products kept: (V plane, Z plane), largest first
+    constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
+
+    int pt = split, it = 0;
+    if (pt < ntAll) dma_tile(pt, 0);
+    for (; pt < ntAll; pt += a.nsplit, ++it) {
+        const int cur = it & 1;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's DMA pieces of buffer `cur` have landed
+        __builtin_amdgcn_s_barrier();                      // ... everybody's; and everybody is done with the other buffer
+        __builtin_amdgcn_sched_barrier(0);
+        if (pt + a.nsplit < ntAll) dma_tile(pt + a.nsplit, cur ^ 1);
+        const float* sG = reinterpret_cast<const float*>(smem) + cur * BUF6_F4 * 4;
+        const float* sX = sG + G6_F4 * 4;
+        // ---- V side: row transform of this lane's 18 window columns (tile columns 8kh .. 8kh+7 of input channel li) ----
+        const float* xA = sX + (ra * HWD + 16 * kh) * CIT + li;
+        const float* xB = sX + (rb * HWD + 16 * kh) * CIT + li;
+        float tw[18];
+#pragma unroll
+        for (int c = 0; c < 18; ++c) tw[c] = xA[c * CIT] + sgn * xB[c * CIT];
+        // ---- Z side: X_b = ca dY[0][b] + cb dY[1][b] of the 8 tiles of output channel li ----
+        __builtin_amdgcn_sched_barrier(0);
+        float x0[8], x1[8];
+        {
+            const float* g0 = sG + (16 * kh) * COT6 + li;
+            const float* g1 = g0 + TW * COT6;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float a0 = g0[(2 * k) * COT6], a1 = g0[(2 * k + 1) * COT6];
+                const float b0 = g1[(2 * k) * COT6], b1 = g1[(2 * k + 1) * COT6];
+                x0[k] = ca * a0 + cb * b0;
+                x1[k] = ca * a1 + cb * b1;
+                // bias: every gradient value is counted by exactly one wave (tile columns k with k % 4 == this wave)
+                if ((k & 3) == ti) bs += (a0 + a1) + (b0 + b1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_sched_barrier(0);             // one column at a time (register budget: 3 waves per SIMD);
+                                                           // the other waves of the SIMD fill the matrix pipe meanwhile
+            float v[8], z[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = (j == 0) ? tw[2 * k] - tw[2 * k + 2] : (j == 1) ? tw[2 * k + 1] + tw[2 * k + 2]
+                     : (j == 2) ? tw[2 * k + 2] - tw[2 * k + 1] : tw[2 * k + 3] - tw[2 * k + 1];
+                z[k] = (j == 0) ? x0[k] : (j == 1) ? x0[k] + x1[k] : (j == 2) ? x0[k] - x1[k] : x1[k];
+            }
+            f32x4 pv[3], pz[3];
+            split8f(v, pv);
+            split8f(z, pz);
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, pv[TA[e]]), __builtin_bit_cast(bf16x8, pz[TB[e]]), acc[j], 0, 0, 0);
+        }
+    }
+
+    // ---- slab: [split][xi][co][ci]; D[ci][co]: lane li = output channel, register quad = 4 ci (as the fp32 tile) ----
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float* sl = a.slabs + ((long long)(split * 16 + ti * 4 + j) * a.CoP) * a.CiP;
+        const int co = co0 + li;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int ci = ci0 + 8 * qd + 4 * kh;
+            f32x4 vv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vv[k] = acc[j][4 * qd + k];
+            f32x4* dst = reinterpret_cast<f32x4*>(sl + (long long)co * a.CiP + ci);
+            if (a.accum) vv += *dst;
+            *dst = vv;
+        }
+    }
+    if (a.bslabs != nullptr && blockIdx.y == 0) {
+        // fixed order: the two column halves (kh) by one shuffle, then the four waves in sequence through LDS
+        float* sred = reinterpret_cast<float*>(smem);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();                                   // every wave is past its last tile read; no DMA in flight
+        const float v = bs + __shfl_xor(bs, 32, 64);
+        if (kh == 0) sred[wave * COT6 + li] = v;
+        __syncthreads();
+        if (tid < COT6) {
+            const float tot = ((sred[tid] + sred[COT6 + tid]) + sred[2 * COT6 + tid]) + sred[3 * COT6 + tid];
+            float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
+            *dst = a.accum ? *dst + tot : tot;
+        }
+    }
+}
+
+#else
+constexpr int TH6 = 2, COT6 = 32;              // (geometry of the experimental six-product kernel: workspace sizing only)
+#endif
+
 struct WrArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
@@ -304,18 +517,20 @@ __global__ __launch_bounds__(256) void wgrad_wino_reduce_kernel(const WrArgs a) 
 struct Geo { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
 
 Geo geo_of(const refid_wgrad_desc* d) {
+    const int TH = d->algo == 3 ? TH6 : TH_FP32;           // the six-product kernel's K tile is one tile row
     Geo g;
-    g.ncoT = cdiv(d->c_o, COT);
+    const int cot = d->algo == 3 ? COT6 : COT;
+    g.ncoT = cdiv(d->c_o, cot);
     const int ci_geo = (d->phase != 0) ? d->i_total - d->i_base : d->c_a + d->c_b;   // stable across steps
     g.nciT = cdiv(ci_geo > d->c_a + d->c_b ? ci_geo : d->c_a + d->c_b, CIT);
     g.tilesX = cdiv(d->wo, TW);
     g.tilesY = cdiv(d->ho, TH);
     g.ntiles = g.tilesX * g.tilesY * d->n;
-    int want = cdiv(512, g.ncoT * g.nciT);
+    int want = cdiv(d->algo == 3 ? 768 : 512, g.ncoT * g.nciT);
     if (want < 1) want = 1;
     if (want > g.ntiles) want = g.ntiles;
     g.nsplit = want;
-    g.CoP = g.ncoT * COT;
+    g.CoP = g.ncoT * cot;
     g.CiP = g.nciT * CIT;
     return g;
 }
@@ -328,8 +543,16 @@ size_t refid_wgrad_wino_workspace_bytes(const refid_wgrad_desc* d) {
 }
 
 int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
+    static std::atomic<unsigned long long> attr_done{0}, attr_done6{0};
     if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino_kernel, LDS_BYTES, "wgrad_wino")) return rc;
+#ifdef REFID_EXPERIMENTAL_TILES
+    static std::atomic<unsigned long long> attr_done62{0};
+    if (int rc = refid_lds_attr_once(attr_done6, &wgrad_wino6_kernel<3>, LDS6_BYTES, "wgrad_wino6")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done62, &wgrad_wino6_kernel<2>, LDS6_BYTES, "wgrad_wino6")) return rc;
+#else
+    REFID_CHECK(d->algo != 3, "wgrad: algo 3 (Winograd, six bf16 products) is an experiment that measured slower than algo 1; "
+                              "build with REFID_EXPERIMENTAL_TILES=1 to run it");
+#endif
     const Geo g = geo_of(d);
     REFID_CHECK(d->c_b == 0 || d->c_a % CIT == 0, "wgrad (Winograd): c_a must be a multiple of %d for two sources", CIT);
     {
@@ -359,7 +582,18 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
     a.CoP = g.CoP; a.CiP = g.CiP;
     a.accum = (d->phase == 2);
     if (d->phase != 3) {
-        hipLaunchKernelGGL(wgrad_wino_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS_BYTES, st, a);
+        if (d->algo == 3) {
+            REFID_CHECK(d->ld_g % 4 == 0 && d->ld_a % 4 == 0 && (d->c_b == 0 || d->ld_b % 4 == 0) && d->c_o % 4 == 0 &&
+                            (d->c_a + d->c_b) % 4 == 0,
+                        "wgrad (Winograd, six products): pitches and channel counts must be multiples of 4");
+#ifdef REFID_EXPERIMENTAL_TILES
+            static const int wps = []() { const char* e = getenv("REFID_WGRAD6_WPS"); return e ? atoi(e) : 2; }();
+            if (wps == 2) hipLaunchKernelGGL(wgrad_wino6_kernel<2>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS6_BYTES, st, a);
+            else hipLaunchKernelGGL(wgrad_wino6_kernel<3>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS6_BYTES, st, a);
+#endif
+        } else {
+            hipLaunchKernelGGL(wgrad_wino_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS_BYTES, st, a);
+        }
         REFID_LAUNCH_CHECK("wgrad_wino");
     }
     if (d->phase == 1 || d->phase == 2) return 0;          // reduction deferred (phase 3)

@@ -197,6 +197,10 @@ DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
 # smallest output-channel count whose 3x3 weight gradient goes to the Winograd tile (64 x 32 channel tiles)
 WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
 WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
+# Experiment (REFID_EXPERIMENTAL_TILES builds only): Winograd weight gradient with six exact-split bf16 products per fp32
+# product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
+# are transformed and split on the fly, ~19 VALU per MFMA.  Off.
+WGRAD_WINO6 = os.environ.get("REFID_WGRAD_WINO6", "0") == "1"
 
 
 def flush_wgrads(device):
@@ -474,6 +478,8 @@ class ConvOp:
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
         if algo == 1 and b is not None and a.shape[3] % 32 != 0:
             algo = 0          # the Winograd weight-gradient tile picks the source per 32-channel tile (base 24, 40, 48 ...)
+        if algo == 1 and WGRAD_WINO6 and not self.bf16:
+            algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):

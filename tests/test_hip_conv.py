@@ -482,8 +482,12 @@ def test_winograd_dgrad(cfg):
     (2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 256, 256, 256), (1, 5, 3, 64, 0, 128),
     (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 32, 32), (1, 8, 32, 32, 0, 3),
 ])
-def test_winograd_wgrad(cfg):
+@pytest.mark.parametrize("algo", [1, 3])
+def test_winograd_wgrad(cfg, algo):
+    """algo 1: fp32 MFMA; algo 3 (experimental builds): six exact-split bf16 products per fp32 product."""
     ops = _ops()
+    if algo == 3:
+        _need_experimental()
     N, H, W, Ca, Cb, Co = cfg
     x = rnd(N, Ca + Cb, H, W, seed=1)
     w = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
@@ -501,7 +505,7 @@ def test_winograd_wgrad(cfg):
     xa = nhwc(x[:, :Ca])
     xb = nhwc(x[:, Ca:]) if Cb else None
     for _ in range(2):
-        ops.conv2d_wgrad(gd, xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=1)
+        ops.conv2d_wgrad(gd, xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=algo)
     scale = max(1.0, float(w.grad.abs().max()))
     np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
     np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
@@ -913,17 +917,20 @@ def test_bf16_weight_gradient_tile(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 33, 64, 64, 128)])
-def test_winograd_wgrad_grouped_time_steps(cfg):
+@pytest.mark.parametrize("algo", [1, 3])
+def test_winograd_wgrad_grouped_time_steps(cfg, algo):
     """refid_wgrad_desc.groups: the Winograd weight gradients of several time steps of one conv in ONE launch (the weights
     are shared over T) == the same calls one by one -- persistent-slab phases included."""
     ops = _ops()
+    if algo == 3:
+        _need_experimental()
     N, H, W, Ca, Cb, Co = cfg
     steps = []
     for t in range(4):
         x = rnd(N, Ca + Cb, H, W, seed=10 + t)
         g = rnd(N, Co, H, W, seed=20 + t)
         steps.append((nhwc(g), nhwc(x[:, :Ca]), nhwc(x[:, Ca:]) if Cb else None))
-    kw = dict(kh=3, kw=3, stride=1, pad=1, algo=1, i_total=Ca + Cb)
+    kw = dict(kh=3, kw=3, stride=1, pad=1, algo=algo, i_total=Ca + Cb)
 
     def run(grouping):
         dw = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")

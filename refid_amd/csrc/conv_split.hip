@@ -226,9 +226,12 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
                     const int it = i - 2 * C::A_ITEMS;
                     // (the hardware range check covers the vector offset only: a sub-chunk past K -- Ctot % 16 == 8 with
                     //  two sub-chunks per stage -- must not travel as a scalar offset, it would read past the class's weights)
-                    const bool wok = ch * KS + sub < nsub;
+                    //  forced out of range with an OR: a select here becomes a branch around the load + a full wait)
+                    //  Only MODE 2 can get there (MODE 0 stages one sub-chunk, MODE 1's four sub-chunks always exist).
+                    int vo = voW[it];
+                    if constexpr (MODE == 2) vo |= (ch * KS + sub < nsub) ? 0 : OOB;
                     rb[sub][it] = __builtin_bit_cast(
-                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, wok ? voW[it] : OOB, wok ? (ch * KS + sub) * wChunk : 0, 0));
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, (ch * KS + sub) * wChunk, 0));
                 }
             }
         }

@@ -1,7 +1,8 @@
 #!/bin/bash
-# One round's profile artefacts (run on the GPU box):  bash tools/profile_round.sh r02
+# One round's profile artefacts (run on the GPU box):  bash tools/profile_round.sh r03
 # -> gpurun_out/<tag>_*: rocprofv3 kernel stats of the default bench command (weight gradients on the side stream) and of the
-#    single-stream variant, B=1 and bf16 variants, FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs), Winograd tile traces.
+#    single-stream variant, B=1 and bf16 variants, FETCH_SIZE / WRITE_SIZE and SQ counter passes (separate --pmc runs, with
+#    --kernel-trace only), the per-kernel roofline table (tools/roofline_report.py), bench lines of the three dtypes.
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -9,23 +10,31 @@ bash $R/tools/prof_step.sh ${tag}_bench_n1 --steps 3 --warmup 1 --no-cpu-baselin
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 bash $R/tools/prof_step.sh ${tag}_bench_n1_nooverlap --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
 bash $R/tools/prof_step.sh ${tag}_b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 bash $R/tools/prof_step.sh ${tag}_bf16_nooverlap --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
-REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 bash $R/tools/prof_step.sh ${tag}_bf16x3_nooverlap --dtype bf16x3 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
 cd /tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+PASSES="FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CU_CYCLES,GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_VALU,SQ_INSTS_LDS"
+i=0
+for c in $PASSES; do
+  i=$((i+1)); rm -rf /tmp/pmc_$i
+  REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 rocprofv3 --kernel-trace --pmc ${c//,/ } --output-format csv -d /tmp/pmc_$i -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
 done
-f=$(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1)
-w=$(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+f=$(find /tmp/pmc_1 -name "*counter_collection.csv" | head -1)
+w=$(find /tmp/pmc_2 -name "*counter_collection.csv" | head -1)
 python $R/tools/pmc_traffic.py "$f" "$w" $R/gpurun_out/${tag}_pmc_traffic.json
+# the same two passes for the bf16 mode (roofline.traffic of `bench.py --dtype bf16`)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmcb_$c
+  REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcb_$c -- python $R/bench.py --dtype bf16 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+done
+python $R/tools/pmc_traffic.py "$(find /tmp/pmcb_FETCH_SIZE -name '*counter_collection.csv' | head -1)" "$(find /tmp/pmcb_WRITE_SIZE -name '*counter_collection.csv' | head -1)" $R/gpurun_out/${tag}_pmc_traffic_bf16.json
 cd $R
-python tools/probes/wino_trace.py > gpurun_out/${tag}_wino_tile_trace.txt 2>&1
-python tools/probes/wino_trace.py --persistent > gpurun_out/${tag}_wino_persistent_trace.txt 2>&1
-python tools/bench_wino2.py > gpurun_out/${tag}_wino_tiles_bench.txt 2>&1
-python tools/probes/split_trace.py > gpurun_out/${tag}_split_tile_trace.txt 2>&1
-python tools/bench_split.py > gpurun_out/${tag}_split_tiles_bench.txt 2>&1
-ZERO=1 python tools/bench_split.py > gpurun_out/${tag}_split_tiles_bench_zero_data.txt 2>&1
-tools/probes/bin/mfma_lds_feed > gpurun_out/${tag}_mfma_lds_feed.txt 2>&1
+python tools/profile_step.py --json gpurun_out/${tag}_algorithmic.json > gpurun_out/${tag}_profile_step.txt 2>&1
+python tools/roofline_report.py --stats gpurun_out/${tag}_bench_n1_nooverlap_kernel_stats.csv --steps 4 \
+  --algo gpurun_out/${tag}_algorithmic.json --traffic gpurun_out/${tag}_pmc_traffic.json \
+  --sq $(find /tmp/pmc_3 /tmp/pmc_4 -name "*counter_collection.csv") \
+  --out gpurun_out/${tag}_roofline_per_kernel.csv --summary gpurun_out/${tag}_pmc_summary.txt > gpurun_out/${tag}_roofline_report.txt 2>&1
+python tools/bench_wino6.py > gpurun_out/${tag}_wino6_tiles_bench.txt 2>&1
+python tools/probes/wino6_ablate.py > gpurun_out/${tag}_wino6_ablation.txt 2>&1
+tools/probes/bin/wino6_loop > gpurun_out/${tag}_wino6_loop_probe.txt 2>&1
 python tools/grad_error_report.py > gpurun_out/${tag}_grad_error_report.txt 2>&1
 for d in fp32 bf16x3 bf16; do python bench.py --dtype $d --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_$d.json; done
 ls -la gpurun_out | tail -30

@@ -28,6 +28,13 @@ agg = collections.defaultdict(lambda: [0.0, 0.0, 0])
 for name, fl, s, e, shape, _nb in prof:
     k = (name.replace("conv_igemm_kernel", "conv").replace("Cfg", ""), shape)
     v = agg[k]; v[0] += fl; v[1] += s.elapsed_time(e); v[2] += 1
+if "--json" in sys.argv:          # algorithmic FLOPs / bytes per kernel family for tools/roofline_report.py
+    import json
+    fam = collections.defaultdict(lambda: dict(flops=0.0, bytes=0.0, ms=0.0, launches=0))
+    for name, fl, s, e, shape, nb in prof:
+        f = fam[name]
+        f["flops"] += fl; f["bytes"] += nb; f["ms"] += s.elapsed_time(e); f["launches"] += 1
+    json.dump(fam, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
 tot = sum(v[1] for v in agg.values())
 print(f"step {step_ms:.1f} ms, instrumented GEMM kernels {tot:.1f} ms")
 byname = collections.defaultdict(lambda: [0.0, 0])

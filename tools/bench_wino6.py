@@ -47,8 +47,9 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
         ref = ref * torch.where(m[:1, :crop - 2].cpu() > 0, 1.0, 0.2)
     e1 = (o1[:1, :crop - 2].double().cpu() - ref).abs().max().item()
     e6 = (o6[:1, :crop - 2].double().cpu() - ref).abs().max().item()
-    print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us | x6 4-wave {t6n*1e6:7.1f} us | x6 auto (wide) {t6*1e6:7.1f} us {fl/t6/1e12:6.1f} TF(eff) "
-          f"x{t1/t6:4.2f} | wide == 4-wave bits: {same} | diff {diff:.1e}  err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}", flush=True)
+    wide = "wide 8-wave tile" if lib().refid_experimental_tiles() else "repeat"
+    print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us | x6 {t6n*1e6:7.1f} us {fl/t6n/1e12:6.1f} TF(eff) x{t1/t6n:4.2f} | x6 {wide} {t6*1e6:7.1f} us "
+          f"(same bits: {same}) | x6 vs fp32 {diff:.1e}  err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -198,7 +198,10 @@ typedef struct refid_wgrad_desc {
                                                    geometry and phases identical to algo 0);
                                                    3 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured
                                                    0.75x algo 1): Winograd with the transform-domain products as six
-                                                   bf16 MFMAs on exactly split operands, as refid_conv2d algo 5  */
+                                                   bf16 MFMAs on exactly split operands, as refid_conv2d algo 5;
+                                                   4 = experiment (same builds; measured equal to algo 1 in the train step):
+                                                   algo 1's fp32 tile fed by LDS-DMA into two buffers, one barrier per K
+                                                   tile (pitches multiples of 4 floats, 16-byte aligned tensors)  */
     int phase;                                  /* 0 = partial products + reduction in one call;
                                                    weights shared over the T recurrent steps can instead
                                                    keep accumulating in their own `slabs`:

@@ -482,12 +482,15 @@ def test_winograd_dgrad(cfg):
     (2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 256, 256, 256), (1, 5, 3, 64, 0, 128),
     (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 32, 32), (1, 8, 32, 32, 0, 3),
 ])
-@pytest.mark.parametrize("algo", [1, 3])
+@pytest.mark.parametrize("algo", [1, 3, 4])
 def test_winograd_wgrad(cfg, algo):
-    """algo 1: fp32 MFMA; algo 3 (experimental builds): six exact-split bf16 products per fp32 product."""
+    """algo 1: fp32 MFMA; experimental builds: algo 3 = six exact-split bf16 products per fp32 product, algo 4 = the fp32
+    tile fed by LDS-DMA into two buffers."""
     ops = _ops()
-    if algo == 3:
+    if algo in (3, 4):
         _need_experimental()
+    if algo == 4 and cfg[5] % 4:
+        pytest.skip("the LDS-DMA kernel moves 16-byte pieces")
     N, H, W, Ca, Cb, Co = cfg
     x = rnd(N, Ca + Cb, H, W, seed=1)
     w = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
@@ -917,12 +920,12 @@ def test_bf16_weight_gradient_tile(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 33, 64, 64, 128)])
-@pytest.mark.parametrize("algo", [1, 3])
+@pytest.mark.parametrize("algo", [1, 3, 4])
 def test_winograd_wgrad_grouped_time_steps(cfg, algo):
     """refid_wgrad_desc.groups: the Winograd weight gradients of several time steps of one conv in ONE launch (the weights
     are shared over T) == the same calls one by one -- persistent-slab phases included."""
     ops = _ops()
-    if algo == 3:
+    if algo in (3, 4):
         _need_experimental()
     N, H, W, Ca, Cb, Co = cfg
     steps = []

@@ -146,7 +146,10 @@ typedef struct refid_conv_desc {
                                                    build runs the default tile.  Same results bit for bit; 2 measured
                                                    10-30 % slower.                                                    */
     const refid_pw_extras* pw;                  /* algo 3 only: fusions around the pointwise conv, or NULL               */
-    int mfma_terms;                             /* algo 4 only: 0 / 6 = three bf16 planes per operand, six products
+    int mfma_terms;                             /* algo 3: 0 = fp32 MFMA products; 6 = six bf16 products on exactly split
+                                                   operands (w_packed from refid_pack_conv_weights_split with kh = kw = 1,
+                                                   three planes; channel counts multiples of 16, more than 32 outputs).
+                                                   algo 4: 0 / 6 = three bf16 planes per operand, six products
                                                    (error <= 2^-23 per product: fp32 class, closer to the fp64 result
                                                    than the fp32 Winograd tile); 3 = two planes, three products
                                                    (2^-16 per product: explicit opt-in, still finer than TF32)       */
@@ -253,6 +256,10 @@ int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* pack
  *   4x4 stride 2, REFID_ROLE_FWD (conv_down):     [chunk8][in-block row sy][in-block column sx][plane][block tap (ty,tx)]
  *                                                 [rows][8] = W[row][k][2ty+sy][2tx+sx]
  *   4x4 stride 2, REFID_ROLE_DOWN_DGRAD:          [parity class][chunk8][plane][tap (ta,tb)][rows][8]
+ *   1x1 (REFID_ROLE_FWD / REFID_ROLE_DGRAD, refid_conv2d algo 3 with mfma_terms 6, bn = 32):
+ *                                                 [chunk16][plane][rows padded to bn][16], a row's 16 channels stored as the
+ *                                                 two K halves of the pointwise tile's lanes: slot 8h + t = channel 4h + t
+ *                                                 (t < 4) or 8 + 4h + (t - 4)
  * refid_packed_weight_split_bytes gives the buffer size. */
 size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes);
 int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,

@@ -52,4 +52,5 @@ struct PwExtra {
     const float* res2 = nullptr; int ldR2 = 0;
     float* out2 = nullptr; int ldO2 = 0;
 };
-int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st, const PwExtra* ex = nullptr);
+// terms: 0 = fp32 MFMA products, 6 = six bf16 products on exactly split operands (weights from refid_pack_conv_weights_split, 1x1)
+int refid_launch_pointwise(const ConvKArgs& a, hipStream_t st, const PwExtra* ex = nullptr, int terms = 0);

@@ -528,9 +528,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
             REFID_CHECK((!e.lnOut || al(e.lnOut, e.ldLn)) && (!e.xsOut || al(e.xsOut, e.ldXs)) && (!e.res2 || al(e.res2, e.ldR2)) &&
                             (!e.out2 || al(e.out2, e.ldO2)) && (!e.lnG || (al(e.lnG, 4) && al(e.lnB, 4))),
                         "conv2d: pointwise fusion tensors must be 16-byte aligned with pitches that are multiples of 4");
-            return refid_launch_pointwise(a, st, &e);
+            return refid_launch_pointwise(a, st, &e, d->mfma_terms);
         }
-        return refid_launch_pointwise(a, st);
+        return refid_launch_pointwise(a, st, nullptr, d->mfma_terms);
     }
     if (d->algo == 4) {
         static int cus = 0;

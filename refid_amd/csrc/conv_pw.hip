@@ -13,13 +13,44 @@
 // (1 KB contiguous per wave, L2 resident).  Activations are prefetched 32-64 channels ahead, weights one
 // chunk ahead; <= 128 registers => 4 waves per SIMD overlap the load / MFMA / store phases of different
 // waves (measured: occupancy matters more here than activation re-use across column tiles).  Fused 16-byte epilogue as everywhere else.
+//
+// SIX (refid_conv_desc.mfma_terms = 6; channel counts multiples of 16): the same tile with its products on the bf16 matrix
+// cores -- every fp32 operand is the exact sum of three bf16 numbers (weights pre-split by refid_pack_conv_weights_split's
+// 1x1 layout, activations split in registers: 44 VALU per 8 values), six v_mfma_f32_32x32x16_bf16 per fp32 product
+// (conv_split.hip's list).  Per 16 input channels and 64 output channels: 12 x 32 = 384 matrix-pipe cycles instead of
+// 16 x 64 = 1024, at the fp32 tile's distance from the float64 result.  The waves of a workgroup run their load / MFMA /
+// store phases in lockstep, so the MFMA phase is a third of the kernel's time when the operands are warm (1.03-1.26x then,
+// tools/bench_pw6.py); inside the train step, on cold operands, the two forms time the same (39.8 vs 39.2 ms per step): the
+// engine keeps the fp32 form (REFID_PW6=1 switches).
 #include "common.h"
 #include "conv_args.h"
 
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int KC = 8;
+// the six products kept, largest first: (weight plane, activation plane)
+__device__ constexpr int PW_TA[6] = {0, 1, 0, 2, 0, 1};
+__device__ constexpr int PW_TB[6] = {0, 0, 1, 0, 2, 1};
+
+// v = h + m + l exactly (h = rne(v), m = rne(v - h), l = v - h - m), eight values -> three bf16x8 planes
+__device__ __forceinline__ void pw_split8(const f32x4& v0, const f32x4& v1, f32x4 (&pl)[3]) {
+    bf16x8 p0, p1, p2;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = k < 4 ? v0[k] : v1[k - 4];
+        const __bf16 h = (__bf16)v;
+        p0[k] = h;
+        const float r = v - (float)h;
+        const __bf16 m = (__bf16)r;
+        p1[k] = m;
+        p2[k] = (__bf16)(r - (float)m);
+    }
+    pl[0] = __builtin_bit_cast(f32x4, p0);
+    pl[1] = __builtin_bit_cast(f32x4, p1);
+    pl[2] = __builtin_bit_cast(f32x4, p2);
+}
 constexpr int OOB = -1;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
@@ -36,8 +67,8 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 //     [xi*s | xe*s] concatenation is never a tensor on the inference path; training stores it once for conv3's weight
 //     gradient);
 //   * a second residual (y = ev + img + beta*conv3(.), fm:319) and a GELU second output (fm:327-329).
-template <int NT, int XD, bool EX>
-__global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, const PwExtra e) {
+template <int NT, int XD, bool EX, bool SIX = false>
+__global__ __launch_bounds__(256, SIX ? 3 : 4) void conv_pw_kernel(const ConvKArgs a, const PwExtra e) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const long long npix = (long long)a.N * a.H * a.W;
@@ -50,8 +81,9 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.inB ? a.inB : a.inA), 0, (int)min(npix * (a.inB ? a.ldB : a.ldA) * 4, 0x7fffffffLL),
         0x00020000);
+    // (SIX: [chunk16][plane][row][16] bf16 = 3 x 32 bytes per row and 16 channels -- 1.5x the fp32 bytes)
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * a.CoutPad * KC * 4, 0x7fffffffLL), 0x00020000);
+        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * a.CoutPad * KC * (SIX ? 6 : 4), 0x7fffffffLL), 0x00020000);
     const bool pok = p < npix;
     const int voA = pok ? (int)(p * a.ldA * 4) + kh * 16 : OOB;
     const int voB = pok ? (int)(p * a.ldB * 4) + kh * 16 : OOB;
@@ -59,9 +91,10 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int row = a.coBase + n0 + nt * 32 + li;
-        voW[nt] = (row < a.CoutPad) ? (row * KC + kh * 4) * 4 : OOB;
+        voW[nt] = (row < a.CoutPad) ? (SIX ? row * 32 + kh * 16 : (row * KC + kh * 4) * 4) : OOB;
     }
     const int wChunk = a.CoutPad * KC * 4;
+    const int wPlane = a.CoutPad * 32;                      // SIX: bytes per (chunk16, plane)
 
     f32x16 acc[NT];
 #pragma unroll
@@ -83,12 +116,32 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
         for (int nt = 0; nt < NT; ++nt)
             dst[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[nt], ch * wChunk, 0));
     };
+    // SIX: the three planes of chunk pair c16; lane (li = row, kh) gets channels {4kh..4kh+3, 8+4kh..8+4kh+3} of the 16 --
+    // the order in which the activation registers of two consecutive 8-channel chunks line up
+    auto load_w6 = [&](int c16, f32x4 (&dst)[3][NT]) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                dst[pl][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, voW[nt], (c16 * 3 + pl) * wPlane, 0));
+    };
+    auto mfma6 = [&](const f32x4& x0, const f32x4& x1, const f32x4 (&w6)[3][NT]) {
+        f32x4 pl[3];
+        pw_split8(x0, x1, pl);
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w6[PW_TA[t]][nt]),
+                                                                  __builtin_bit_cast(bf16x8, pl[PW_TB[t]]), acc[nt], 0, 0, 0);
+    };
 
     // Activations are prefetched XD chunks (= 8*XD channels, HBM latency) ahead, weights one chunk
     // (L2 latency) ahead.  vmcnt retires in issue order, so inside iteration c the weight load of c+1
     // is issued BEFORE the activation load of c+XD: waiting for the former never waits for the latter.
     f32x4 xr[2 * XD];
-    f32x4 wr[2][NT];
+    f32x4 wr[SIX ? 1 : 2][NT];
+    f32x4 w6[SIX ? 2 : 1][3][NT];
     const int nch = a.nchunks;
     __shared__ float sS[EX ? 128 : 1];                       // squeeze-excite vector of this workgroup's sample
     bool ln_done = false;
@@ -125,7 +178,8 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
             // LayerNorm2d prologue: all nch (<= 2*XD) chunks of this lane's half of the pixel in registers
 #pragma unroll
             for (int j = 0; j < 2 * XD; ++j) xr[j] = (j < nch) ? load_x(j) : f32x4{0.f, 0.f, 0.f, 0.f};
-            load_w(0, wr[0]);
+            if constexpr (SIX) load_w6(0, w6[0]);
+            else load_w(0, wr[0]);
             float s1 = 0.f;
 #pragma unroll
             for (int j = 0; j < 2 * XD; ++j) s1 += (xr[j][0] + xr[j][1]) + (xr[j][2] + xr[j][3]);
@@ -151,16 +205,25 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
                     if (e.lnOut != nullptr && blockIdx.y == 0 && pok)
                         *reinterpret_cast<f32x4*>(e.lnOut + p * e.ldLn + c) = xr[j];
                 }
+            if constexpr (SIX) {
 #pragma unroll
-            for (int j = 0; j < 2 * XD; ++j)
-                if (j < nch) {
-                    if (j + 1 < nch) load_w(j + 1, wr[(j + 1) & 1]);
+                for (int j = 0; j < 2 * XD; j += 2)
+                    if (j < nch) {
+                        if (j + 2 < nch) load_w6(j / 2 + 1, w6[(j / 2 + 1) & 1]);
+                        mfma6(xr[j], xr[j + 1], w6[(j / 2) & 1]);
+                    }
+            } else {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
+                for (int j = 0; j < 2 * XD; ++j)
+                    if (j < nch) {
+                        if (j + 1 < nch) load_w(j + 1, wr[(j + 1) & 1]);
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
-                }
+                        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+                    }
+            }
             ln_done = true;
         }
     }
@@ -168,13 +231,18 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
 #pragma unroll
         for (int j = 0; j < XD; ++j)
             if (j < nch) xr[j] = load_x(j);
-        load_w(0, wr[0]);
+        if constexpr (SIX) load_w6(0, w6[0]);
+        else load_w(0, wr[0]);
         for (int c0 = 0; c0 < nch; c0 += 2 * XD) {
 #pragma unroll
             for (int j = 0; j < 2 * XD; ++j) {
                 const int c = c0 + j;
                 if (c < nch) {
-                    if (c + 1 < nch) load_w(c + 1, wr[(j + 1) & 1]);
+                    if constexpr (SIX) {
+                        if ((j & 1) == 0 && c + 2 < nch) load_w6(c / 2 + 1, w6[(j / 2 + 1) & 1]);
+                    } else {
+                        if (c + 1 < nch) load_w(c + 1, wr[(j + 1) & 1]);
+                    }
                     if (c + XD < nch) xr[(j + XD) % (2 * XD)] = load_x(c + XD);
                     if constexpr (EX) {
                         if (e.pool != nullptr) {                   // operand channel k scaled by s[k mod C]
@@ -185,11 +253,15 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
                                 *reinterpret_cast<f32x4*>(e.xsOut + p * e.ldXs + k0) = xr[j];
                         }
                     }
+                    if constexpr (SIX) {
+                        if (j & 1) mfma6(xr[j - 1], xr[j], w6[(j / 2) & 1]);       // host: an even number of 8-channel chunks
+                    } else {
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
+                        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[j & 1][nt][kk], xr[j][kk], acc[nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -276,11 +348,15 @@ __global__ __launch_bounds__(256, 4) void conv_pw_kernel(const ConvKArgs a, cons
 
 }  // namespace
 
-int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* ex) {
+int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* ex, int terms) {
     ConvKArgs a = ka;
     a.nchunks = cdiv(a.Ctot, KC);
     const long long npix = (long long)a.N * a.H * a.W;
     const int nb = (int)((npix + 127) / 128);
+    const bool six = terms == 6;
+    REFID_CHECK(terms == 0 || terms == 6, "conv2d: the pointwise tile has fp32 products (0) or six bf16 products (6), got %d", terms);
+    REFID_CHECK(!six || (a.Ctot % 16 == 0 && (a.inB == nullptr || a.Ca % 16 == 0) && a.Cout > 32),
+                "conv2d: the six-product pointwise tile needs channel counts that are multiples of 16 and more than 32 outputs");
     if (ex != nullptr) {
         REFID_CHECK(a.vecOK && a.Cout > 32, "conv2d: pointwise fusions need 16-byte aligned tensors and more than 32 outputs");
         REFID_CHECK(!ex->lnG || (a.inB == nullptr && a.Ctot % 8 == 0 && a.Ctot <= 64 && ex->lnB),
@@ -289,13 +365,15 @@ int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* e
                                   a.Ctot % ex->seC == 0 && ex->poolParts > 0 && ex->seW1 && ex->seB1 && ex->seW2 && ex->seB2 &&
                                   (!ex->seS || (ex->seM && ex->seZ1)) && !ex->lnG),
                     "conv2d: bad squeeze-excite fusion arguments (pixels per sample must be a multiple of 128)");
-        hipLaunchKernelGGL((conv_pw_kernel<2, 4, true>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, *ex);
+        if (six) hipLaunchKernelGGL((conv_pw_kernel<2, 4, true, true>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, *ex);
+        else hipLaunchKernelGGL((conv_pw_kernel<2, 4, true>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, *ex);
         REFID_LAUNCH_CHECK("conv_pw/fused");
         return 0;
     }
     const PwExtra none;
     // wider layers run as 64-channel column tiles (grid.y): 4 waves/SIMD beat re-using the activations
-    if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1, 8, false>), dim3(nb, 1), dim3(256), 0, st, a, none);
+    if (six) hipLaunchKernelGGL((conv_pw_kernel<2, 4, false, true>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, none);
+    else if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1, 8, false>), dim3(nb, 1), dim3(256), 0, st, a, none);
     else hipLaunchKernelGGL((conv_pw_kernel<2, 4, false>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, none);
     REFID_LAUNCH_CHECK("conv_pw");
     return 0;

@@ -202,6 +202,30 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int p
     }
 }
 
+// 1x1 (conv_pw.hip, six products): [chunk16][plane][rowsPad][16]; the 16 channels of a row are stored as the two MFMA K
+// halves of the pointwise tile's lanes: slot 8h + t = channel 4h + t (t < 4) or 8 + 4h + (t - 4)
+__global__ __launch_bounds__(256) void pack_pw6_kernel(const PackArgs p, int planes) {
+    const int nc16 = (p.K + 15) / 16;
+    const long long total = (long long)nc16 * planes * p.rowsPad * 16;
+    __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        long long r = e;
+        const int slot = r % 16; r /= 16;
+        const int row = r % p.rowsPad; r /= p.rowsPad;
+        const int plane = r % planes;
+        const int chunk = r / planes;
+        const int h = slot >> 3, t = slot & 7;
+        const int k = chunk * 16 + (t < 4 ? 4 * h + t : 8 + 4 * h + (t - 4));
+        float v = 0.f;
+        if (row < p.rows && k < p.K) v = pack_fetch(p, 0, 0, row, k);
+        const __bf16 hh = (__bf16)v;
+        const float r1 = v - (float)hh;
+        const __bf16 m = (__bf16)r1;
+        const __bf16 l = (__bf16)(r1 - (float)m);
+        dst[e] = plane == 0 ? hh : (plane == 1 ? m : l);
+    }
+}
+
 // Winograd-domain weights U = G g G^T as three bf16 planes for conv_wino6.hip: [chunk16][xi][plane][rowsPad][16]
 __global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
     const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
@@ -281,10 +305,12 @@ static int split_pack_mode(int role, int kh, int kw) {
     if ((role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD) && kh == 3 && kw == 3) return 0;
     if (role == REFID_ROLE_FWD && kh == 4 && kw == 4) return 1;
     if (role == REFID_ROLE_DOWN_DGRAD && kh == 4 && kw == 4) return 2;
+    if ((role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD) && kh == 1 && kw == 1) return 3;
     return -1;
 }
 
 static long long split_pack_elems(const PackArgs& p, int planes, int mode) {
+    if (mode == 3) return (long long)((p.K + 15) / 16) * planes * p.rowsPad * 16;
     return (long long)p.ncls * p.nchunks * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? p.ntaps + 1 : 4) * p.rowsPad * 8;
 }
 
@@ -301,12 +327,13 @@ extern "C" int refid_pack_conv_weights_split(const float* w, const float* oscale
     PackArgs p;
     REFID_CHECK(w && packed, "pack_split: null pointer");
     const int mode = split_pack_mode(role, kh, kw);
-    REFID_CHECK(mode >= 0, "pack_split: FWD / DGRAD of a 3x3 kernel, FWD / DOWN_DGRAD of a 4x4 (stride 2) kernel");
+    REFID_CHECK(mode >= 0, "pack_split: FWD / DGRAD of a 3x3 or 1x1 kernel, FWD / DOWN_DGRAD of a 4x4 (stride 2) kernel");
     REFID_CHECK(planes >= 1 && planes <= 3, "pack_split: 1, 2 or 3 planes (got %d)", planes);
     REFID_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_split: unknown role %d", role);
     p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
     const long long total = split_pack_elems(p, planes, mode);
-    hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes, mode);
+    if (mode == 3) hipLaunchKernelGGL(pack_pw6_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes);
+    else hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes, mode);
     REFID_LAUNCH_CHECK("pack_conv_weights_split");
     return 0;
 }

@@ -194,6 +194,12 @@ WINO6 = os.environ.get("REFID_WINO6", "1") != "0"
 # fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
 # split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
 DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
+# 1x1 convolutions on the pointwise tile's six-product form (refid_conv2d algo 3, mfma_terms 6).  Measured
+# (tools/bench_pw6.py, profiles/r03_pw6_bench.txt): 1.03-1.26x the fp32-MFMA form when the launch is repeated on warm
+# operands, NO gain inside the train step (676 launches: 39.8 vs 39.2 ms; the squeeze-excite fused conv3 is slower, 116
+# vs 90 us) -- on cold operands these tiles wait for HBM, not for the matrix pipe, and the six-product form runs 3 instead of
+# 4 waves per SIMD (144 registers).  Off; the form stays reachable through the C ABI and is tested.
+PW6 = os.environ.get("REFID_PW6", "0") == "1"
 # smallest output-channel count whose 3x3 weight gradient goes to the Winograd tile (64 x 32 channel tiles)
 WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
 WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
@@ -317,6 +323,15 @@ class ConvOp:
             self.d_pad = -(-self.d_rows // self.d_bn) * self.d_bn
             self.wd = torch.empty(ops.packed_weight_floats(self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci),
                                   dtype=pdt, device=dev)
+        # pointwise tile, six bf16 products per fp32 product: second packing (three bf16 planes, 16-channel chunks)
+        self.wpp6 = self.wdp6 = None
+        if PW6 and self.f_algo == 3 and self.ci % 16 == 0 and self.co % 16 == 0:
+            if self.co > 32:
+                self.wpp6 = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, 3) // 2,
+                                        dtype=torch.bfloat16, device=dev)
+            if need_dgrad and self.ci > 32:
+                self.wdp6 = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, 3) // 2,
+                                        dtype=torch.bfloat16, device=dev)
         # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T
         self.wp6 = self.wd6 = None
         if WINO6 and not bf16 and self.f_algo == 1 and self.co > 32 and self.ci % 4 == 0:
@@ -376,6 +391,10 @@ class ConvOp:
         pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp, oscale=self.scale)
         if self.wd is not None:
             pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd, oscale=self.scale)
+        if self.wpp6 is not None:
+            ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, planes=3, out=self.wpp6, oscale=self.scale)
+        if self.wdp6 is not None:
+            ops.pack_conv_weights_split(self.w, ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, planes=3, out=self.wdp6, oscale=self.scale)
         if self.wp6 is not None:
             ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, out=self.wp6, oscale=self.scale)
         if self.wd6 is not None:
@@ -415,6 +434,10 @@ class ConvOp:
             ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
                        bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5)
             return out
+        if self.wpp6 is not None and a.shape[3] % 16 == 0 and (b is None or b.shape[3] % 16 == 0):
+            ops.conv2d(a, self.wpp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
+                       bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=3, pw=pw, terms=6)
+            return out
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
                    cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post,
                    algo=self.f_algo, pw=pw)
@@ -445,6 +468,10 @@ class ConvOp:
         if self.wd6 is not None and self.split == 0 and cnt > 32:
             ops.conv2d(g, self.wd6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=5)
+            return out
+        if self.wdp6 is not None and cnt > 32 and g.shape[3] % 16 == 0:
+            ops.conv2d(g, self.wdp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
+                       res=res, mask=mask, slope_mask=slope_mask, algo=3, terms=6)
             return out
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
                    co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo)

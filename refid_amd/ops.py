@@ -173,7 +173,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
            in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0, pw=None,
            terms=0):
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc.  pw: dict of the pointwise tile's
-    EGACA fusions (refid_pw_extras); terms: algo 4's product count (0 / 6, or 3)."""
+    EGACA fusions (refid_pw_extras); terms: algo 4's product count (0 / 6, or 3); algo 3: 0 = fp32 MFMA, 6 = six bf16 products
+    (w_packed from pack_conv_weights_split with kh = kw = 1)."""
     d = ConvDesc()
     d.mfma_terms = terms
     if pw is not None:
@@ -236,7 +237,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     if algo == 4:
         name = "conv_split_kernel<%d>" % (terms or 6)
     if algo == 3:
-        name = "conv_pw_kernel<1, 8>" if cout <= 32 else "conv_pw_kernel<2, 4>"
+        name = "conv_pw_kernel<1, 8>" if cout <= 32 else ("conv_pw_kernel<2, 4, six>" if terms == 6 else "conv_pw_kernel<2, 4>")
     opix = d.n * out.shape[1] * out.shape[2]
     nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + opix * out.shape[3] * (1 + (res is not None) + (mask is not None))
                     + cout * (d.c_a + d.c_b) * taps)

@@ -670,6 +670,58 @@ def test_pointwise_tile(cfg):
         np.testing.assert_allclose(nchw(o2).numpy(), xg.grad[:, Ca:].numpy(), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co
+    (2, 8, 16, 64, 64, 64), (1, 16, 16, 32, 0, 64), (1, 8, 8, 128, 0, 128), (1, 5, 7, 256, 256, 256), (1, 9, 11, 64, 0, 128),
+    (1, 6, 10, 128, 0, 64), (1, 7, 9, 16, 0, 48), (1, 4, 33, 48, 16, 80),
+])
+def test_pointwise_tile_six_products(cfg):
+    """refid_conv2d algo 3 with mfma_terms = 6: the pointwise tile's products as six bf16 MFMAs on exactly split operands
+    (weights: refid_pack_conv_weights_split's 1x1 layout).  Same contract and the same distance from the float64 result as
+    the fp32 MFMA form -- also for operands of magnitude 1e-8 (bf16 has fp32's exponent range)."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    Ci = Ca + Cb
+    for mag in (1.0, 1e-8):
+        x = rnd(N, Ci, H, W, seed=1) * mag
+        w = rnd(Co, Ci, 1, 1, seed=2, scale=1.0 / np.sqrt(Ci))
+        b = rnd(Co, seed=3) * mag
+        r = rnd(N, Co, H, W, seed=4) * mag
+        m = rnd(N, Co, H, W, seed=5)
+        ref = lrelu(lrelu(F.conv2d(x, w, b), 0.2) + r, 0.5) * torch.where(m > 0, 1.0, 0.3)
+        kw_ = dict(kh=1, kw=1, cout=Co, cout_pad=-(-Co // 32) * 32, algo=3, in_b=nhwc(x[:, Ca:]) if Cb else None,
+                   bias=b.float().cuda(), res=nhwc(r), mask=nhwc(m), slope_pre=0.2, slope_post=0.5, slope_mask=0.3)
+        w6 = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_FWD, 32, 1, 1, Co, Ci, planes=3)
+        o6 = torch.empty(N, H, W, Co, device="cuda")
+        ops.conv2d(nhwc(x[:, :Ca]), w6, o6, terms=6, **kw_)
+        wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_FWD, 32, 8, 1, 1, Co, Ci)
+        o32 = torch.empty(N, H, W, Co, device="cuda")
+        ops.conv2d(nhwc(x[:, :Ca]), wp, o32, **kw_)
+        e6 = float((nchw(o6).double() - ref).abs().max()) / mag
+        e32 = float((nchw(o32).double() - ref).abs().max()) / mag
+        assert e6 <= 2.0 * e32 + 2e-7, (mag, e6, e32)
+        assert e6 <= 5e-6, (mag, e6)
+    # input gradient = the same tile on the transposed packing, issued as a row range
+    if Cb > 32:
+        xg = x.clone().requires_grad_(True)
+        g = rnd(N, Co, H, W, seed=6)
+        F.conv2d(xg, w, None).backward(g)
+        wd = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_DGRAD, 32, 1, 1, Co, Ci, planes=3)
+        o2 = torch.empty(N, H, W, Cb, device="cuda")
+        ops.conv2d(nhwc(g), wd, o2, kh=1, kw=1, cout=Cb, cout_pad=-(-Ci // 32) * 32, co_base=Ca, algo=3, terms=6)
+        assert float((nchw(o2).double() - xg.grad[:, Ca:]).abs().max()) <= 5e-6 * max(1.0, float(xg.grad.abs().max()))
+
+
+def test_pointwise_tile_six_products_rejects_odd_chunks():
+    ops = _ops()
+    from refid_amd._lib import RefidHipError
+    x = torch.zeros(1, 4, 4, 24, device="cuda")
+    w6 = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty(1, 4, 4, 64, device="cuda")
+    with pytest.raises(RefidHipError, match="multiples of 16"):
+        ops.conv2d(x, w6, out, kh=1, kw=1, cout=64, cout_pad=64, algo=3, terms=6)
+
+
 @pytest.mark.parametrize("cfg", [(3, 16, 40, 2, 32, 5), (2, 9, 33, 2, 8, 5), (1, 8, 32, 3, 16, 3), (5, 12, 64, 4, 32, 5)])
 def test_thin_input_wgrad(cfg):
     """Event-head style weight gradient: <= 4 (zero padded) input channels, K x K taps packed 8 per MFMA column tile;

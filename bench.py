@@ -351,14 +351,28 @@ def main(argv=None):
             # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
             traffic = None
             import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            suffix = {"fp32": "", "bf16": "_bf16"}.get(args.dtype)
+            pats = [] if suffix is None else sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")),
+                                                    reverse=True)
+            for path in pats:
                 try:
-                    rec = json.load(open(path)).get(name)
+                    table = json.load(open(path))
                 except (OSError, ValueError):
-                    rec = None
+                    continue
+                rec = table.get(name)
                 if rec:
                     traffic = rec["hbm_bytes_per_launch"]
                     break
+                if name.startswith("conv_split_kernel<"):
+                    # the event timing groups the split tile by its product count; rocprof names the template instances
+                    # <MT, NT, planes, KS, mode>: launch-weighted mean over the instances with that many planes
+                    planes = {"1": 1, "3": 2, "6": 3}[name[len("conv_split_kernel<"):-1]]
+                    rows = [v for k, v in table.items() if k.startswith("conv_split_kernel<") and
+                            int(k[len("conv_split_kernel<"):-1].split(",")[2]) == planes]
+                    if rows:
+                        traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) /
+                                      sum(v["launches"] for v in rows))
+                        break
             # Winograd F(2x2,3x3) executes 16/36 of the direct convolution's multiplies on the matrix
             # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
             # the SURVEY 8(d) direct-convolution figure beside it.

@@ -30,6 +30,15 @@ void refid_set_error(const char* fmt, ...);
     } while (0)
 
 __device__ __forceinline__ float lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+// four values at once; `on` is workgroup-uniform (slope != 1): a scalar branch skips the 3 VALU per value of an identity
+// activation (every input-gradient conv, half of the forward convs) -- the tiles are VALU + MFMA issue bound
+__device__ __forceinline__ void lrelu4(f32x4& v, float slope, bool on) {
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], slope);
+        asm volatile("" ::: "memory");                      // (keeps the branch: the compiler would turn it into selects)
+    }
+}
 
 // Deterministic sum over the threads of a wave that share q = lane % LPP (LPP a power of two): fixed xor-shuffle tree;
 // the total ends up in every lane.  (Reductions of parameter gradients never use floating-point atomics: a step's

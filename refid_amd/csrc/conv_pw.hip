@@ -299,14 +299,12 @@ __global__ __launch_bounds__(256, SIX ? 3 : 4) void conv_pw_kernel(const ConvKAr
                 if (pp >= npix || j0 >= a.Cout) continue;
                 f32x4 v = t[px * PITCH + c4];
                 if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + a.coBase + j0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePre);
+                lrelu4(v, a.slopePre, a.slopePre != 1.f);
                 if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pp * a.ldR + j0);
                 if constexpr (EX) {
                     if (e.res2) v += *reinterpret_cast<const f32x4*>(e.res2 + pp * e.ldR2 + j0);
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                lrelu4(v, a.slopePost, a.slopePost != 1.f);
                 if (a.mask) {
                     const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + pp * a.ldM + j0);
 #pragma unroll

@@ -393,12 +393,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+            v += bv;
+            lrelu4(v, a.slopePre, a.slopePre != 1.f);
             if (vec) {
                 if (a.res) v += pres[it];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+                lrelu4(v, a.slopePost, a.slopePost != 1.f);
                 if (a.mask) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] *= (pmask[it][k] > 0.f) ? 1.f : a.slopeMask;

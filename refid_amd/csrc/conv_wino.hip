@@ -330,12 +330,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+        v += bv;
+        lrelu4(v, a.slopePre, a.slopePre != 1.f);
         if (vec) {
             if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+            lrelu4(v, a.slopePost, a.slopePost != 1.f);
             if (a.mask) {
                 const f32x4 mv = pre ? pmask[it] : *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
 #pragma unroll
@@ -368,11 +367,9 @@ __global__ __launch_bounds__(256) void wino_splitk_finish_kernel(const ConvKArgs
         for (int s = 1; s < a.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(ws + s * a.wsStride + op * ldW + j0);
         if (a.vecOK && j0 + 3 < a.Cout) {
             if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + a.coBase + j0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePre);
+            lrelu4(v, a.slopePre, a.slopePre != 1.f);
             if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+            lrelu4(v, a.slopePost, a.slopePost != 1.f);
             if (a.mask) {
                 const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
 #pragma unroll

@@ -319,16 +319,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k] + bv[k], a.slopePre);
+        v += bv;
+        lrelu4(v, a.slopePre, a.slopePre != 1.f);
         if (REFID_WINO6_ABLATE == 4 || REFID_WINO6_ABLATE == 10) {
             if (v[0] == 12345.678f) a.out[op * a.ldO + j0] = v[1];
             continue;
         }
         if (vec) {
             if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = lrelu(v[k], a.slopePost);
+            lrelu4(v, a.slopePost, a.slopePost != 1.f);
             if (a.mask) {
                 const f32x4 mv = pre ? pmask[it] : *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
 #pragma unroll

@@ -271,78 +271,83 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
             xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r0;
             xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r1;
         }
-    constexpr int NIT = (TH * TW * (BN / 4)) / 256;
-    const bool pre = REFID_WINO6_ABLATE != 4 && REFID_WINO6_ABLATE != 10 && a.vecOK && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
+    // ---- fused epilogue, COALESCED: thread -> (output pixel, channel quad) in memory order.  Item it of a thread is pixel
+    // (row it >> 1, column 16 (it & 1) + (tid >> 4)) of the 4 x 32 tile and ALWAYS channel quad tid & 15: the addresses are
+    // one 64-bit base per tensor and thread plus workgroup-uniform steps (a generic (n, oy, ox) -> offset product per item
+    // was 160 quarter-rate integer multiplies per tile -- as much vector-issue time as the K loop at 64 input channels).
+    constexpr int NIT = (TH * TW * (BN / 4)) / 256;        // 8
+    static_assert(BN / 4 == 16 && TW == 32 && NIT == 8, "epilogue item mapping");
+    const int p0 = tid >> 4, c = (tid & 15) * 4;
+    const int j0 = n0 + c;
+    const int nt = c >> 5, rq = (c & 31) >> 3, ckh = (c & 7) >> 2;
+    const long long opb = (long long)(n * a.Ho + oy0) * a.Wo + ox0 + p0;
+    const bool jok = j0 < a.Cout;
+    const bool vec = a.vecOK && (j0 + 3 < a.Cout);
+    const bool cok[2] = {ox0 + p0 < a.Wo, ox0 + 16 + p0 < a.Wo};
+    float* const outB = a.out + (a.ksplit > 1 ? blockIdx.y * a.wsStride : 0) + opb * a.ldO + j0;
+    const float* const resB = a.res ? a.res + opb * a.ldR + j0 : nullptr;
+    const float* const mskB = a.mask ? a.mask + opb * a.ldM + j0 : nullptr;
+    const int stepO[2] = {a.Wo * a.ldO, 16 * a.ldO}, stepR[2] = {a.Wo * a.ldR, 16 * a.ldR}, stepM[2] = {a.Wo * a.ldM, 16 * a.ldM};
+    const bool pre = REFID_WINO6_ABLATE != 4 && REFID_WINO6_ABLATE != 10 && vec && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
     f32x4 pres[NIT], pmask[NIT];
     if (pre) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int f = it * 256 + tid;
-            const int c4 = f % (BN / 4), pr = f / (BN / 4);
-            const int oy = oy0 + pr / TW, ox = ox0 + pr % TW, j0 = n0 + c4 * 4;
-            const bool ok = oy < a.Ho && ox < a.Wo && j0 + 3 < a.Cout;
-            const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+            const bool ok = (oy0 + (it >> 1) < a.Ho) && cok[it & 1];
             pres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             pmask[it] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
-            if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+            if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(resB + (it >> 1) * stepR[0] + (it & 1) * stepR[1]);
+            if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(mskB + (it >> 1) * stepM[0] + (it & 1) * stepM[1]);
         }
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};                        // the same four output channels for all of a thread's items
+    if (a.bias && a.ksplit == 1 && jok) {
+        const float* bp = a.bias + a.coBase + j0;
+        if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
+        else
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
     }
     __syncthreads();
 
-    constexpr int C4 = BN / 4;                              // float4 per pixel
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int f = it * 256 + tid;
-        const int c4 = f % C4, pr = f / C4;
-        const int row = pr / TW, col = pr % TW;
-        const int c = c4 * 4;
-        const int nt = c >> 5, rq = (c & 31) >> 3, ckh = (c & 7) >> 2;
+        const int row = it >> 1, colb = it & 1;
+        const int col = colb * 16 + p0;
         const int oa = row & 1, tile = ((row & 3) >> 1) * 16 + (col >> 1), ob = col & 1;
-        const int oy = oy0 + row, ox = ox0 + col;
-        const int j0 = n0 + c;
-        if (oy >= a.Ho || ox >= a.Wo || j0 >= a.Cout) continue;
+        if (oy0 + row >= a.Ho || !cok[colb] || !jok) continue;
         const f32x4* xp = xch + (((oa * 2 + ob) * 2 + nt) * 4 + rq) * XL + ckh * 33 + tile;   // row i0 = oa
         const float sg = oa ? -1.f : 1.f;                   // a=0: R0+R1+R2 ; a=1: R1-R2-R3
         f32x4 v = xp[0] + (xp[16 * XL] + xp[32 * XL]) * sg;
-        const long long op = (long long)(n * a.Ho + oy) * a.Wo + ox;
+        float* const outp = outB + row * stepO[0] + colb * stepO[1];
         if (a.ksplit > 1) {                                 // raw partial sums; the finishing pass applies the epilogue
-            *reinterpret_cast<f32x4*>(a.out + blockIdx.y * a.wsStride + op * a.ldO + j0) = v;
+            *reinterpret_cast<f32x4*>(outp) = v;
             continue;
-        }
-        const bool vec = a.vecOK && (j0 + 3 < a.Cout);
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-            const float* bp = a.bias + a.coBase + j0;
-            if (vec) bv = *reinterpret_cast<const f32x4*>(bp);
-            else
-#pragma unroll
-                for (int k = 0; k < 4; ++k) if (j0 + k < a.Cout) bv[k] = bp[k];
         }
         v += bv;
         lrelu4(v, a.slopePre, a.slopePre != 1.f);
         if (REFID_WINO6_ABLATE == 4 || REFID_WINO6_ABLATE == 10) {
-            if (v[0] == 12345.678f) a.out[op * a.ldO + j0] = v[1];
+            if (v[0] == 12345.678f) outp[0] = v[1];
             continue;
         }
         if (vec) {
-            if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + j0);
+            if (a.res) v += pre ? pres[it] : *reinterpret_cast<const f32x4*>(resB + row * stepR[0] + colb * stepR[1]);
             lrelu4(v, a.slopePost, a.slopePost != 1.f);
             if (a.mask) {
-                const f32x4 mv = pre ? pmask[it] : *reinterpret_cast<const f32x4*>(a.mask + op * a.ldM + j0);
+                const f32x4 mv = pre ? pmask[it] : *reinterpret_cast<const f32x4*>(mskB + row * stepM[0] + colb * stepM[1]);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
             }
-            *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+            *reinterpret_cast<f32x4*>(outp) = v;
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (j0 + k >= a.Cout) break;
                 float tv = v[k];
-                if (a.res) tv += a.res[op * a.ldR + j0 + k];
+                if (a.res) tv += resB[row * stepR[0] + colb * stepR[1] + k];
                 tv = lrelu(tv, a.slopePost);
-                if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
-                a.out[op * a.ldO + j0 + k] = tv;
+                if (a.mask) tv *= (mskB[row * stepM[0] + colb * stepM[1] + k] > 0.f) ? 1.f : a.slopeMask;
+                outp[k] = tv;
             }
         }
     }

@@ -69,12 +69,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     const int co0 = blockIdx.z * COT, ci0 = blockIdx.y * CIT;
     const int split = blockIdx.x;
 
-    // B^T rows: i=0: d0-d2  i=1: d1+d2  i=2: d2-d1  i=3: d1-d3 ;  A rows: X_b = ca*dY0b + cb*dY1b
-    const int ra = (ti == 0) ? 0 : ((ti == 2) ? 2 : 1);
-    const int rb = (ti == 0) ? 2 : ((ti == 1) ? 2 : ((ti == 2) ? 1 : 3));
-    const float sgn = (ti == 1) ? 1.f : -1.f;
-    const float ca = (ti == 3) ? 0.f : 1.f;
-    const float cb = (ti == 0) ? 0.f : ((ti == 1) ? 1.f : -1.f);
 
     const int gq = tid % G4, xq = tid % X4;
     const int gco = co0 + gq * 4;
@@ -149,79 +143,96 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         }
     };
 
-    int pt = split;
-    if (pt < ntAll) {
-        load_tile(pt);
-        store_tile();
-    }
-    __syncthreads();
-
-    for (; pt < ntAll; pt += a.nsplit) {
-        const bool more = pt + a.nsplit < ntAll;
-        if (more && REFID_WW_ABLATE != 2 && REFID_WW_ABLATE < 3) load_tile(pt + a.nsplit);
-
-        // 16 K steps per K tile, fully unrolled (every LDS address is base + immediate).  A step pairs the two tile
-        // ROWS of one tile column (MFMA K half kh = tile row), so consecutive steps of a lane walk along a row and
-        // the 4-column input window slides by 2: only 2 new columns per row are read per step (12 instead of 16
-        // LDS floats per 8 MFMAs -- LDS bytes and VALU instructions do not hide under MFMAs on gfx950).
-        // The raw operands of step s+1 are fetched before the 8 MFMAs of step s issue.
-        const float* xA = sX + ((2 * kh + ra) * HWD) * CIT + li;     // + (2*s + b) * CIT
-        const float* xB = sX + ((2 * kh + rb) * HWD) * CIT + li;
-        const float* gP = sG + (2 * kh * TW) * COT + li;             // + (2*s) * COT
-        // T_b = d[ra][b] + sgn d[rb][b] for the 34 window columns of this lane's row pair, consumed two per step; the
-        // step loop is fully unrolled, so tw[] / gbuf[] are plain registers (no copies between steps).
-        float tw[4];
-        float gbuf[2][2][4];
-        auto fetch_g = [&](int s, float (&pg)[2][4]) {
-            const int go = (2 * s) * COT;
-#pragma unroll
-            for (int sm = 0; sm < 2; ++sm) {
-                if (REFID_WW_ABLATE == 4) {
-                    pg[sm][0] = pg[sm][1] = pg[sm][2] = pg[sm][3] = __builtin_bit_cast(float, go + sm + (int)threadIdx.x);
-                    continue;
-                }
-                pg[sm][0] = gP[go + sm * 32];            pg[sm][1] = gP[go + sm * 32 + COT];
-                pg[sm][2] = gP[go + sm * 32 + TW * COT]; pg[sm][3] = gP[go + sm * 32 + TW * COT + COT];
-            }
-        };
-#pragma unroll
-        for (int b4 = 0; b4 < 4; ++b4) tw[b4] = xA[b4 * CIT] + sgn * xB[b4 * CIT];
-        fetch_g(0, gbuf[0]);
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float n2 = 0.f, n3 = 0.f;
-            if (s + 1 < 16) {
-                fetch_g(s + 1, gbuf[(s + 1) & 1]);
-                if (REFID_WW_ABLATE == 4) {
-                    n2 = tw[0] + sgn * tw[1]; n3 = tw[1] + sgn * tw[0];
-                } else {
-                    n2 = xA[(2 * s + 4) * CIT] + sgn * xB[(2 * s + 4) * CIT];
-                    n3 = xA[(2 * s + 5) * CIT] + sgn * xB[(2 * s + 5) * CIT];
-                }
-            }
-            const float (&cg)[2][4] = gbuf[s & 1];
-            // column transform; the 4th operand carries the sign of Z's 4th column (z3 = -x1), so Z needs no negation
-            const float v[4] = {tw[0] - tw[2], tw[1] + tw[2], tw[2] - tw[1], tw[3] - tw[1]};
-            // Z row ti:  X_b = ca dY[0][b] + cb dY[1][b];  z = {x0, x0 + x1, x0 - x1, (-)x1}
-            float z[2][4];
-#pragma unroll
-            for (int sm = 0; sm < 2; ++sm) {
-                const float x0 = ca * cg[sm][0] + cb * cg[sm][2];
-                const float x1 = ca * cg[sm][1] + cb * cg[sm][3];
-                z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = x1;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int sm = 0; sm < 2; ++sm)
-                    acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
-            tw[0] = tw[2]; tw[1] = tw[3]; tw[2] = n2; tw[3] = n3;
-        }
-        if (REFID_WW_ABLATE < 3) __syncthreads();
-        if (more && REFID_WW_ABLATE != 1 && REFID_WW_ABLATE < 3) {
+    // The K loop exists four times, one per transform row (wave-uniform switch): with the row's coefficients as compile-time
+    // constants the Z transform costs 0-2 instead of 4 VALU per column tile and step, rows 0 and 3 read only the gradient
+    // row they use (8 instead of 12 LDS reads per step), and row 3's minus sign moves into the V window (d3 - d1).
+    //   B^T rows: i=0: d0-d2  i=1: d1+d2  i=2: d2-d1  i=3: d1-d3 ;  A rows: X_b = ca dY[0][b] + cb dY[1][b],
+    //   (ca, cb) = (1,0) (1,1) (1,-1) (0,-1)
+    auto kloop = [&](auto TI) {
+        constexpr int I = decltype(TI)::value;
+        constexpr int ra = (I == 0) ? 0 : ((I == 2) ? 2 : 1);
+        constexpr int rb = (I == 0) ? 2 : ((I == 1) ? 2 : ((I == 2) ? 1 : 3));
+        auto comb = [](float pa, float pb) { return I == 1 ? pa + pb : (I == 3 ? pb - pa : pa - pb); };   // window row pair
+        int pt = split;
+        if (pt < ntAll) {
+            load_tile(pt);
             store_tile();
-            __syncthreads();
         }
+        __syncthreads();
+
+        for (; pt < ntAll; pt += a.nsplit) {
+            const bool more = pt + a.nsplit < ntAll;
+            if (more && REFID_WW_ABLATE != 2 && REFID_WW_ABLATE < 3) load_tile(pt + a.nsplit);
+
+            // 16 K steps per K tile, fully unrolled (every LDS address is base + immediate).  A step pairs the two tile
+            // ROWS of one tile column (MFMA K half kh = tile row), so consecutive steps of a lane walk along a row and
+            // the 4-column input window slides by 2: only 2 new columns per row are read per step (12 instead of 16
+            // LDS floats per 8 MFMAs -- LDS bytes and VALU instructions do not hide under MFMAs on gfx950).
+            // The raw operands of step s+1 are fetched before the 8 MFMAs of step s issue.
+            const float* xA = sX + ((2 * kh + ra) * HWD) * CIT + li;     // + (2*s + b) * CIT
+            const float* xB = sX + ((2 * kh + rb) * HWD) * CIT + li;
+            const float* gP = sG + (2 * kh * TW) * COT + li;             // + (2*s) * COT
+            // T_b = d[ra][b] +- d[rb][b] for the 34 window columns of this lane's row pair, consumed two per step; the
+            // step loop is fully unrolled, so tw[] / gbuf[] are plain registers (no copies between steps).
+            float tw[4];
+            float gbuf[2][2][4];
+            auto fetch_g = [&](int s, float (&pg)[2][4]) {
+                const int go = (2 * s) * COT;
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm) {
+                    if (REFID_WW_ABLATE == 4) {
+                        pg[sm][0] = pg[sm][1] = pg[sm][2] = pg[sm][3] = __builtin_bit_cast(float, go + sm + (int)threadIdx.x);
+                        continue;
+                    }
+                    if (I != 3) { pg[sm][0] = gP[go + sm * 32]; pg[sm][1] = gP[go + sm * 32 + COT]; }
+                    if (I != 0) { pg[sm][2] = gP[go + sm * 32 + TW * COT]; pg[sm][3] = gP[go + sm * 32 + TW * COT + COT]; }
+                }
+            };
+#pragma unroll
+            for (int b4 = 0; b4 < 4; ++b4) tw[b4] = comb(xA[b4 * CIT], xB[b4 * CIT]);
+            fetch_g(0, gbuf[0]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float n2 = 0.f, n3 = 0.f;
+                if (s + 1 < 16) {
+                    fetch_g(s + 1, gbuf[(s + 1) & 1]);
+                    if (REFID_WW_ABLATE == 4) {
+                        n2 = tw[0] - tw[1]; n3 = tw[1] - tw[0];
+                    } else {
+                        n2 = comb(xA[(2 * s + 4) * CIT], xB[(2 * s + 4) * CIT]);
+                        n3 = comb(xA[(2 * s + 5) * CIT], xB[(2 * s + 5) * CIT]);
+                    }
+                }
+                const float (&cg)[2][4] = gbuf[s & 1];
+                // column transform; the 4th operand carries the sign of Z's 4th column (z3 = -x1), so Z needs no negation
+                const float v[4] = {tw[0] - tw[2], tw[1] + tw[2], tw[2] - tw[1], tw[3] - tw[1]};
+                // Z row I:  X_b = ca dY[0][b] + cb dY[1][b] (row 3: +dY[1][b], its sign sits in the window);  z = {x0, x0 + x1, x0 - x1, (-)x1}
+                float z[2][4];
+#pragma unroll
+                for (int sm = 0; sm < 2; ++sm) {
+                    const float x0 = I == 0 ? cg[sm][0] : (I == 1 ? cg[sm][0] + cg[sm][2] : (I == 2 ? cg[sm][0] - cg[sm][2] : cg[sm][2]));
+                    const float x1 = I == 0 ? cg[sm][1] : (I == 1 ? cg[sm][1] + cg[sm][3] : (I == 2 ? cg[sm][1] - cg[sm][3] : cg[sm][3]));
+                    z[sm][0] = x0; z[sm][1] = x0 + x1; z[sm][2] = x0 - x1; z[sm][3] = x1;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int sm = 0; sm < 2; ++sm)
+                        acc[j][sm] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j], z[sm][j], acc[j][sm], 0, 0, 0);
+                tw[0] = tw[2]; tw[1] = tw[3]; tw[2] = n2; tw[3] = n3;
+            }
+            if (REFID_WW_ABLATE < 3) __syncthreads();
+            if (more && REFID_WW_ABLATE != 1 && REFID_WW_ABLATE < 3) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    };
+    switch (__builtin_amdgcn_readfirstlane(ti)) {
+        case 0: kloop(std::integral_constant<int, 0>{}); break;
+        case 1: kloop(std::integral_constant<int, 1>{}); break;
+        case 2: kloop(std::integral_constant<int, 2>{}); break;
+        default: kloop(std::integral_constant<int, 3>{}); break;
     }
 
     // ---- slab: [split][xi][co][ci]; D[ci][co]: lane li = output channel, register quad = 4 ci ------

@@ -363,6 +363,10 @@ def main(argv=None):
                 if rec:
                     traffic = rec["hbm_bytes_per_launch"]
                     break
+                inst = [v for k, v in table.items() if k.startswith(name + "<")]      # template instances of the same kernel
+                if inst and not name.startswith("conv_split_kernel<"):
+                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
+                    break
                 if name.startswith("conv_split_kernel<"):
                     # the event timing groups the split tile by its product count; rocprof names the template instances
                     # <MT, NT, planes, KS, mode>: launch-weighted mean over the instances with that many planes

@@ -270,6 +270,16 @@ int refid_pack_conv_weights_split(const float* w, const float* oscale, void* pac
 size_t refid_packed_weight_wino6_bytes(int role, int o, int i, int bn);
 int refid_pack_conv_weights_wino6(const float* w, const float* oscale, void* packed, int role, int o, int i, int bn,
                                   void* stream);
+/* All packings of a model in ONE launch.  The caller builds a table of refid_pack_entry_bytes()-sized records in host
+ * memory with refid_pack_entry_fill (kind 0: refid_pack_conv_weights[_scaled / _bf16] -- `planes` = 1 selects bf16 output;
+ * 1: refid_pack_conv_weights_split, 3x3 / 4x4; 2: the same, 1x1; 3: refid_pack_conv_weights_wino6; 4: dst[e] = w[e] *
+ * oscale[e] for e < o (refid_mul_vec)), copies it to device memory once, and calls refid_pack_batch whenever the weights have
+ * changed.  `blk0` = the sum of the values returned for the records before this one (each call returns its record's
+ * workgroup count, -1 on error); nblocks = the sum over all records.  Same bits as the one-by-one calls. */
+size_t refid_pack_entry_bytes(void);
+int refid_pack_entry_fill(void* entry_host, int kind, const float* w, const float* oscale, void* dst, int role, int o, int i,
+                          int kh, int kw, int kc, int bn, int planes, int blk0);
+int refid_pack_batch(const void* table_dev, int n, int nblocks, void* stream);
 int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
 /* After BPTT, turn the gradient of the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r]) of THIS backward pass
  * (gw_folded, gb_folded: private buffers, zero before BPTT) into gradients of (W, b, scale) and ACCUMULATE them:

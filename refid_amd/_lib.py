@@ -121,6 +121,10 @@ def _bind_extra(L):
     L.refid_packed_weight_wino6_bytes.restype = C.c_size_t
     L.refid_pack_conv_weights_wino6.argtypes = [vp, vp, vp] + [i] * 4 + [vp]
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
+    L.refid_pack_entry_bytes.restype = C.c_size_t
+    L.refid_pack_entry_bytes.argtypes = []
+    L.refid_pack_entry_fill.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, i, i, i, i]
+    L.refid_pack_batch.argtypes = [vp, i, i, vp]
     L.refid_fold_back.argtypes = [vp] * 8 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
     L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, vp, ll, i, f, vp]

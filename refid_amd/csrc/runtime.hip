@@ -1,6 +1,7 @@
 // Error plumbing, device queries, layout conversion, weight packing and small
 // elementwise kernels of the REFID C ABI.
 #include "common.h"
+#include <cstring>
 
 static thread_local char g_err[512] = "";
 
@@ -152,33 +153,34 @@ __device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap,
     return 0.f;
 }
 
+__device__ __forceinline__ void pack_elem(const PackArgs& p, long long e) {
+    long long r = e;
+    const int kk = r % p.KC; r /= p.KC;
+    const int row = r % p.rowsPad; r /= p.rowsPad;
+    const int tap = r % p.ntaps; r /= p.ntaps;
+    const int chunk = r % p.nchunks;
+    const int cls = r / p.nchunks;
+    const int k = chunk * p.KC + kk;
+    float v = 0.f;
+    if (row < p.rows && k < p.K) v = pack_fetch(p, cls, tap, row, k);
+    if (p.bf16) reinterpret_cast<__bf16*>(p.dst)[e] = (__bf16)v;
+    else p.dst[e] = v;
+}
+
 __global__ __launch_bounds__(256) void pack_kernel(const PackArgs p) {
     const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        long long r = e;
-        const int kk = r % p.KC; r /= p.KC;
-        const int row = r % p.rowsPad; r /= p.rowsPad;
-        const int tap = r % p.ntaps; r /= p.ntaps;
-        const int chunk = r % p.nchunks;
-        const int cls = r / p.nchunks;
-        const int k = chunk * p.KC + kk;
-        float v = 0.f;
-        if (row < p.rows && k < p.K) v = pack_fetch(p, cls, tap, row, k);
-        if (p.bf16) reinterpret_cast<__bf16*>(p.dst)[e] = (__bf16)v;
-        else p.dst[e] = v;
-    }
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_elem(p, e);
 }
 
 // split-bf16 planes for conv_split.hip (8-channel sub-chunks, `planes` bf16 numbers per weight):
 //   mode 0 (3x3 s1):        [chunk8][plane][tap 0..9][rowsPad][8]            the tenth tap is zero (tap pairs fill K = 16)
 //   mode 1 (4x4 s2 forward): [chunk8][sy][sx][plane][tap (ty,tx)][rowsPad][8]  = W[row][k][2ty+sy][2tx+sx]  (2x2 input blocks)
 //   mode 2 (its dgrad):      [class][chunk8][plane][tap (ta,tb)][rowsPad][8]   (REFID_ROLE_DOWN_DGRAD's classes / taps)
-__global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes, int mode) {
+__device__ __forceinline__ void pack_split_elem(const PackArgs& p, int planes, int mode, long long e) {
     const int ntp = mode == 0 ? p.ntaps + 1 : 4;
     const int nsub = mode == 1 ? 4 : 1;
-    const long long total = (long long)p.ncls * p.nchunks * nsub * planes * ntp * p.rowsPad * 8;
     __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    {
         long long r = e;
         const int k8 = r % 8; r /= 8;
         const int row = r % p.rowsPad; r /= p.rowsPad;
@@ -202,13 +204,16 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int p
     }
 }
 
+__global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes, int mode) {
+    const long long total = (long long)p.ncls * p.nchunks * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? p.ntaps + 1 : 4) * p.rowsPad * 8;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_split_elem(p, planes, mode, e);
+}
+
 // 1x1 (conv_pw.hip, six products): [chunk16][plane][rowsPad][16]; the 16 channels of a row are stored as the two MFMA K
 // halves of the pointwise tile's lanes: slot 8h + t = channel 4h + t (t < 4) or 8 + 4h + (t - 4)
-__global__ __launch_bounds__(256) void pack_pw6_kernel(const PackArgs p, int planes) {
-    const int nc16 = (p.K + 15) / 16;
-    const long long total = (long long)nc16 * planes * p.rowsPad * 16;
+__device__ __forceinline__ void pack_pw6_elem(const PackArgs& p, int planes, long long e) {
     __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    {
         long long r = e;
         const int slot = r % 16; r /= 16;
         const int row = r % p.rowsPad; r /= p.rowsPad;
@@ -226,11 +231,15 @@ __global__ __launch_bounds__(256) void pack_pw6_kernel(const PackArgs p, int pla
     }
 }
 
+__global__ __launch_bounds__(256) void pack_pw6_kernel(const PackArgs p, int planes) {
+    const long long total = (long long)((p.K + 15) / 16) * planes * p.rowsPad * 16;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_pw6_elem(p, planes, e);
+}
+
 // Winograd-domain weights U = G g G^T as three bf16 planes for conv_wino6.hip: [chunk16][xi][plane][rowsPad][16]
-__global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
-    const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+__device__ __forceinline__ void pack_wino6_elem(const PackArgs& p, long long e) {
     __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    {
         long long r = e;
         const int k16 = r % 16; r /= 16;
         const int row = r % p.rowsPad; r /= p.rowsPad;
@@ -245,6 +254,42 @@ __global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
         const __bf16 m = (__bf16)r1;
         const __bf16 l = (__bf16)(r1 - (float)m);
         dst[e] = plane == 0 ? h : (plane == 1 ? m : l);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
+    const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_wino6_elem(p, e);
+}
+
+// ---- all packings of a model in ONE launch (refid_pack_batch): the table lives in device memory, a workgroup finds its
+// entry by binary search over the entries' first block.  ~220 dependent 6-20 us launches per optimiser step become one.
+struct PackEntry {
+    PackArgs p;
+    int kind;                  // 0 pack_kernel (fp32 / bf16), 1 split (modes 0-2), 2 1x1 split, 3 Winograd x six, 4 out = a * b (vectors)
+    int planes, mode;
+    int blk0, nblk;            // this entry's workgroups: [blk0, blk0 + nblk)
+    long long total;           // elements
+};
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                       // last entry with blk0 <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackEntry& en = table[lo];
+    const PackArgs p = en.p;
+    const int kind = en.kind, planes = en.planes, mode = en.mode;
+    const long long total = en.total, stride = (long long)en.nblk * 256;
+    for (long long e = (long long)(blockIdx.x - en.blk0) * 256 + threadIdx.x; e < total; e += stride) {
+        switch (kind) {
+            case 0: pack_elem(p, e); break;
+            case 1: pack_split_elem(p, planes, mode, e); break;
+            case 2: pack_pw6_elem(p, planes, e); break;
+            case 3: pack_wino6_elem(p, e); break;
+            default: p.dst[e] = p.w[e] * p.oscale[e]; break;
+        }
     }
 }
 
@@ -355,6 +400,54 @@ extern "C" int refid_pack_conv_weights_wino6(const float* w, const float* oscale
     const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
     hipLaunchKernelGGL(pack_wino6_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
     REFID_LAUNCH_CHECK("pack_conv_weights_wino6");
+    return 0;
+}
+
+// ---- batched packing ------------------------------------------------------------------------------------------------
+extern "C" size_t refid_pack_entry_bytes(void) { return sizeof(PackEntry); }
+
+extern "C" int refid_pack_entry_fill(void* entry_host, int kind, const float* w, const float* oscale, void* dst, int role, int o,
+                                     int i, int kh, int kw, int kc, int bn, int planes, int blk0) {
+    REFID_CHECK(entry_host && w && dst, "pack_entry_fill: null pointer");
+    PackEntry en;
+    memset(&en, 0, sizeof(en));
+    en.kind = kind; en.planes = planes; en.mode = 0; en.blk0 = blk0;
+    PackArgs& p = en.p;
+    if (kind == 4) {                                        // out[e] = w[e] * oscale[e], e < o
+        REFID_CHECK(oscale != nullptr && o > 0, "pack_entry_fill: the vector product needs both factors");
+        p.w = w; p.oscale = oscale; p.dst = reinterpret_cast<float*>(dst);
+        en.total = o;
+    } else if (kind == 0) {
+        REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        p.bf16 = planes;                                    // (kind 0: `planes` = 1 selects bf16 output)
+        en.total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
+    } else if (kind == 1 || kind == 2) {
+        const int mode = split_pack_mode(role, kh, kw);
+        REFID_CHECK(mode >= 0 && (kind == 2) == (mode == 3) && planes >= 1 && planes <= 3, "pack_entry_fill: bad split geometry");
+        REFID_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        p.bf16 = 1;
+        en.mode = mode;
+        en.total = split_pack_elems(p, planes, mode);
+    } else if (kind == 3) {
+        REFID_CHECK((role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD) && kh == 3 && kw == 3, "pack_entry_fill: Winograd roles, 3x3");
+        REFID_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        p.bf16 = 1;
+        en.total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+    } else {
+        REFID_CHECK(false, "pack_entry_fill: unknown kind %d", kind);
+    }
+    if (kind != 4) { p.w = w; p.dst = reinterpret_cast<float*>(dst); p.oscale = oscale; }
+    long long nb = (en.total + 255) / 256;
+    en.nblk = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
+    memcpy(entry_host, &en, sizeof(en));
+    return en.nblk;
+}
+
+extern "C" int refid_pack_batch(const void* table_dev, int n, int nblocks, void* stream) {
+    REFID_CHECK(table_dev != nullptr && n > 0 && nblocks > 0, "pack_batch: empty table");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackEntry*>(table_dev), n);
+    REFID_LAUNCH_CHECK("pack_batch");
     return 0;
 }
 

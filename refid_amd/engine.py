@@ -151,6 +151,7 @@ EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
 # weight-gradient side stream: the same wavefront over BPTT measured SLOWER (B=1 120 ms, B=8 544 ms: the weight-gradient
 # stream then has to wait for every chain).  REFID_PIPELINE=0: one chain.
 PIPELINE = os.environ.get("REFID_PIPELINE", "1") != "0"
+PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
 
 
 class _SideStreams:
@@ -384,6 +385,28 @@ class ConvOp:
         # backward -- the image branch, every EvhinetEngine op -- must not wait for finish_wgrad); Engine sets
         # min(WGRAD_GROUP, T) on the convs the T recurrent steps share (Engine._set_wgrad_groups)
         self.w_group = 1
+
+    def plan_repack(self, plan):
+        """The same packings as repack(), as entries of an ops.PackPlan (one launch for the whole model)."""
+        k = self.k
+        plan.add_pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, self.wp, oscale=self.scale, bf16=self.bf16)
+        if self.wd is not None:
+            plan.add_pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, self.wd, oscale=self.scale, bf16=self.bf16)
+        if self.wpp6 is not None:
+            plan.add_split(self.w, ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, 3, self.wpp6, oscale=self.scale)
+        if self.wdp6 is not None:
+            plan.add_split(self.w, ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, 3, self.wdp6, oscale=self.scale)
+        if self.wp6 is not None:
+            plan.add_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, self.wp6, oscale=self.scale)
+        if self.wd6 is not None:
+            plan.add_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, self.wd6, oscale=self.scale)
+        if self.wps is not None:
+            plan.add_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, self.s_planes, self.wps, oscale=self.scale)
+        if self.wds is not None:
+            plan.add_split(self.w, ops.ROLE_DOWN_DGRAD if self.kind == "down" else ops.ROLE_DGRAD, self.sd_bn, k, k, self.co,
+                           self.ci, self.s_planes, self.wds, oscale=self.scale)
+        if self.scale is not None and self.has_bias:
+            plan.add_mul_vec(self.b, self.scale, self.b_eff)
 
     def repack(self):
         k = self.k
@@ -674,6 +697,7 @@ class Engine:
             self.early_ops += [d["t2"]] + d["trunk"].ops()
         self.packed_version = -1
         self.param_version = 0
+        self._pack_plan = None
         self.ctx = None
         self._bind_fold_scratch()
         # convs whose weights the T (or 2T) recurrent steps share: their weight gradients may wait for a group of steps
@@ -703,10 +727,20 @@ class Engine:
         self.param_version += 1
 
     def repack(self):
+        """Packed copies of the weights, once per optimiser step: ONE launch for all ~220 packings (ops.PackPlan; built on
+        first use -- the parameter arena and the packed buffers never move).  REFID_PACK_BATCH=0: one launch per packing."""
         if self.packed_version == self.param_version:
             return
-        for o in self.all_ops:
-            o.repack()
+        if PACK_BATCH:
+            if self._pack_plan is None:
+                plan = ops.PackPlan(self.all_ops[0].w.device)
+                for o in self.all_ops:
+                    o.plan_repack(plan)
+                self._pack_plan = plan.build()
+            self._pack_plan.run()
+        else:
+            for o in self.all_ops:
+                o.repack()
         self.packed_version = self.param_version
 
     # -------------------------------------------------------------------------------------------

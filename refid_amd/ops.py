@@ -543,6 +543,59 @@ def colsum(g, db):
     check(lib().refid_colsum(pg, ld, _c(db, "db"), parts.data_ptr(), npix, g.shape[3], _stream()), "refid_colsum")
 
 
+class PackPlan:
+    """All weight packings of a model as ONE launch (refid_pack_batch).  add_* mirror pack_conv_weights[_bf16 / _split /
+    _wino6] and mul_vec with preallocated outputs; the tensors must stay alive and in place (parameter arena, packed
+    buffers).  run() after every optimiser step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.esz = lib().refid_pack_entry_bytes()
+        self.items = []
+        self.keep = []
+        self.table = None
+        self.nblocks = 0
+
+    def _add(self, kind, w, oscale, dst, role=0, o=0, i=0, kh=1, kw=1, kc=8, bn=32, planes=0):
+        if self.table is not None:
+            raise _lib.RefidHipError("PackPlan: already built")
+        for t in (w, oscale, dst):
+            if t is not None and not t.is_contiguous():
+                raise _lib.RefidHipError("PackPlan: tensors must be contiguous")
+        self.items.append((kind, w, oscale, dst, role, o, i, kh, kw, kc, bn, planes))
+        self.keep += [w, oscale, dst]
+
+    def add_pack(self, w, role, bn, kc, kh, kw, o, i, out, oscale=None, bf16=False):
+        self._add(0, w, oscale, out, role, o, i, kh, kw, kc, bn, 1 if bf16 else 0)
+
+    def add_split(self, w, role, bn, kh, kw, o, i, planes, out, oscale=None):
+        self._add(2 if kh == 1 and kw == 1 else 1, w, oscale, out, role, o, i, kh, kw, 8, bn, planes)
+
+    def add_wino6(self, w, role, o, i, out, oscale=None):
+        self._add(3, w, oscale, out, role, o, i, 3, 3, 16, 64, 3)
+
+    def add_mul_vec(self, a, b, out):
+        self._add(4, a, b, out, o=a.numel())
+
+    def build(self):
+        L = lib()
+        buf = (C.c_char * (self.esz * len(self.items)))()
+        blk = 0
+        for n, (kind, w, oscale, dst, role, o, i, kh, kw, kc, bn, planes) in enumerate(self.items):
+            nb = L.refid_pack_entry_fill(C.addressof(buf) + n * self.esz, kind, w.data_ptr(),
+                                         oscale.data_ptr() if oscale is not None else None, dst.data_ptr(), role, o, i, kh, kw,
+                                         kc, bn, planes, blk)
+            if nb <= 0:
+                raise _lib.RefidHipError("refid_pack_entry_fill: " + L.refid_last_error().decode())
+            blk += nb
+        self.nblocks = blk
+        self.table = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(self.device)
+        return self
+
+    def run(self):
+        check(lib().refid_pack_batch(self.table.data_ptr(), len(self.items), self.nblocks, _stream()), "refid_pack_batch")
+
+
 def mul_vec(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)

@@ -277,3 +277,46 @@ def test_parameter_hooks_fire_and_grads_do_not_alias_the_arena(golden_dir):
     net.zero_grad(set_to_none=True)
     net(x=x.cuda(), event=ev.cuda()).mean().backward()
     assert [k for k, p in net.named_parameters() if p.grad is not None] == ["pred.conv2d.weight"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "bf16x3"])
+def test_batched_weight_packing_equals_the_one_by_one_calls(dtype):
+    """Engine.repack(): every packed copy of the weights (direct / Winograd / Winograd x six / split planes / folded biases) written
+    by ONE launch (refid_pack_batch) is bit-identical to the per-packing calls."""
+    import torch
+    from refid_amd import engine as E
+    from refid_amd.archs.final_bidirection_attenfusion_arch import FinalBidirectionAttenfusion
+    torch.manual_seed(3)
+    net = FinalBidirectionAttenfusion(img_chn=6, ev_chn=2, out_chn=3, num_encoders=3, base_num_channels=16, num_block=1,
+                                      num_residual_blocks=2, compute_dtype=dtype).cuda()
+    eng = net.engine
+    names = ("wp", "wd", "wpp6", "wdp6", "wp6", "wd6", "wps", "wds", "b_eff")
+
+    def snapshot():
+        out = []
+        for o in eng.all_ops:
+            for nm in names:
+                t = getattr(o, nm, None)
+                if t is not None and t is not o.b:
+                    out.append(t.clone())
+        return out
+
+    old = E.PACK_BATCH
+    try:
+        E.PACK_BATCH = True
+        eng.mark_params_changed(); eng.repack()
+        a = snapshot()
+        for o in eng.all_ops:                       # poison, then the one-by-one path
+            for nm in names:
+                t = getattr(o, nm, None)
+                if t is not None and t is not o.b:
+                    t.view(torch.uint8).fill_(0x5a)
+        E.PACK_BATCH = False
+        eng.mark_params_changed(); eng.repack()
+        b = snapshot()
+    finally:
+        E.PACK_BATCH = old
+    assert len(a) == len(b) and len(a) > 100
+    for x, y in zip(a, b):
+        assert torch.equal(x.view(torch.uint8), y.view(torch.uint8))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 5
+#define REFID_ABI_VERSION 6
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -275,8 +275,12 @@ int refid_pack_conv_weights_wino6(const float* w, const float* oscale, void* pac
  * 1: refid_pack_conv_weights_split, 3x3 / 4x4; 2: the same, 1x1; 3: refid_pack_conv_weights_wino6; 4: dst[e] = w[e] *
  * oscale[e] for e < o (refid_mul_vec)), copies it to device memory once, and calls refid_pack_batch whenever the weights have
  * changed.  `blk0` = the sum of the values returned for the records before this one (each call returns its record's
- * workgroup count, -1 on error); nblocks = the sum over all records.  Same bits as the one-by-one calls. */
+ * workgroup count >= 1, -1 on error -- the same argument checks as the one-by-one entry points); nblocks = the sum over
+ * all records.  refid_pack_table_check walks a finished HOST table (every record filled, first blocks consecutive from 0:
+ * the kernel finds a workgroup's record by binary search over them) and returns that sum, -1 on error.  Same bits as the
+ * one-by-one calls. */
 size_t refid_pack_entry_bytes(void);
+int refid_pack_table_check(const void* table_host, int n);
 int refid_pack_entry_fill(void* entry_host, int kind, const float* w, const float* oscale, void* dst, int role, int o, int i,
                           int kh, int kw, int kc, int bn, int planes, int blk0);
 int refid_pack_batch(const void* table_dev, int n, int nblocks, void* stream);
@@ -290,7 +294,8 @@ int refid_fold_back(const float* w, const float* b, const float* scale, const fl
 
 /* ------------------------------------------------------------------------------------
  * EGACA non-GEMM pieces (fusion_modules.py:290-333) and LayerNorm2d (fusion_modules.py:97-134).
- * c in {16,32,64,128}.  Parameter gradients ACCUMULATE (atomics) into dw/db.
+ * c in {16,32,64,128}.  Parameter gradients ACCUMULATE into dw/db (deterministic: per-workgroup partial rows in the
+ * caller's scratch, finished in index order -- no floating-point atomics).
  * ---------------------------------------------------------------------------------- */
 int refid_layernorm2d_fwd(const float* x, int ld_x, const float* w, const float* b, float* out,
                           int ld_out, long long npix, int c, float eps, void* stream);
@@ -364,13 +369,20 @@ int refid_colsum(const float* g, int ld_g, float* db, float* parts, long long np
 /* ------------------------------------------------------------------------------------
  * Train-step tail (twoImage_event_recurrent_model.py:273-310; losses/losses.py:28-30,143-173).
  * ---------------------------------------------------------------------------------- */
-/* *loss_sum = sum sqrt((pred-gt)^2+eps); grad = (pred-gt)/sqrt(.)*grad_scale (grad may be NULL) */
-int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, long long count,
+/* Every scalar reduction of this section and of the validation tail below is TWO-STAGE and deterministic (no floating-point
+ * atomics: a logged loss / PSNR / SSIM does not depend on workgroup arrival order): per-workgroup partial sums go to the
+ * caller's `parts` scratch (refid_*_parts(...) doubles), a second launch adds them in index order. */
+/* *loss_sum = sum sqrt((pred-gt)^2+eps); grad = (pred-gt)/sqrt(.)*grad_scale (grad may be NULL);
+ * parts: refid_charbonnier_parts(count) doubles. */
+int refid_charbonnier_parts(long long count);
+int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, double* parts, long long count,
                       float eps, float grad_scale, void* stream);
 /* PSNRLoss (losses.py:95-120, toY = False; image_event_restoration_model.py uses it for the HINet network):
  * *loss = weight * 10/ln10 * mean_b log(mse_b + 1e-8), mse_b over the per_sample elements of sample b;
- * grad (may be NULL) = d loss / d pred; sq = scratch of n_samples doubles. */
-int refid_psnr_loss(const float* pred, const float* gt, float* grad, double* sq, double* loss, int n_samples,
+ * grad (may be NULL) = d loss / d pred; sq = n_samples doubles (receives the per-sample squared errors);
+ * parts: refid_psnr_loss_parts(n_samples, per_sample) doubles. */
+int refid_psnr_loss_parts(int n_samples, long long per_sample);
+int refid_psnr_loss(const float* pred, const float* gt, float* grad, double* sq, double* loss, double* parts, int n_samples,
                     long long per_sample, float weight, void* stream);
 /* out[0] = sum g^2 (deterministic two-stage reduction: replicas of a data-parallel job must agree bit for
  * bit); `out` must hold REFID_SQNORM_WORDS doubles (out[1..] is scratch). */
@@ -422,13 +434,17 @@ int refid_events_to_voxel(const double* ts, const int* xs, const int* ys, const 
                           int num_bins, int width, int height, double first_stamp, double last_stamp,
                           float* voxel, void* stream);
 /* tensor2img quantisation (utils/img_util.py:90-117: clamp [0,1], x255, round) fused with the squared
- * error of calculate_psnr (metrics/psnr_ssim.py:48-63): sq[f] = sum (q(a)-q(b))^2 per frame, float64. */
-int refid_sqerr_u8(const float* a, const float* b, int n_frames, long long frame_elems, double* sq,
+ * error of calculate_psnr (metrics/psnr_ssim.py:48-63): sq[f] = sum (q(a)-q(b))^2 per frame, float64;
+ * parts: refid_sqerr_u8_parts(...) doubles (refid_ssim3d_u8: refid_ssim3d_u8_parts(...)). */
+int refid_sqerr_u8_parts(int n_frames, long long frame_elems);
+int refid_sqerr_u8(const float* a, const float* b, int n_frames, long long frame_elems, double* sq, double* parts,
                    void* stream);
 /* calculate_ssim -> _ssim_3d (metrics/psnr_ssim.py:135-182,225-303): separable 11^3 Gaussian (sigma 1.5,
  * replicate padding) over (H, W, C=3) of the uint8-quantised frames, fp32; sum_out[f] = sum of the ssim
  * map of frame f (divide by 3*h*w for the mean).  a, b: (n_frames, 3, h, w) in [0,1]. */
-int refid_ssim3d_u8(const float* a, const float* b, int n_frames, int h, int w, double* sum_out, void* stream);
+int refid_ssim3d_u8_parts(int n_frames, int h, int w);
+int refid_ssim3d_u8(const float* a, const float* b, int n_frames, int h, int w, double* sum_out, double* parts,
+                    void* stream);
 /* grids_inverse (twoImage_event_recurrent_model.py:252-268): acc[:, i0:i0+th, j0:j0+tw] += tile,
  * cnt += 1; then acc /= cnt. */
 int refid_tile_add(const float* tile, float* acc, float* cnt, int c, int th, int tw, int h, int w, int i0, int j0,

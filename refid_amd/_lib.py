@@ -66,7 +66,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 5          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 6          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 
@@ -125,6 +125,7 @@ def _bind_extra(L):
     L.refid_pack_entry_bytes.argtypes = []
     L.refid_pack_entry_fill.argtypes = [vp, i, vp, vp, vp, i, i, i, i, i, i, i, i, i]
     L.refid_pack_batch.argtypes = [vp, i, i, vp]
+    L.refid_pack_table_check.argtypes = [vp, i]
     L.refid_fold_back.argtypes = [vp] * 8 + [i, i, vp]
     L.refid_layernorm2d_fwd.argtypes = [vp, i, vp, vp, vp, i, ll, i, f, vp]
     L.refid_layernorm2d_bwd.argtypes = [vp, i, vp, i, vp, vp, i, vp, i, vp, vp, vp, ll, i, f, vp]
@@ -143,15 +144,19 @@ def _bind_extra(L):
     L.refid_gelu_fwd.argtypes = [vp, vp, ll, vp]
     L.refid_gelu_bwd.argtypes = [vp, vp, vp, ll, vp]
     L.refid_colsum.argtypes = [vp, i, vp, vp, ll, i, vp]
-    L.refid_charbonnier.argtypes = [vp, vp, vp, vp, ll, f, f, vp]
+    L.refid_charbonnier_parts.argtypes = [ll]
+    L.refid_charbonnier.argtypes = [vp, vp, vp, vp, vp, ll, f, f, vp]
     L.refid_grad_sqnorm.argtypes = [vp, vp, ll, vp]
-    L.refid_psnr_loss.argtypes = [vp, vp, vp, vp, vp, i, ll, f, vp]
+    L.refid_psnr_loss_parts.argtypes = [i, ll]
+    L.refid_psnr_loss.argtypes = [vp, vp, vp, vp, vp, vp, i, ll, f, vp]
     L.refid_clip_adamw.argtypes = [vp, vp, vp, vp, vp, f, f, f, f, f, f, f, i, ll, vp]
     L.refid_clip_adamw_dev.argtypes = [vp, vp, vp, vp, vp, f, f, vp, f, f, f, f, ll, vp]
     d = C.c_double
     L.refid_events_to_voxel.argtypes = [vp, vp, vp, vp, ll, i, i, i, d, d, vp, vp]
-    L.refid_sqerr_u8.argtypes = [vp, vp, i, ll, vp, vp]
-    L.refid_ssim3d_u8.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.refid_sqerr_u8_parts.argtypes = [i, ll]
+    L.refid_sqerr_u8.argtypes = [vp, vp, i, ll, vp, vp, vp]
+    L.refid_ssim3d_u8_parts.argtypes = [i, i, i]
+    L.refid_ssim3d_u8.argtypes = [vp, vp, i, i, i, vp, vp, vp]
     L.refid_tile_add.argtypes = [vp, vp, vp, i, i, i, i, i, i, i, vp]
     L.refid_tile_normalize.argtypes = [vp, vp, i, i, i, vp]
     L.refid_hin_parts.argtypes = [i]

@@ -1,9 +1,14 @@
 """Architecture discovery with the reference's contract
 (/root/reference/basicsr/models/archs/__init__.py:9-46): every ``*_arch.py`` file in this
 folder is imported and ``define_network(opt)`` pops ``type`` and instantiates the first
-module attribute of that name with the remaining keys; unknown types raise ValueError."""
+module attribute of that name with the remaining keys; unknown types raise ValueError.
+
+The arch classes are also registered with ``@ARCH_REGISTRY.register()`` (``refid_amd.registry``: the surface of later
+BasicSR releases, which the reference's vintage does not have); ``define_network`` asks the registry first."""
 import importlib
 import os
+
+from ..registry import ARCH_REGISTRY
 
 _arch_folder = os.path.dirname(os.path.abspath(__file__))
 _arch_filenames = sorted(os.path.splitext(f)[0] for f in os.listdir(_arch_folder) if f.endswith('_arch.py'))
@@ -23,4 +28,6 @@ def dynamic_instantiation(modules, cls_type, opt):
 
 def define_network(opt):
     network_type = opt.pop('type')
+    if network_type in ARCH_REGISTRY:
+        return ARCH_REGISTRY.get(network_type)(**opt)
     return dynamic_instantiation(_arch_modules, network_type, opt)

@@ -12,6 +12,7 @@ runs in librefid_hip.so; there is no torch/CPU fallback -- calling it without th
 import torch
 from torch import nn
 
+from ..registry import ARCH_REGISTRY
 from .. import autograd as hip_autograd
 from ..engine import Engine, param_shapes
 from .._lib import RefidHipError
@@ -24,6 +25,7 @@ class _Node(nn.Module):
         return ""
 
 
+@ARCH_REGISTRY.register()
 class FinalBidirectionAttenfusion(nn.Module):
     def __init__(self, img_chn, ev_chn, out_chn=3, skip_type='sum', recurrent_block_type='convlstm',
                  activation='sigmoid', num_encoders=4, base_num_channels=32, num_residual_blocks=2, norm=None,

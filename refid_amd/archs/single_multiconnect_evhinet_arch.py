@@ -10,6 +10,7 @@ import math
 import torch
 from torch import nn
 
+from ..registry import ARCH_REGISTRY
 from .. import autograd as hip_autograd
 from .._lib import RefidHipError
 from ..evhinet import EvhinetEngine, param_shapes
@@ -20,6 +21,7 @@ class _Node(nn.Module):
         return ""
 
 
+@ARCH_REGISTRY.register()
 class SingleMultiConnectEVHINet(nn.Module):
     def __init__(self, in_chn=3, ev_chn=6, wf=64, depth=3, fac_place=2, fac_kernel_size=1, fac_before_downsample=True,
                  event_feature_transfer=False, relu_slope=0.2, hin_position_left=0, hin_position_right=4):

@@ -30,15 +30,21 @@ def _newer(src_list, target):
 def build(verbose=False, force=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     flags = list(FLAGS)
-    stamp = os.path.join(CSRC, ".experimental")          # a change of the switch rebuilds everything
-    was = os.path.exists(stamp)
+    # The flag set the objects and the library were built with is recorded AFTER a successful link (never before: a failed
+    # compile must not leave a stamp that says "already built this way"); a different or missing record rebuilds everything.
+    stamp = os.path.join(CSRC, ".buildflags")
     if EXPERIMENTAL:
         srcs += sorted(glob.glob(os.path.join(CSRC, "experimental", "*.hip")))
         flags.append("-DREFID_EXPERIMENTAL_TILES")
-        open(stamp, "w").close()
-    elif was:
-        os.remove(stamp)
-    force = force or (was != EXPERIMENTAL)
+    want = " ".join(flags)
+    try:
+        have = open(stamp).read()
+    except OSError:
+        have = None if os.path.exists(LIB) else want       # a tree that was never built: nothing stale to distrust
+    if have != want:
+        force = True
+        if os.path.exists(stamp):
+            os.remove(stamp)                               # until the link below succeeds the tree counts as unknown
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "refid_hip.h")]
     objs = []
     jobs = []
@@ -70,6 +76,9 @@ def build(verbose=False, force=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if not os.path.exists(stamp):
+        with open(stamp, "w") as f:
+            f.write(want)
     return LIB
 
 

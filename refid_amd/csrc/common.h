@@ -50,6 +50,9 @@ __device__ __forceinline__ float refid_wave_rows_sum(float v) {
     return v;
 }
 
+// out[r] = sum of the n doubles of row r of `part`, in a fixed order (train.hip): second stage of every scalar reduction
+int refid_launch_sum_rows_f64(const double* part, int rows, int n, double* out, hipStream_t st);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

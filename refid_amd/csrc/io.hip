@@ -3,7 +3,8 @@
 //   * validation tail        basicsr/utils/img_util.py:90-117 (tensor2img quantisation) +
 //                            basicsr/metrics/psnr_ssim.py:48-63 (calculate_psnr, float64 MSE)
 //   * tile overlap-averaging basicsr/models/twoImage_event_recurrent_model.py:252-268 (grids_inverse)
-// All HBM/atomic-bound streaming kernels.
+// HBM-bound streaming kernels; the scalar sums (PSNR / SSIM) are two-stage and deterministic, only the event scatter-add
+// uses (fp32) atomics, as np.add.at's order is unspecified too.
 #include "common.h"
 
 namespace {
@@ -32,7 +33,7 @@ __device__ __forceinline__ float quant255(float v) {          // tensor2img: cla
     return rintf(v * 255.f);
 }
 
-// sq[f] += sum over the frame of (q(a) - q(b))^2 ; grid = (chunks, frames)
+// sq[f][chunk] = sum over the chunk's share of the frame of (q(a) - q(b))^2 ; grid = (chunks, frames)
 __global__ __launch_bounds__(256) void sqerr_u8_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                       long long frame_elems, double* __restrict__ sq) {
     __shared__ double sh[4];
@@ -48,7 +49,7 @@ __global__ __launch_bounds__(256) void sqerr_u8_kernel(const float* __restrict__
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(sq + f, sh[0] + sh[1] + sh[2] + sh[3]);
+    if (threadIdx.x == 0) sq[f * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];   // partial [frame][chunk]
 }
 
 // acc[c][i0+y][j0+x] += tile[c][y][x] ; cnt[i0+y][j0+x] += 1     (one tile)
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256) void ssim3d_kernel(const float* __restrict__ a
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out + f, sred[0] + sred[1] + sred[2] + sred[3]);
+    if (threadIdx.x == 0)                                           // partial [frame][tile row][tile column]
+        out[((long long)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
 }
 
 int nb(long long n) { long long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b)); }
@@ -155,17 +157,23 @@ extern "C" int refid_events_to_voxel(const double* ts, const int* xs, const int*
     return 0;
 }
 
+static int sqerr_chunks(long long frame_elems) {
+    const int c = nb(frame_elems);
+    return c > 256 ? 256 : c;
+}
+
+extern "C" int refid_sqerr_u8_parts(int n_frames, long long frame_elems) {
+    return (n_frames > 0 && frame_elems > 0) ? n_frames * sqerr_chunks(frame_elems) : 0;
+}
+
 extern "C" int refid_sqerr_u8(const float* a, const float* b, int n_frames, long long frame_elems, double* sq,
-                              void* stream) {
-    REFID_CHECK(a && b && sq && n_frames > 0 && frame_elems > 0, "sqerr_u8: bad arguments");
+                              double* parts, void* stream) {
+    REFID_CHECK(a && b && sq && parts && n_frames > 0 && frame_elems > 0, "sqerr_u8: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sq, 0, sizeof(double) * n_frames, st);
-    REFID_CHECK(e == hipSuccess, "sqerr_u8: memset failed: %s", hipGetErrorString(e));
-    int chunks = nb(frame_elems);
-    if (chunks > 256) chunks = 256;
-    hipLaunchKernelGGL(sqerr_u8_kernel, dim3(chunks, n_frames), dim3(256), 0, st, a, b, frame_elems, sq);
+    const int chunks = sqerr_chunks(frame_elems);
+    hipLaunchKernelGGL(sqerr_u8_kernel, dim3(chunks, n_frames), dim3(256), 0, st, a, b, frame_elems, parts);
     REFID_LAUNCH_CHECK("sqerr_u8");
-    return 0;
+    return refid_launch_sum_rows_f64(parts, n_frames, chunks, sq, st);
 }
 
 extern "C" int refid_tile_add(const float* tile, float* acc, float* cnt, int c, int th, int tw, int h, int w, int i0,
@@ -186,12 +194,14 @@ extern "C" int refid_tile_normalize(float* acc, const float* cnt, int c, int h, 
     return 0;
 }
 
+extern "C" int refid_ssim3d_u8_parts(int n_frames, int h, int w) {
+    return (n_frames > 0 && h > 0 && w > 0) ? n_frames * cdiv(w, 16) * cdiv(h, 16) : 0;
+}
+
 extern "C" int refid_ssim3d_u8(const float* a, const float* b, int n_frames, int h, int w, double* sum_out,
-                               void* stream) {
-    REFID_CHECK(a && b && sum_out && n_frames > 0 && h > 0 && w > 0, "ssim3d_u8: bad arguments");
+                               double* parts, void* stream) {
+    REFID_CHECK(a && b && sum_out && parts && n_frames > 0 && h > 0 && w > 0, "ssim3d_u8: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sum_out, 0, sizeof(double) * n_frames, st);
-    REFID_CHECK(e == hipSuccess, "ssim3d_u8: memset failed: %s", hipGetErrorString(e));
     SsimConst k;
     double g[11], s = 0.0;                                  // cv2.getGaussianKernel(11, 1.5)
     for (int i = 0; i < 11; ++i) { g[i] = exp(-((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += g[i]; }
@@ -202,7 +212,7 @@ extern "C" int refid_ssim3d_u8(const float* a, const float* b, int n_frames, int
         for (int q = 0; q < 3; ++q) k.mc[c][q] = (float)m[q];
     }
     dim3 grid(cdiv(w, 16), cdiv(h, 16), n_frames);
-    hipLaunchKernelGGL(ssim3d_kernel, grid, dim3(256), 0, st, a, b, h, w, k, sum_out);
+    hipLaunchKernelGGL(ssim3d_kernel, grid, dim3(256), 0, st, a, b, h, w, k, parts);
     REFID_LAUNCH_CHECK("ssim3d_u8");
-    return 0;
+    return refid_launch_sum_rows_f64(parts, n_frames, (int)(grid.x * grid.y), sum_out, st);
 }

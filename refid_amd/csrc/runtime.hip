@@ -406,41 +406,78 @@ extern "C" int refid_pack_conv_weights_wino6(const float* w, const float* oscale
 // ---- batched packing ------------------------------------------------------------------------------------------------
 extern "C" size_t refid_pack_entry_bytes(void) { return sizeof(PackEntry); }
 
+// error paths of the table builder return -1 (a positive value is a workgroup count), never REFID_CHECK's 1
+#define REFID_FILL_CHECK(cond, ...)               \
+    do {                                          \
+        if (!(cond)) {                            \
+            refid_set_error(__VA_ARGS__);         \
+            return -1;                            \
+        }                                         \
+    } while (0)
+
 extern "C" int refid_pack_entry_fill(void* entry_host, int kind, const float* w, const float* oscale, void* dst, int role, int o,
                                      int i, int kh, int kw, int kc, int bn, int planes, int blk0) {
-    REFID_CHECK(entry_host && w && dst, "pack_entry_fill: null pointer");
+    REFID_FILL_CHECK(entry_host && w && dst, "pack_entry_fill: null pointer");
+    REFID_FILL_CHECK(blk0 >= 0, "pack_entry_fill: negative first block %d", blk0);
     PackEntry en;
     memset(&en, 0, sizeof(en));
     en.kind = kind; en.planes = planes; en.mode = 0; en.blk0 = blk0;
     PackArgs& p = en.p;
     if (kind == 4) {                                        // out[e] = w[e] * oscale[e], e < o
-        REFID_CHECK(oscale != nullptr && o > 0, "pack_entry_fill: the vector product needs both factors");
+        REFID_FILL_CHECK(oscale != nullptr && o > 0, "pack_entry_fill: the vector product needs both factors");
         p.w = w; p.oscale = oscale; p.dst = reinterpret_cast<float*>(dst);
         en.total = o;
     } else if (kind == 0) {
-        REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        // the same conditions as refid_pack_conv_weights / _scaled / _bf16 (pack_impl)
+        REFID_FILL_CHECK(planes == 0 || planes == 1, "pack_entry_fill: kind 0 takes planes = 0 (fp32) or 1 (bf16), got %d", planes);
+        REFID_FILL_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        REFID_FILL_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),
+                         "pack_entry_fill: convT roles need a 2x2 kernel");
+        REFID_FILL_CHECK(role != REFID_ROLE_DOWN_DGRAD || (kh == 4 && kw == 4), "pack_entry_fill: down-dgrad needs a 4x4 kernel");
+        const bool wino = role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD;
+        REFID_FILL_CHECK(!wino || (kh == 3 && kw == 3 && kc == 8 && planes == 0),
+                         "pack_entry_fill: Winograd roles need a 3x3 kernel, kc = 8 and fp32 output");
+        REFID_FILL_CHECK(oscale == nullptr || role == REFID_ROLE_FWD || role == REFID_ROLE_DGRAD || wino,
+                         "pack_entry_fill: only FWD/DGRAD roles take a scale");
         p.bf16 = planes;                                    // (kind 0: `planes` = 1 selects bf16 output)
         en.total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
     } else if (kind == 1 || kind == 2) {
         const int mode = split_pack_mode(role, kh, kw);
-        REFID_CHECK(mode >= 0 && (kind == 2) == (mode == 3) && planes >= 1 && planes <= 3, "pack_entry_fill: bad split geometry");
-        REFID_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        REFID_FILL_CHECK(mode >= 0 && (kind == 2) == (mode == 3) && planes >= 1 && planes <= 3, "pack_entry_fill: bad split geometry");
+        REFID_FILL_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
         p.bf16 = 1;
         en.mode = mode;
         en.total = split_pack_elems(p, planes, mode);
     } else if (kind == 3) {
-        REFID_CHECK((role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD) && kh == 3 && kw == 3, "pack_entry_fill: Winograd roles, 3x3");
-        REFID_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        REFID_FILL_CHECK((role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD) && kh == 3 && kw == 3, "pack_entry_fill: Winograd roles, 3x3");
+        REFID_FILL_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
         p.bf16 = 1;
         en.total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
     } else {
-        REFID_CHECK(false, "pack_entry_fill: unknown kind %d", kind);
+        REFID_FILL_CHECK(false, "pack_entry_fill: unknown kind %d", kind);
     }
+    REFID_FILL_CHECK(en.total > 0, "pack_entry_fill: empty packing (o=%d, i=%d)", o, i);
     if (kind != 4) { p.w = w; p.dst = reinterpret_cast<float*>(dst); p.oscale = oscale; }
     long long nb = (en.total + 255) / 256;
     en.nblk = (int)(nb < 1 ? 1 : (nb > 1024 ? 1024 : nb));
     memcpy(entry_host, &en, sizeof(en));
     return en.nblk;
+}
+
+// Host-side check of a finished table (before it is copied to the device): kinds valid, first blocks strictly increasing from
+// 0 with blk0[k+1] = blk0[k] + nblk[k] (the kernel's binary search relies on it).  Returns the total workgroup count, -1 on error.
+extern "C" int refid_pack_table_check(const void* table_host, int n) {
+    REFID_FILL_CHECK(table_host != nullptr && n > 0, "pack_table_check: empty table");
+    const PackEntry* t = reinterpret_cast<const PackEntry*>(table_host);
+    long long blk = 0;
+    for (int k = 0; k < n; ++k) {
+        REFID_FILL_CHECK(t[k].kind >= 0 && t[k].kind <= 4 && t[k].total > 0 && t[k].nblk >= 1,
+                         "pack_table_check: record %d was never filled (kind %d, total %lld)", k, t[k].kind, t[k].total);
+        REFID_FILL_CHECK(t[k].blk0 == blk, "pack_table_check: record %d starts at block %d, expected %lld", k, t[k].blk0, blk);
+        blk += t[k].nblk;
+    }
+    REFID_FILL_CHECK(blk < 0x7fffffffLL, "pack_table_check: too many workgroups");
+    return (int)blk;
 }
 
 extern "C" int refid_pack_batch(const void* table_dev, int n, int nblocks, void* stream) {

@@ -20,7 +20,7 @@ __device__ __forceinline__ double block_sum_double(double v, double* sh) {
     return r;       // valid on thread 0
 }
 
-// loss_sum += sum sqrt(d^2 + eps) ; grad = d / sqrt(d^2 + eps) * gscale     (d = pred - gt)
+// loss_sum[block] = sum sqrt(d^2 + eps) ; grad = d / sqrt(d^2 + eps) * gscale     (d = pred - gt)
 __global__ __launch_bounds__(256) void charbonnier_kernel(const f32x4* __restrict__ pred, const f32x4* __restrict__ gt,
                                                          f32x4* __restrict__ grad, double* __restrict__ loss_sum,
                                                          float eps, float gscale, long long n4) {
@@ -38,11 +38,11 @@ __global__ __launch_bounds__(256) void charbonnier_kernel(const f32x4* __restric
         if (grad) grad[i] = g;
     }
     const double t = block_sum_double((double)acc, sh);
-    if (threadIdx.x == 0) atomicAdd(loss_sum, t);
+    if (threadIdx.x == 0) loss_sum[blockIdx.x] = t;        // per-block partial; summed in index order (sum_rows_kernel)
 }
 
 // PSNRLoss (losses.py:95-120, toY = False): loss = w * 10/ln10 * mean_b log(mse_b + 1e-8), mse_b over (C,H,W).
-// Pass 1: sq[b] += sum (pred - gt)^2 of sample b (grid.y = b).  Pass 2: grad = (pred - gt) * 2 w scale / (n_b B (mse_b + 1e-8));
+// Pass 1: partial sums of (pred - gt)^2 of sample b (grid.y = b), finished in index order into sq[b].  Pass 2: grad = (pred - gt) * 2 w scale / (n_b B (mse_b + 1e-8));
 // block 0 also writes the loss itself.
 __global__ __launch_bounds__(256) void psnr_sq_kernel(const f32x4* __restrict__ pred, const f32x4* __restrict__ gt,
                                                      double* __restrict__ sq, long long per4) {
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void psnr_sq_kernel(const f32x4* __restrict__ 
         acc += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
     }
     const double t = block_sum_double((double)acc, sh);
-    if (threadIdx.x == 0) atomicAdd(sq + blockIdx.y, t);
+    if (threadIdx.x == 0) sq[(long long)blockIdx.y * gridDim.x + blockIdx.x] = t;     // partial [sample][block]
 }
 
 __global__ __launch_bounds__(256) void psnr_grad_kernel(const f32x4* __restrict__ pred, const f32x4* __restrict__ gt,
@@ -85,10 +85,12 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const f32x4* __restrict__ g
     if (threadIdx.x == 0) out[blockIdx.x] = t;             // per-block partial (deterministic 2nd stage)
 }
 
-// fixed-order sum of the per-block partials: every rank of a data-parallel job must derive the SAME
-// clip coefficient from the same all-reduced gradients, so no atomics here
-__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
+// fixed-order sum of per-block partials, one row of n partials per workgroup: every rank of a data-parallel job must
+// derive the SAME clip coefficient from the same all-reduced gradients, and a logged loss / PSNR / SSIM must not depend
+// on the arrival order of workgroups -- so no floating-point atomics anywhere
+__global__ __launch_bounds__(256) void sum_rows_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
     __shared__ double sh[256];
+    part += (long long)blockIdx.x * n;
     double a = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) a += part[i];
     sh[threadIdx.x] = a;
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
         if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = sh[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
 // torch.nn.utils.clip_grad_norm_(max_norm) + torch.optim.AdamW single step.
@@ -135,30 +137,44 @@ int nblocks(long long n4) {
 
 }  // namespace
 
-extern "C" int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, long long count,
-                                 float eps, float grad_scale, void* stream) {
-    REFID_CHECK(pred && gt && loss_sum && count > 0 && count % 4 == 0, "charbonnier: bad arguments (count=%lld)", count);
-    hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(loss_sum, 0, sizeof(double), st);
-    REFID_CHECK(e == hipSuccess, "charbonnier: memset failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(charbonnier_kernel, dim3(nblocks(count / 4)), dim3(256), 0, st, (const f32x4*)pred,
-                       (const f32x4*)gt, (f32x4*)grad, loss_sum, eps, grad_scale, count / 4);
-    REFID_LAUNCH_CHECK("charbonnier");
+int refid_launch_sum_rows_f64(const double* part, int rows, int n, double* out, hipStream_t st) {
+    hipLaunchKernelGGL(sum_rows_kernel, dim3(rows), dim3(256), 0, st, part, n, out);
+    REFID_LAUNCH_CHECK("sum_rows_f64");
     return 0;
 }
 
-extern "C" int refid_psnr_loss(const float* pred, const float* gt, float* grad, double* sq, double* loss, int n_samples,
-                               long long per_sample, float weight, void* stream) {
-    REFID_CHECK(pred && gt && sq && loss && n_samples > 0 && per_sample > 0 && per_sample % 4 == 0,
+extern "C" int refid_charbonnier_parts(long long count) { return count > 0 ? nblocks(count / 4) : 0; }
+
+extern "C" int refid_charbonnier(const float* pred, const float* gt, float* grad, double* loss_sum, double* parts,
+                                 long long count, float eps, float grad_scale, void* stream) {
+    REFID_CHECK(pred && gt && loss_sum && parts && count > 0 && count % 4 == 0, "charbonnier: bad arguments (count=%lld)", count);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = nblocks(count / 4);
+    hipLaunchKernelGGL(charbonnier_kernel, dim3(nb), dim3(256), 0, st, (const f32x4*)pred,
+                       (const f32x4*)gt, (f32x4*)grad, parts, eps, grad_scale, count / 4);
+    REFID_LAUNCH_CHECK("charbonnier");
+    return refid_launch_sum_rows_f64(parts, 1, nb, loss_sum, st);
+}
+
+static int psnr_blocks(long long per_sample) {
+    const int nb = nblocks(per_sample / 4);
+    return nb > 256 ? 256 : nb;
+}
+
+extern "C" int refid_psnr_loss_parts(int n_samples, long long per_sample) {
+    return (n_samples > 0 && per_sample > 0) ? n_samples * psnr_blocks(per_sample) : 0;
+}
+
+extern "C" int refid_psnr_loss(const float* pred, const float* gt, float* grad, double* sq, double* loss, double* parts,
+                               int n_samples, long long per_sample, float weight, void* stream) {
+    REFID_CHECK(pred && gt && sq && loss && parts && n_samples > 0 && per_sample > 0 && per_sample % 4 == 0,
                 "psnr_loss: bad arguments (per_sample=%lld)", per_sample);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sq, 0, sizeof(double) * n_samples, st);
-    REFID_CHECK(e == hipSuccess, "psnr_loss: memset failed: %s", hipGetErrorString(e));
-    int nb = nblocks(per_sample / 4);
-    if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(psnr_sq_kernel, dim3(nb, n_samples), dim3(256), 0, st, (const f32x4*)pred, (const f32x4*)gt, sq,
+    const int nb = psnr_blocks(per_sample);
+    hipLaunchKernelGGL(psnr_sq_kernel, dim3(nb, n_samples), dim3(256), 0, st, (const f32x4*)pred, (const f32x4*)gt, parts,
                        per_sample / 4);
     REFID_LAUNCH_CHECK("psnr_loss/sq");
+    if (int rc = refid_launch_sum_rows_f64(parts, n_samples, nb, sq, st)) return rc;
     hipLaunchKernelGGL(psnr_grad_kernel, dim3(nb, n_samples), dim3(256), 0, st, (const f32x4*)pred, (const f32x4*)gt,
                        (f32x4*)grad, sq, loss, per_sample / 4, n_samples, weight);
     REFID_LAUNCH_CHECK("psnr_loss/grad");
@@ -172,9 +188,7 @@ extern "C" int refid_grad_sqnorm(const float* g, double* out, long long count, v
     const int nb = nblocks(count / 4);
     hipLaunchKernelGGL(sqnorm_kernel, dim3(nb), dim3(256), 0, st, (const f32x4*)g, out + 1, count / 4);
     REFID_LAUNCH_CHECK("grad_sqnorm");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, out + 1, nb, out);
-    REFID_LAUNCH_CHECK("grad_sqnorm/sum");
-    return 0;
+    return refid_launch_sum_rows_f64(out + 1, 1, nb, out, st);
 }
 
 extern "C" int refid_clip_adamw(float* p, const float* g, float* m, float* v, const double* sqnorm, float max_norm,

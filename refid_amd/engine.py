@@ -233,6 +233,18 @@ def _fills_gpu(n, ho, wo, cout, classes):
     return n * -(-ho // 4) * -(-wo // 32) * -(-cout // 64) * classes >= 256
 
 
+_LIM4 = (2 ** 31 - 1) // 4                    # fp32 elements below 2 GiB
+
+
+def _batch_step(n, *tensors):
+    """Largest sub-batch whose tensors all stay below 2 GiB."""
+    per = max(t.stride(0) * 4 for t in tensors if t is not None)
+    if per >= 2 ** 31 - 1:
+        raise RefidHipError(f"conv: one sample's tensor has {per} bytes; the tiles' 32-bit offsets end at 2 GiB (tile the frame: "
+                            "refid_amd.tiling)")
+    return max(1, (2 ** 31 - 2) // per)
+
+
 class ConvOp:
     """One convolution of the network: geometry + packed weights + the three kernels."""
     default_split = 0                         # set by Engine.__init__ for the convs it builds (compute_dtype "bf16x3")
@@ -335,10 +347,12 @@ class ConvOp:
                                         dtype=torch.bfloat16, device=dev)
         # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T
         self.wp6 = self.wd6 = None
-        if WINO6 and not bf16 and self.f_algo == 1 and self.co > 32 and self.ci % 4 == 0:
+        if WINO6 and not bf16 and self.f_algo == 1 and self.co > 32 and self.ci % 4 == 0 and \
+                ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) < 2 ** 31 - 1:
             self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) // 2,
                                    dtype=torch.bfloat16, device=dev)
-        if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci > 32 and self.co % 4 == 0:
+        if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci > 32 and self.co % 4 == 0 and \
+                ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) < 2 ** 31 - 1:
             self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) // 2,
                                    dtype=torch.bfloat16, device=dev)
         # split-bf16 direct tile (algo 4): second packing next to the default one
@@ -445,6 +459,17 @@ class ConvOp:
             if _pad4(oc) != oc:
                 out.zero_()
                 out = out[..., :oc]
+        if n * a.stride(0) >= _LIM4 or n * out.stride(0) >= _LIM4 or (b is not None and n * b.stride(0) >= _LIM4):
+            step = _batch_step(n, a, b, res, out)
+            # the tiles address their tensors with 32-bit byte offsets (hardware range-checked buffer loads): a batch whose
+            # tensors reach 2 GiB is issued in sub-batches -- samples are independent (no cross-sample op on the path)
+            if pw is not None:
+                raise RefidHipError(f"{self.name}: fused pointwise extras cannot be issued in sub-batches (tensor >= 2 GiB)")
+            for i in range(0, n, step):
+                j = min(n, i + step)
+                self.fwd(a[i:j], None if b is None else b[i:j], None if res is None else res[i:j], slope_pre, slope_post,
+                         out[i:j])
+            return out
         kh, kw, st, md = self.f_geo
         if self.wps is not None and (self.split > 1 or b is None) and a.shape[3] % 8 == 0 and pw is None and \
                 (self.kind == "conv" or (b is None and _fills_gpu(n, ho, wo, self.co, 1))):
@@ -480,6 +505,13 @@ class ConvOp:
             ho, wo = h // 2, w // 2
         if out is None:
             out = torch.empty((n, ho, wo, cnt), dtype=torch.float32, device=g.device)
+        if n * g.stride(0) >= _LIM4 or n * out.stride(0) >= _LIM4:      # (see fwd)
+            step = _batch_step(n, g, res, mask, out)
+            for i in range(0, n, step):
+                j = min(n, i + step)
+                self.dgrad(g[i:j], rows, None if res is None else res[i:j], None if mask is None else mask[i:j], slope_mask,
+                           out[i:j])
+            return out
         kh, kw, st, md = self.d_geo
         pad = self.pad if self.kind == "conv" else (1 if self.kind == "down" else 0)
         if self.kind == "conv":
@@ -533,22 +565,36 @@ class ConvOp:
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):
-            # same source split as the waiting calls (the first recurrent step has no second source yet)?
-            if self.w_pend and (self.w_pend[0][2] is None) != (b is None):
+            # same source split and same algorithm as the waiting calls (the first recurrent step has no second source yet)?
+            if self.w_pend and ((self.w_pend[0][2] is None) != (b is None) or self.w_algo != algo):
                 self._launch_group()
             self.w_pend.append((g, a, b))
             self.w_algo = algo
             if len(self.w_pend) >= self.w_group:
                 self._launch_group()
             return
+        self._slab_layout(algo)
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
                                       db=self.gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
                                       slabs=self.wslab)
         self.w_calls += 1
         self.w_last = (g, a, b, algo)
 
+    def _slab_layout(self, algo):
+        """The partial-sum slabs persist over the calls of one backward pass, and their layout belongs to the algorithm
+        ([split][16 xi][co][ci] for the Winograd tiles, [split][tap][co][ci] for the direct ones).  The algorithm is a
+        function of the op's geometry -- except for a two-source call whose split is not a multiple of the Winograd
+        tile's 32 channels -- so a change between two calls is rare; when it happens, what has accumulated is reduced
+        into the parameter gradient (phase 3 ACCUMULATES into dw) and the slabs start over."""
+        if self.w_calls and self.w_last is not None and self.w_last[3] != algo:
+            g, a, b, old = self.w_last
+            ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
+                             db=self.gb, i_total=self.ci, algo=old, phase=3, slabs=self.wslab)
+            self.w_calls = 0
+
     def _launch_group(self):
         (g, a, b), more = self.w_pend[0], self.w_pend[1:]
+        self._slab_layout(self.w_algo)
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
                                       db=self.gb, i_total=self.ci, algo=self.w_algo, phase=1 if self.w_calls == 0 else 2,
                                       slabs=self.wslab, more=more)

@@ -2,7 +2,8 @@
 
 Reference: basicsr/utils/img_util.py:90-117 (clamp to [0,1], x255, round -> uint8; the RGB->BGR
 flip is PSNR-invariant) and basicsr/metrics/psnr_ssim.py:48-63 (float64 MSE over H x W x 3,
-20*log10(255/sqrt(mse)), inf when identical).  One fused kernel, no host round trip per frame."""
+20*log10(255/sqrt(mse)), inf when identical).  One fused kernel + a fixed-order finish (deterministic, no atomics),
+no host round trip per frame."""
 import ctypes as C
 import math
 
@@ -20,11 +21,11 @@ def calculate_psnr_frames(pred, gt):
     pred, gt = pred.contiguous(), gt.contiguous()
     fe = pred.shape[-1] * pred.shape[-2] * pred.shape[-3]
     nf = pred.numel() // fe
-    sq = torch.empty(nf, dtype=torch.float64, device=pred.device)
+    buf = torch.empty(nf + lib().refid_sqerr_u8_parts(nf, fe), dtype=torch.float64, device=pred.device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    check(lib().refid_sqerr_u8(pred.data_ptr(), gt.data_ptr(), nf, fe, sq.data_ptr(), st), "refid_sqerr_u8")
+    check(lib().refid_sqerr_u8(pred.data_ptr(), gt.data_ptr(), nf, fe, buf.data_ptr(), buf[nf:].data_ptr(), st), "refid_sqerr_u8")
     out = []
-    for v in sq.tolist():                         # one device->host copy for all frames
+    for v in buf[:nf].tolist():                         # one device->host copy for all frames
         mse = v / fe
         out.append(float("inf") if mse == 0 else 20.0 * math.log10(255.0 / math.sqrt(mse)))
     return out
@@ -40,10 +41,10 @@ def calculate_ssim_frames(pred, gt):
     pred, gt = pred.contiguous(), gt.contiguous()
     h, w = pred.shape[-2], pred.shape[-1]
     nf = pred.numel() // (3 * h * w)
-    acc = torch.empty(nf, dtype=torch.float64, device=pred.device)
+    buf = torch.empty(nf + lib().refid_ssim3d_u8_parts(nf, h, w), dtype=torch.float64, device=pred.device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    check(lib().refid_ssim3d_u8(pred.data_ptr(), gt.data_ptr(), nf, h, w, acc.data_ptr(), st), "refid_ssim3d_u8")
-    return [v / (3 * h * w) for v in acc.tolist()]
+    check(lib().refid_ssim3d_u8(pred.data_ptr(), gt.data_ptr(), nf, h, w, buf.data_ptr(), buf[nf:].data_ptr(), st), "refid_ssim3d_u8")
+    return [v / (3 * h * w) for v in buf[:nf].tolist()]
 
 
 def split_deblur_interp(psnrs, m, n):

@@ -586,8 +586,11 @@ class PackPlan:
                                          oscale.data_ptr() if oscale is not None else None, dst.data_ptr(), role, o, i, kh, kw,
                                          kc, bn, planes, blk)
             if nb <= 0:
-                raise _lib.RefidHipError("refid_pack_entry_fill: " + L.refid_last_error().decode())
+                raise _lib.RefidHipError(f"refid_pack_entry_fill (record {n}, kind {kind}): " + L.refid_last_error().decode())
             blk += nb
+        # every record filled, first blocks consecutive from 0 (the kernel's binary search relies on it)
+        if L.refid_pack_table_check(C.addressof(buf), len(self.items)) != blk:
+            raise _lib.RefidHipError("refid_pack_table_check: " + L.refid_last_error().decode())
         self.nblocks = blk
         self.table = torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8).to(self.device)
         return self
@@ -614,24 +617,26 @@ def fold_back(w, b, scale, gw_folded, gb_folded, gw, gb, dscale):
 
 
 def charbonnier(pred, gt, grad=None, eps=1e-12, grad_scale=None):
-    """Returns the device double holding sum sqrt((pred-gt)^2+eps); grad (optional) gets d/dpred of the MEAN."""
+    """Returns the device double holding sum sqrt((pred-gt)^2+eps); grad (optional) gets d/dpred of the MEAN.
+    Two-stage, deterministic: buf[0] = the sum, buf[1:] = the per-workgroup partials."""
     n = pred.numel()
-    loss_sum = torch.empty(1, dtype=torch.float64, device=pred.device)
+    buf = torch.empty(1 + lib().refid_charbonnier_parts(n), dtype=torch.float64, device=pred.device)
     if grad_scale is None:
         grad_scale = 1.0 / n
     check(lib().refid_charbonnier(_c(pred, "pred"), _c(gt, "gt"), grad.data_ptr() if grad is not None else None,
-                                  loss_sum.data_ptr(), n, eps, grad_scale, _stream()), "refid_charbonnier")
-    return loss_sum
+                                  buf.data_ptr(), buf[1:].data_ptr(), n, eps, grad_scale, _stream()), "refid_charbonnier")
+    return buf[:1]
 
 
 def psnr_loss(pred, gt, grad=None, weight=1.0):
     """PSNRLoss (losses.py:95-120) of (B, ...) tensors; returns the 1-element double device tensor holding the loss."""
     nb = pred.shape[0]
     per = pred.numel() // nb
-    buf = torch.empty(nb + 1, dtype=torch.float64, device=pred.device)
+    buf = torch.empty(nb + 1 + lib().refid_psnr_loss_parts(nb, per), dtype=torch.float64, device=pred.device)
     check(lib().refid_psnr_loss(_c(pred, "pred"), _c(gt, "gt"), grad.data_ptr() if grad is not None else None,
-                                buf.data_ptr(), buf[nb:].data_ptr(), nb, per, weight, _stream()), "refid_psnr_loss")
-    return buf[nb:]
+                                buf.data_ptr(), buf[nb:].data_ptr(), buf[nb + 1:].data_ptr(), nb, per, weight, _stream()),
+          "refid_psnr_loss")
+    return buf[nb:nb + 1]
 
 
 SQNORM_WORDS = 2049

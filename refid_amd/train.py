@@ -361,24 +361,33 @@ class TwoImageEventRecurrentRestorationModel:
             self.exp_avg.copy_(o["exp_avg"])
             self.exp_avg_sq.copy_(o["exp_avg_sq"])
         elif "state" in o and "param_groups" in o:
+            # torch keys the state by the parameter's index in param_groups (= named_parameters order, setup_optimizers
+            # :67-95) and creates an entry lazily, at the first step() that sees a gradient for it.  atten_fuse.se_2 is
+            # never used in forward (fusion_modules.py:261 vs :312-315): it only has a gradient because of the wrapper's
+            # `0 * sum(p.sum())` term (:301), so a `.state` written by a loop without that term holds SPARSE integer
+            # keys.  Parameters without an entry keep zero moments -- exactly what torch creates on first use.
             keys = list(arena.offsets)
             st = o["state"]
-            if len(st) != len(keys):
-                raise ValueError(f"resume_training: torch optimizer state for {len(st)} parameters, this network has "
-                                 f"{len(keys)}")
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
             steps = set()
-            for i, k in enumerate(keys):
-                e = st[i]
+            for idx, e in st.items():
+                i = int(idx)
+                if not 0 <= i < len(keys):
+                    raise ValueError(f"resume_training: optimizer state index {i} outside this network's {len(keys)} "
+                                     "parameters")
+                k = keys[i]
                 off, n = arena.offsets[k]
-                if e["exp_avg"].numel() != n:
+                if e["exp_avg"].numel() != n or e["exp_avg_sq"].numel() != n:
                     raise ValueError(f"resume_training: optimizer state {i} has {e['exp_avg'].numel()} values, parameter "
                                      f"{k} has {n}")
                 self.exp_avg[off:off + n].copy_(e["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(e["exp_avg_sq"].reshape(-1))
                 steps.add(int(e["step"]))
-            if len(steps) != 1:
+            if len(steps) > 1:
                 raise ValueError(f"resume_training: per-parameter step counts differ ({sorted(steps)[:4]} ...)")
-            self.step_count = steps.pop()
+            # (an empty state = an optimizer that never stepped)
+            self.step_count = steps.pop() if steps else 0
         else:
             raise ValueError("resume_training: unknown optimizer entry (neither refid_amd.fused_adamw arenas nor a "
                              "torch.optim.AdamW state_dict)")

@@ -21,6 +21,39 @@ def test_define_network_contract():
         define_network(dict(type="NoSuchNet"))
 
 
+def test_arch_registry_surface():
+    """BASELINE north_star's `@ARCH_REGISTRY.register()` surface (later BasicSR; the reference's vintage scans *_arch.py
+    files instead, archs/__init__.py:9-46 -- define_network serves both)."""
+    from refid_amd import archs
+    from refid_amd.registry import ARCH_REGISTRY, Registry
+    assert set(ARCH_REGISTRY.keys()) >= {"FinalBidirectionAttenfusion", "SingleMultiConnectEVHINet"}
+    cls = ARCH_REGISTRY.get("FinalBidirectionAttenfusion")
+    assert cls is archs.final_bidirection_attenfusion_arch.FinalBidirectionAttenfusion
+    with pytest.raises(KeyError):
+        ARCH_REGISTRY.get("NoSuchNet")
+    reg = Registry("t")
+
+    @reg.register()
+    class A:                                              # noqa: N801
+        pass
+
+    @reg.register
+    class B:                                              # noqa: N801
+        pass
+    assert reg.get("A") is A and reg.get("B") is B and "A" in reg
+    with pytest.raises(AssertionError, match="already registered"):
+        reg.register(A)
+    # a class that is only discoverable by the reference's module scan still resolves (registry first, scan second)
+    class OnlyScanned:                                    # noqa: N801
+        def __init__(self, k):
+            self.k = k
+    archs._arch_modules[0].OnlyScanned = OnlyScanned
+    try:
+        assert archs.define_network(dict(type="OnlyScanned", k=3)).k == 3
+    finally:
+        del archs._arch_modules[0].OnlyScanned
+
+
 @pytest.mark.parametrize("img_chn,count", [(26, 15928355), (6, 15912355), (3, 15909955)])
 def test_state_dict_keys_shapes_and_counts(img_chn, count):
     from refid_amd.archs import define_network

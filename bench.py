@@ -26,6 +26,18 @@ Prints ONE JSON line on rank 0 (contract in the task description) with two extra
   cpu_baseline  the CPU oracle (oracle/refid_oracle.py, kind "port") timed on this box's host
                 cores for train steps at B=1 of the same workload (rank 0, N=1 only).
 
+Input hand-over (the reference's hot loop is prefetcher.next() -> feed_data -> optimize_parameters, train.py:217-232, with
+`prefetch_mode: cuda` copying batch k+1 host -> device on a side stream during step k, data/prefetch_dataloader.py:84-125):
+--h2d prefetch (default) keeps the synthetic batches in PINNED HOST memory and runs refid_amd.data.CUDAPrefetcher + feed_data
+inside the timed loop; step k's inputs are resident in HBM when step k starts (the copy rode under step k-1), and the line
+reports how long the compute stream had to wait for copies (`h2d_ms_exposed`, per step).  --h2d resident feeds once outside
+the loop (the rounds 1-3 protocol).
+
+--mode infer --config 4|5: inference throughput of BASELINE configs[3] (HighREV 7-skip sharp-VFI, 512x512, T=7, img_chn 6) and
+configs[4] (15-skip, 1224x1632, T=15, the reference's 512x512 tile grid through refid_amd.tiling, tiles sharded over the ranks,
+PSNR/SSIM validation tail on the GPU); one "step" = one sample through `test()` (twoImage_event_recurrent_model.py:312-330).
+The default command (no --mode) stays the configs[1] train step.
+
 --dry-run --backend gloo: launcher / rendezvous / gradient-sync / timing protocol only, on CPU tensors (no
 model step; `value` is null).  Used by tests/test_bench_launcher.py; never a measurement.
 """
@@ -65,8 +77,10 @@ def synthetic_batch(B, T, H, W, img_chn, seed, device):
 
 
 def options(args):
+    if args.mode == "infer":
+        args.img_chn = INFER_CONFIGS[args.config]["img_chn"]
     return {
-        "name": "bench", "is_train": True, "num_gpu": 1,
+        "name": "bench", "is_train": args.mode == "train", "num_gpu": 1,
         "network_g": dict(type="FinalBidirectionAttenfusion", img_chn=args.img_chn, ev_chn=2, num_encoders=3,
                           base_num_channels=32, num_block=1, num_residual_blocks=2, compute_dtype=args.dtype),
         "path": {"pretrain_network_g": None},
@@ -141,6 +155,201 @@ def cpu_baseline(args):
                       f"{_cpu_model()}"}
 
 
+def roofline_from_profile(prof, step_seconds, dtype, unit_note):
+    """Dominant kernel (largest accumulated HIP-event time in one instrumented single-stream pass) against its roof."""
+    agg = {}
+    for name, fl, e0, e1, _shape, nb in prof:
+        a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
+        a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1; a[3] += nb
+    name, (fl, sec, cnt, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
+    # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
+    traffic = None
+    import glob
+    suffix = {"fp32": "", "bf16": "_bf16"}.get(dtype)
+    pats = [] if suffix is None else sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")),
+                                            reverse=True)
+    for path in pats:
+        try:
+            table = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        rec = table.get(name)
+        if rec:
+            traffic = rec["hbm_bytes_per_launch"]
+            break
+        inst = [v for k, v in table.items() if k.startswith(name + "<")]      # template instances of the same kernel
+        if inst and not name.startswith("conv_split_kernel<"):
+            traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
+            break
+        if name.startswith("conv_split_kernel<"):
+            # the event timing groups the split tile by its product count; rocprof names the template instances
+            # <MT, NT, planes, KS, mode>: launch-weighted mean over the instances with that many planes
+            planes = {"1": 1, "3": 2, "6": 3}[name[len("conv_split_kernel<"):-1]]
+            rows = [v for k, v in table.items() if k.startswith("conv_split_kernel<") and
+                    int(k[len("conv_split_kernel<"):-1].split(",")[2]) == planes]
+            if rows:
+                traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) /
+                              sum(v["launches"] for v in rows))
+                break
+    # Winograd F(2x2,3x3) executes 16/36 of the direct convolution's multiplies on the matrix
+    # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
+    # the SURVEY 8(d) direct-convolution figure beside it.
+    executed = fl * (16.0 / 36.0) if "wino" in name else fl
+    peak = FP32_MFMA_PEAK_TFLOPS
+    ach = executed / sec / 1e12
+    bound, unit = "mfma", "TFLOP/s"
+    if "wino6" in name:
+        # Winograd-domain products as six bf16 MFMAs each (exact three-plane operand split): issued FLOPs on the
+        # bf16 matrix pipe = direct x 16/36 x 6
+        executed = fl * (16.0 / 36.0) * 6.0
+        ach = executed / sec / 1e12
+    if "split" in name:
+        # split-bf16 tile: `terms` bf16 MFMAs per direct-conv multiply (+ 1/9 for the zero tenth tap of its tap pairs)
+        executed = fl * int(name.split("<")[1].split(">")[0]) * 10.0 / 9.0
+        ach = executed / sec / 1e12
+    if "bf16" in name or "split" in name or "wino6" in name:
+        # bf16 matrix-core operands: the dense bf16 MFMA peak is 2.5 PFLOP/s (MI355X_MICROARCH.md); such a
+        # tile streams fp32 tensors and is priced against whichever roof it is closer to
+        peak = 2500.0
+        gbs = nbytes / sec / 1e9
+        if gbs / 8000.0 > ach / peak:
+            bound, unit, ach, peak = "hbm", "GB/s", gbs, 8000.0
+    conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
+    return {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
+            "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
+            "avg_launch_us": round(sec / cnt * 1e6, 2),
+            "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
+            "note": unit_note,
+            "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
+                                 "share_of_step": round(conv_t / step_seconds, 3)}}
+
+
+INFER_CONFIGS = {
+    # BASELINE.json configs[3]: options/test/GoPro|HighREV Test_Final_7skip.yml shape (SURVEY.md 8d "Config 4")
+    4: dict(name="HighREV 7-skip sharp-VFI inference", H=512, W=512, T=7, img_chn=6, crop=None,
+            metric="interpolated frames/sec (inference) HighREV 7-skip 512x512 T=7"),
+    # configs[4]: 15-skip at the sensor resolution, the reference's tile grid (val.grids / crop_size 512), PSNR/SSIM tail
+    5: dict(name="HighREV 15-skip sharp-VFI tiled inference + PSNR/SSIM", H=1224, W=1632, T=15, img_chn=6, crop=512,
+            metric="interpolated frames/sec (tiled inference + PSNR/SSIM) HighREV 15-skip 1632x1224 T=15"),
+}
+
+
+def infer_cpu_baseline(args, cfg):
+    """The oracle's forward on the host cores: config 4 whole (B=1, 512x512, T=7); config 5 on ONE of its 12 tiles
+    (512x512, T=15) -- frames/s scaled by 1/12 since every tile costs the same."""
+    from oracle import refid_oracle as O
+    torch.manual_seed(0)
+    P = O.make_params(cfg["img_chn"], mode="init", seed=0)
+    ncpu = os.cpu_count() or 1
+    nthr = min(ncpu, 16)                                    # the train-step sweep's optimum on this host class
+    torch.set_num_threads(nthr)
+    side = 512
+    x, ev, _ = O.make_inputs(1, cfg["T"], side, side, cfg["img_chn"], seed=1, mode="rng")
+    with torch.no_grad():
+        O.forward(P, x[..., :128, :128].contiguous(), ev[:, :2, :, :128, :128].contiguous())       # warm-up (allocator, threads)
+        times = []
+        t_begin = time.perf_counter()
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.forward(P, x, ev)
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_begin > args.cpu_budget * 0.5:
+                break
+    med = sorted(times)[len(times) // 2]
+    tiles = 1
+    if cfg["crop"]:
+        from refid_amd.tiling import grid_indices
+        tiles = len(grid_indices(cfg["H"], cfg["W"], cfg["crop"])[0])
+    return {"value": round(cfg["T"] / (med * tiles), 4), "unit": "frames/s", "cores": nthr, "kind": "port",
+            "sample": f"oracle forward (no_grad), B=1, 512x512, T={cfg['T']}, fp32, median of {len(times)} at {nthr} threads "
+                      f"({med:.2f} s per pass)" + (f"; one of the {tiles} tiles, value = T / ({tiles} x pass)" if tiles > 1 else "") +
+                      f"; host: {ncpu} logical CPUs, {_cpu_model()}"}
+
+
+def infer_main(args, model, dev, rank, world, use_dist, sync):
+    """--mode infer: `test()` (eval, no_grad, no BPTT stash) of one sample per step; config 5 through the tile grid with the
+    tiles rank-strided over the ranks and the PSNR / SSIM validation tail (GPU kernels, one small D2H) in the step."""
+    from refid_amd import engine as _engine, ops
+    from refid_amd.metrics import calculate_psnr_frames, calculate_ssim_frames
+    from refid_amd.tiling import grid_indices, tiled_forward
+    cfg = INFER_CONFIGS[args.config]
+    H, W, T = cfg["H"], cfg["W"], cfg["T"]
+    g = torch.Generator(device=dev).manual_seed(7 + args.config)
+    x = torch.rand(1, 2, 3, H, W, generator=g, device=dev)
+    gt = torch.rand(1, T, 3, H, W, generator=g, device=dev)
+    v = torch.clamp(torch.round(torch.randn(1, T, 2, H, W, generator=g, device=dev) * 8) / 8, -4, 4)
+    ev = torch.where(torch.rand(1, T, 2, H, W, generator=g, device=dev) < 0.85, torch.zeros_like(v), v)
+    del v
+    net = model.net_g
+    tiles = len(grid_indices(H, W, cfg["crop"])[0]) if cfg["crop"] else 1
+    metrics = {}
+
+    def one():
+        if cfg["crop"] is None:
+            model.feed_data({"lq": x, "voxel": ev})
+            model.test()                                        # twoImage_event_recurrent_model.py:312-330
+            return model.output
+        net.eval()
+        out = tiled_forward(net, x, ev, crop=cfg["crop"], max_minibatch=args.max_minibatch, rank=rank, world=world)
+        net.train()
+        if rank == 0:                                           # validation runs on rank 0 only (:348-355)
+            metrics["psnr"] = calculate_psnr_frames(out[0], gt[0])
+            metrics["ssim"] = calculate_ssim_frames(out[0], gt[0])
+        return out
+
+    for _ in range(args.warmup):
+        one()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one()
+    sync()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    roof = None
+    if not args.no_roofline:
+        pipeline, _engine.PIPELINE = _engine.PIPELINE, False
+        if rank == 0:
+            ops.PROFILE = []
+        one()
+        torch.cuda.synchronize()
+        _engine.PIPELINE = pipeline
+        if rank == 0:
+            prof, ops.PROFILE = ops.PROFILE, None
+            roof = roofline_from_profile(prof, dt / args.steps, args.dtype,
+                                         "per-kernel timing from one extra single-stream inference pass")
+    if use_dist:
+        torch.distributed.barrier()
+    if rank == 0:
+        frames = T * args.steps
+        out = {"metric": cfg["metric"], "value": round(frames / dt, 3), "unit": "frames/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+               "ms_per_frame": round(dt / frames * 1e3, 3), "higher_is_better": True,
+               "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+               "dtype": {"fp32": "f32", "bf16x3": "f32 tensors, 3 bf16 products", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+               "rccl_ranks": world if use_dist else 0,
+               "config": {"workload": f"{cfg['name']}, B=1, {W}x{H}, T={T}, img_chn={cfg['img_chn']}, {args.dtype} "
+                                      f"(BASELINE configs[{args.config - 1}])" +
+                                      (f", {tiles} tiles of {cfg['crop']}x{cfg['crop']} (max_minibatch {args.max_minibatch}), "
+                                       f"rank-strided over {world} rank(s)" if cfg["crop"] else ""),
+                          "global_batch": 1, "parallelism": f"tiles over {world} rank(s)" if cfg["crop"] else "replica"}}
+        if metrics:
+            out["config"]["psnr_mean_dB"] = round(sum(metrics["psnr"]) / len(metrics["psnr"]), 4)
+            out["config"]["ssim_mean"] = round(sum(metrics["ssim"]) / len(metrics["ssim"]), 6)
+        if roof is not None:
+            out["roofline"] = roof
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = infer_cpu_baseline(args, cfg)
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        torch.distributed.destroy_process_group()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -167,6 +376,14 @@ def parse_args(argv=None):
                     help="1: time the CPU baseline on all T frames (the contract's B=1, T=23 configuration); 0: on the "
                          "--cpu-frames sample only")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--h2d", choices=["prefetch", "resident"], default="prefetch",
+                    help="prefetch: pinned host batches, side-stream host->device copy of step k+1 during step k, feed_data in "
+                         "the timed loop (the reference's CUDAPrefetcher); resident: feed once before the loop")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train")
+    ap.add_argument("--config", type=int, choices=[4, 5], default=4,
+                    help="--mode infer: 4 = BASELINE configs[3] (512x512, T=7), 5 = configs[4] (1224x1632, T=15, tiled)")
+    ap.add_argument("--max-minibatch", dest="max_minibatch", type=int, default=2,
+                    help="--mode infer --config 5: tiles per forward call (val.max_minibatch)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak runs: skip the extra strong-scaling timing")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the step from captured hipGraphs (auto = off: measured slower than eager launches)")
@@ -287,33 +504,68 @@ def main(argv=None):
         model.net_g.notify_params_changed()
 
     it = 0
+    h2d = {"exposed_ms": None}
+
+    class _HostBatches:
+        """Endless re-iterable of synthetic batches that live in pinned host memory (what a DataLoader with
+        pin_memory: true hands to the prefetcher); two distinct batches alternate."""
+
+        def __init__(self, per_gpu_batch):
+            self.batches = []
+            for k in range(2):
+                x, ev, gt = synthetic_batch(per_gpu_batch, args.T, args.size, args.size, args.img_chn, 100 + rank + 1000 * k, dev)
+                self.batches.append({"lq": x.cpu().pin_memory(), "voxel": ev.cpu().pin_memory(), "gt": gt.cpu().pin_memory()})
+                del x, ev, gt
+
+        def __iter__(self):
+            k = 0
+            while True:
+                yield dict(self.batches[k % 2])
+                k += 1
 
     def timed(per_gpu_batch, steps, warmup):
         """W warm-up steps, then K steps bracketed by barrier + device sync; MAX over ranks."""
         nonlocal it
+        pre = None
         if not args.dry_run:
-            x, ev, gt = synthetic_batch(per_gpu_batch, args.T, args.size, args.size, args.img_chn, 100 + rank, dev)
-            model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+            if args.h2d == "prefetch":
+                from refid_amd.data import CUDAPrefetcher
+                pre = CUDAPrefetcher(_HostBatches(per_gpu_batch), device=dev)
+            else:
+                x, ev, gt = synthetic_batch(per_gpu_batch, args.T, args.size, args.size, args.img_chn, 100 + rank, dev)
+                model.feed_data({"lq": x, "voxel": ev, "gt": gt})
             use_graph = args.graph == "on"      # auto: eager (measured r02: replay 164 -> 171 ms at B=1; the GPU is the limiter)
             if hasattr(model, "set_graph_mode"):
                 model.set_graph_mode(use_graph)
-        for _ in range(warmup):
+
+        def one():
+            nonlocal it
             it += 1
+            if pre is not None:
+                model.feed_data(pre.next())       # train.py:217-232: prefetcher.next() -> feed_data -> optimize_parameters
             model.update_learning_rate(it)
             model.optimize_parameters(it)
+
+        for _ in range(warmup):
+            one()
         sync()
+        if pre is not None:
+            pre.exposed_ms()                      # (clears the warm-up's records)
         t0 = time.perf_counter()
         for _ in range(steps):
-            it += 1
-            model.update_learning_rate(it)
-            model.optimize_parameters(it)
+            one()
         sync()
         dt = time.perf_counter() - t0
+        if pre is not None:
+            h2d["exposed_ms"] = round(pre.exposed_ms() / max(1, steps), 4)
         if use_dist:
             tt = torch.tensor([dt], dtype=torch.float64, device=dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             dt = float(tt.item())
         return dt
+
+    if args.mode == "infer":
+        return infer_main(args, model, dev, rank, world, use_dist, sync)
 
     per_gpu = args.batch if args.scaling == "weak" else args.batch // world
     dt = timed(per_gpu, args.steps, args.warmup)
@@ -342,75 +594,10 @@ def main(argv=None):
         _engine.PIPELINE = pipeline
         if rank == 0:
             prof, ops.PROFILE = ops.PROFILE, None
-            agg = {}
-            for name, fl, e0, e1, _shape, nb in prof:
-                a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
-                a[0] += fl; a[1] += e0.elapsed_time(e1) * 1e-3; a[2] += 1; a[3] += nb
-            name, (fl, sec, cnt, nbytes) = max(agg.items(), key=lambda kv: kv[1][1])
-            # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-            # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
-            traffic = None
-            import glob
-            suffix = {"fp32": "", "bf16": "_bf16"}.get(args.dtype)
-            pats = [] if suffix is None else sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")),
-                                                    reverse=True)
-            for path in pats:
-                try:
-                    table = json.load(open(path))
-                except (OSError, ValueError):
-                    continue
-                rec = table.get(name)
-                if rec:
-                    traffic = rec["hbm_bytes_per_launch"]
-                    break
-                inst = [v for k, v in table.items() if k.startswith(name + "<")]      # template instances of the same kernel
-                if inst and not name.startswith("conv_split_kernel<"):
-                    traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in inst) / sum(v["launches"] for v in inst))
-                    break
-                if name.startswith("conv_split_kernel<"):
-                    # the event timing groups the split tile by its product count; rocprof names the template instances
-                    # <MT, NT, planes, KS, mode>: launch-weighted mean over the instances with that many planes
-                    planes = {"1": 1, "3": 2, "6": 3}[name[len("conv_split_kernel<"):-1]]
-                    rows = [v for k, v in table.items() if k.startswith("conv_split_kernel<") and
-                            int(k[len("conv_split_kernel<"):-1].split(",")[2]) == planes]
-                    if rows:
-                        traffic = int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows) /
-                                      sum(v["launches"] for v in rows))
-                        break
-            # Winograd F(2x2,3x3) executes 16/36 of the direct convolution's multiplies on the matrix
-            # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
-            # the SURVEY 8(d) direct-convolution figure beside it.
-            executed = fl * (16.0 / 36.0) if "wino" in name else fl
-            peak = FP32_MFMA_PEAK_TFLOPS
-            ach = executed / sec / 1e12
-            bound, unit = "mfma", "TFLOP/s"
-            if "wino6" in name:
-                # Winograd-domain products as six bf16 MFMAs each (exact three-plane operand split): issued FLOPs on the
-                # bf16 matrix pipe = direct x 16/36 x 6
-                executed = fl * (16.0 / 36.0) * 6.0
-                ach = executed / sec / 1e12
-            if "split" in name:
-                # split-bf16 tile: `terms` bf16 MFMAs per direct-conv multiply (+ 1/9 for the zero tenth tap of its tap pairs)
-                executed = fl * int(name.split("<")[1].split(">")[0]) * 10.0 / 9.0
-                ach = executed / sec / 1e12
-            if "bf16" in name or "split" in name or "wino6" in name:
-                # bf16 matrix-core operands: the dense bf16 MFMA peak is 2.5 PFLOP/s (MI355X_MICROARCH.md); such a
-                # tile streams fp32 tensors and is priced against whichever roof it is closer to
-                peak = 2500.0
-                gbs = nbytes / sec / 1e9
-                if gbs / 8000.0 > ach / peak:
-                    bound, unit, ach, peak = "hbm", "GB/s", gbs, 8000.0
-            conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
-            roof = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
-                    "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
-                    "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
-                    "avg_launch_us": round(sec / cnt * 1e6, 2),
-                    "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
-                    "note": "per-kernel timing from one extra single-stream step (kernels run alone; the timed steps "
-                            "overlap wgrad kernels on a side stream); rocprof counterpart: "
-                            "profiles/*_nooverlap_kernel_stats.csv",
-                    "all_gemm_kernels": {"direct_conv_equivalent_tflops": round(conv_fl / conv_t / 1e12, 2),
-                                         "share_of_step": round(conv_t / (dt / args.steps), 3)}}
+            roof = roofline_from_profile(prof, dt / args.steps, args.dtype,
+                                         "per-kernel timing from one extra single-stream step (kernels run alone; the timed "
+                                         "steps overlap wgrad kernels on a side stream); rocprof counterpart: "
+                                         "profiles/*_nooverlap_kernel_stats.csv")
 
     strong = None
     if world > 1 and args.scaling == "weak" and not args.no_strong_leg and args.batch % world == 0 and not args.dry_run:
@@ -447,6 +634,10 @@ def main(argv=None):
                                    (" (BASELINE configs[1])" if args.dtype == "fp32" and args.T == 23 and gbatch == 8 * (world if args.scaling == "weak" else 1) else ""),
                        "global_batch": gbatch, "parallelism": f"dp{world}", "loss": round(loss, 6)},
         }
+        if not args.dry_run:
+            out["h2d"] = ("prefetched, in timed region (pinned host batch -> HBM on a side stream during the previous step; "
+                          "feed_data inside the loop)") if args.h2d == "prefetch" else "resident (fed once before the timed region)"
+            out["h2d_ms_exposed"] = h2d["exposed_ms"]
         if pinned:
             out["rank0_cpu_affinity"] = f"{len(pinned)} cores ({pinned[0]}-{pinned[-1]})"
         if args.dry_run:

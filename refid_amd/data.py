@@ -1,4 +1,10 @@
-"""Event voxelisation on the GPU (the step immediately before the hot path).
+"""Host -> device hand-over of a batch and event voxelisation on the GPU (the steps immediately before the hot path).
+
+``CUDAPrefetcher`` mirrors the reference's class of that name (basicsr/data/prefetch_dataloader.py:84-125, selected by
+``prefetch_mode: cuda`` + ``pin_memory: true`` in the dataset options, train.py:197-205): batch k+1 travels host -> HBM on a
+side stream while step k computes; ``next()`` makes the compute stream wait for the copy and starts the following one.
+
+Event voxelisation:
 
 Mirrors ``events_to_voxel_grid(events, num_bins, width, height)`` of the reference
 (basicsr/data/event_util.py:6-66; events = [N x 4] rows of [timestamp, x, y, polarity], sorted by
@@ -40,3 +46,64 @@ def sliding_bin_pairs(voxel):
     """(bins,H,W) -> (bins-1, 2, H, W): adjacent-bin pairs fed to the network as `event`
     (image_npy_dataset.py:226-232)."""
     return torch.stack([voxel[:-1], voxel[1:]], dim=1)
+
+
+class CUDAPrefetcher:
+    """prefetch_dataloader.py:84-125.  ``loader`` is any re-iterable of dict batches whose tensors live in (preferably
+    pinned) host memory; ``next()`` returns the batch on the device, or None at the end of an epoch; ``reset()`` starts
+    the next epoch.  Additions over the reference: the returned tensors are tied to the consumer stream
+    (``record_stream``: the caching allocator must not hand their memory to the NEXT copy while the step still reads
+    them), and the time the compute stream actually had to wait for a copy is measured with events
+    (``exposed_ms()``)."""
+
+    def __init__(self, loader, opt=None, device=None):
+        self.ori_loader = loader
+        self.loader = iter(loader)
+        self.opt = opt
+        if device is None:
+            device = torch.device("cuda" if (opt or {}).get("num_gpu", 1) != 0 else "cpu")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RefidHipError("CUDAPrefetcher: a GPU device is required (the HIP path has no CPU fallback)")
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._waits = []                     # (event before the wait, event after it) on the consumer stream
+        self.preload()
+
+    def preload(self):
+        try:
+            self.batch = next(self.loader)
+        except StopIteration:
+            self.batch = None
+            return None
+        with torch.cuda.stream(self.stream):
+            self.batch = {k: (v.to(device=self.device, non_blocking=True) if torch.is_tensor(v) else v)
+                          for k, v in self.batch.items()}
+
+    def next(self):
+        cur = torch.cuda.current_stream(self.device)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        cur.wait_stream(self.stream)
+        e1.record(cur)
+        self._waits.append((e0, e1))
+        batch = self.batch
+        if batch is not None:
+            for v in batch.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
+        self.preload()
+        return batch
+
+    def reset(self):
+        self.loader = iter(self.ori_loader)
+        self.preload()
+
+    def exposed_ms(self, clear=True):
+        """Total time (ms) the consumer stream spent waiting for host -> device copies since the last call
+        (synchronises the device)."""
+        torch.cuda.synchronize(self.device)
+        t = sum(a.elapsed_time(b) for a, b in self._waits)
+        if clear:
+            self._waits = []
+        return t

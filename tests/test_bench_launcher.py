@@ -67,3 +67,38 @@ def test_more_ranks_than_devices_is_an_error():
     r = _run(["--gpus", str(n), "--steps", "1", "--warmup", "0"])
     assert r.returncode != 0 and "refusing to run fewer ranks" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_train_line_feeds_data_inside_the_timed_region():
+    """The reference's hot loop is prefetcher.next() -> feed_data -> optimize_parameters (train.py:217-232,
+    data/prefetch_dataloader.py:84-125): the default bench run keeps the batches in pinned host memory and prefetches."""
+    base = ["--steps", "2", "--warmup", "1", "--batch", "1", "--T", "3", "--size", "64", "--no-cpu-baseline"]
+    r = _run(base)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["h2d"].startswith("prefetched, in timed region") and out["h2d_ms_exposed"] is not None
+    assert out["h2d_ms_exposed"] >= 0.0 and out["value"] > 0 and "roofline" in out
+    r2 = _run(base + ["--h2d", "resident"])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    out2 = _json_line(r2.stdout)
+    assert out2["h2d"].startswith("resident") and out2["h2d_ms_exposed"] is None
+    # both protocols feed the same kind of data to the same step: the loss of the last step is of the same size
+    assert abs(out["config"]["loss"] - out2["config"]["loss"]) < 0.2 * abs(out2["config"]["loss"])
+
+
+@pytest.mark.gpu
+def test_inference_bench_modes():
+    """bench.py --mode infer --config 4|5: BASELINE configs[3] / configs[4] (`test()`, twoImage_event_recurrent_model.py:
+    312-330; config 5 through the tile grid + PSNR/SSIM tail)."""
+    r = _run(["--mode", "infer", "--config", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert "configs[3]" in out["config"]["workload"] and "512x512" in out["config"]["workload"]
+    assert out["unit"] == "frames/s" and out["value"] > 0 and abs(out["ms_per_frame"] * 7 - out["ms_per_step"]) < 0.1
+    assert out["roofline"]["kernel"] and 0 < out["roofline"]["frac"] < 1
+    r = _run(["--mode", "infer", "--config", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert "configs[4]" in out["config"]["workload"] and "12 tiles" in out["config"]["workload"]
+    assert out["config"]["psnr_mean_dB"] > 0 and 0 < out["config"]["ssim_mean"] < 1

@@ -77,10 +77,11 @@ def synthetic_batch(B, T, H, W, img_chn, seed, device):
 
 
 def options(args):
-    if args.mode == "infer":
+    mode = getattr(args, "mode", "train")                  # (tools/profile_step.py passes its own minimal namespace)
+    if mode == "infer":
         args.img_chn = INFER_CONFIGS[args.config]["img_chn"]
     return {
-        "name": "bench", "is_train": args.mode == "train", "num_gpu": 1,
+        "name": "bench", "is_train": mode == "train", "num_gpu": 1,
         "network_g": dict(type="FinalBidirectionAttenfusion", img_chn=args.img_chn, ev_chn=2, num_encoders=3,
                           base_num_channels=32, num_block=1, num_residual_blocks=2, compute_dtype=args.dtype),
         "path": {"pretrain_network_g": None},

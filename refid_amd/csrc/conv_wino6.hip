@@ -30,6 +30,7 @@
 //   * the raw halo of chunk c+2 is requested at the top of chunk c (global -> VGPR -> LDS, double buffered).
 #include "common.h"
 #include "conv_args.h"
+#include <algorithm>
 #include <cstdlib>
 
 #ifndef REFID_WINO6_ABLATE
@@ -41,13 +42,14 @@ namespace {
 constexpr int TW = 32;                  // output pixels per workgroup row
 constexpr int KC = 16;                  // input channels per chunk = K of one bf16 MFMA
 constexpr int HWD = TW + 2;             // halo pixels per row
-constexpr int TH = 4, BN = 64;
+constexpr int TH = 4;                   // (output channels per workgroup: 32 * NT, NT = 32-channel column tiles per wave)
 constexpr int ROWP = 40;                // LDS slots per halo row: even columns at 0..16, odd columns at 20..36
 constexpr int PLANE = 6 * ROWP + 5;     // slots per channel-quad plane (245: plane pitch 980 dwords = 20 mod 32)
 constexpr int R_F4 = 4 * PLANE;         // one raw halo buffer: [quad][row][slot] float4
 constexpr int HP = (TH + 2) * HWD;      // 204 halo pixels
 constexpr int R_ITEMS = (4 * HP + 255) / 256;
-constexpr int LDS_BYTES = 64 * 66 * 16; // 2 raw buffers (31 KB) in the K loop; 66 KB row exchange afterwards
+// 2 raw buffers (31 KB) in the K loop; afterwards the row exchange: 66 KB for 64 output channels, 33 KB for 32
+constexpr int lds_bytes(int nt) { return nt == 2 ? 64 * 66 * 16 : (32 * 66 * 16 > 2 * R_F4 * 16 ? 32 * 66 * 16 : 2 * R_F4 * 16); }
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -69,7 +71,13 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (
     pl[2] = __builtin_bit_cast(f32x4, p2);
 }
 
-__global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
+// NT = 2: 64 output channels per workgroup (8 accumulators per wave, two workgroups per CU).
+// NT = 1: the 32-output-channel layers (decoder 2's trunk, the input gradient of level 0's first conv; round 4 -- they ran
+//         on the fp32 Winograd tile at 0.36 of the fp32 roof): 4 accumulators per wave, three workgroups per CU; every V
+//         split feeds 6 instead of 12 MFMAs, so this form is vector-issue bound -- and still well ahead of 64 fp32 MFMAs.
+template <int NT>
+__global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const ConvKArgs a) {
+    constexpr int BN = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sR = reinterpret_cast<f32x4*>(smem);            // two raw halo buffers
 
@@ -120,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
         sdst[it] = hp < HP ? q * PLANE + row * ROWP + (col >> 1) + (col & 1) * 20 : q * PLANE + 6 * ROWP + (tid & 3);
     }
     // U fragments of this lane: rows (cout) n0 + nt*32 + li, channels 8kh .. 8kh+7
-    int voU[2];
+    int voU[NT];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
         const int urow = a.coBase + n0 + nt * 32 + li;
         voU[nt] = (urow < a.CoutPad) ? (urow * KC + kh * 8) * 2 + ti * 4 * uXi : OOB;
         if (REFID_WINO6_ABLATE == 12) voU[nt] = ti * 4 * uXi;
@@ -161,25 +169,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
         for (int it = 0; it < R_ITEMS; ++it) sR[buf * R_F4 + sdst[it]] = src[it];
     };
     // fragments of column j of chunk ch: [plane][nt]
-    auto load_u = [&](int ch, int j, f32x4 (&dst)[3][2]) {
+    auto load_u = [&](int ch, int j, f32x4 (&dst)[3][NT]) {
         // (the hardware range check covers the vector offset only: a chunk past the range must not travel as a scalar offset)
         const bool in = ch < kc1;
         const int so = (REFID_WINO6_ABLATE == 1 ? 0 : ch) * uChunk + j * uXi;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                if (REFID_WINO6_ABLATE == 13 && nt == 1) { dst[p][1] = dst[p][0]; continue; }
+            for (int nt = 0; nt < NT; ++nt) {
+                if (REFID_WINO6_ABLATE == 13 && nt == 1) { dst[p][nt] = dst[p][0]; continue; }
                 dst[p][nt] = __builtin_bit_cast(
                     f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, in ? voU[nt] : OOB, in ? so + p * uPlane : 0, 0));
             }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NT];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
 
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     constexpr int TA[6] = {0, 0, 1, 0, 2, 1};              // products kept: (V plane, U plane), largest first
     constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
 
-    f32x4 uA[3][2], uB[3][2];
+    f32x4 uA[3][NT], uB[3][NT];
     auto phase = [&](int ch) {
         const int lc = ch - kc0;
         if (REFID_WINO6_ABLATE != 7 && REFID_WINO6_ABLATE != 8) {
@@ -214,8 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
             for (int b = 0; b < 4; ++b) t[qq][b] = r[qq * PLANE + offP + BOFF[b]] + r[qq * PLANE + offM + BOFF[b]] * sgn;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x4 (&cur)[3][2] = (j & 1) ? uB : uA;
-            f32x4 (&nxt)[3][2] = (j & 1) ? uA : uB;
+            f32x4 (&cur)[3][NT] = (j & 1) ? uB : uA;
+            f32x4 (&nxt)[3][NT] = (j & 1) ? uA : uB;
             if (REFID_WINO6_ABLATE != 6 && REFID_WINO6_ABLATE != 8) load_u(j == 3 ? ch + 1 : ch, (j + 1) & 3, nxt);
 #ifdef REFID_WINO6_PIN
             __builtin_amdgcn_sched_barrier(0x38F);         // vector-memory instructions stay where they are written
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
 #pragma unroll
             for (int e = 0; e < 6; ++e)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)             // consecutive MFMAs hit different accumulators
+                for (int nt = 0; nt < NT; ++nt)            // consecutive MFMAs hit different accumulators
                     acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                         __builtin_bit_cast(bf16x8, cur[TB[e]][nt]), __builtin_bit_cast(bf16x8, pl[TA[e]]), acc[j][nt], 0, 0, 0);
         }
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     constexpr int XL = 66;
     f32x4* xch = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             f32x4 r0, r1;
@@ -268,36 +276,41 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
                 r0[k] = acc[0][t][r] + acc[1][t][r] + acc[2][t][r];
                 r1[k] = acc[1][t][r] - acc[2][t][r] - acc[3][t][r];
             }
-            xch[(((ti * 2 + 0) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r0;
-            xch[(((ti * 2 + 1) * 2 + t) * 4 + rq) * XL + kh * 33 + li] = r1;
+            xch[(((ti * 2 + 0) * NT + t) * 4 + rq) * XL + kh * 33 + li] = r0;
+            xch[(((ti * 2 + 1) * NT + t) * 4 + rq) * XL + kh * 33 + li] = r1;
         }
-    // ---- fused epilogue, COALESCED: thread -> (output pixel, channel quad) in memory order.  Item it of a thread is pixel
-    // (row it >> 1, column 16 (it & 1) + (tid >> 4)) of the 4 x 32 tile and ALWAYS channel quad tid & 15: the addresses are
+    // ---- fused epilogue, COALESCED: thread -> (output pixel, channel quad) in memory order.  A pass of the 256 threads covers
+    // PPT = 256 / (BN / 4) consecutive pixels of a row x all BN channels (16 pixels x 64 channels, or 32 x 32); item it of a
+    // thread is pixel (row it / CPR, column PPT (it % CPR) + p0) and ALWAYS the thread's own channel quad: the addresses are
     // one 64-bit base per tensor and thread plus workgroup-uniform steps (a generic (n, oy, ox) -> offset product per item
     // was 160 quarter-rate integer multiplies per tile -- as much vector-issue time as the K loop at 64 input channels).
-    constexpr int NIT = (TH * TW * (BN / 4)) / 256;        // 8
-    static_assert(BN / 4 == 16 && TW == 32 && NIT == 8, "epilogue item mapping");
-    const int p0 = tid >> 4, c = (tid & 15) * 4;
+    constexpr int QUADS = BN / 4, PPT = 256 / QUADS, CPR = TW / PPT;        // 16 / 16 / 2   or   8 / 32 / 1
+    constexpr int NIT = TH * CPR;                                           // 8 or 4
+    static_assert(TW == 32 && (NT == 1 || NT == 2) && PPT * CPR == TW, "epilogue item mapping");
+    constexpr int TI_STRIDE = 2 * NT * 4 * XL;             // exchange slots between transform rows i and i + 1
+    const int p0 = tid / QUADS, c = (tid % QUADS) * 4;
     const int j0 = n0 + c;
     const int nt = c >> 5, rq = (c & 31) >> 3, ckh = (c & 7) >> 2;
     const long long opb = (long long)(n * a.Ho + oy0) * a.Wo + ox0 + p0;
     const bool jok = j0 < a.Cout;
     const bool vec = a.vecOK && (j0 + 3 < a.Cout);
-    const bool cok[2] = {ox0 + p0 < a.Wo, ox0 + 16 + p0 < a.Wo};
+    bool cok[CPR];
+#pragma unroll
+    for (int q2 = 0; q2 < CPR; ++q2) cok[q2] = ox0 + q2 * PPT + p0 < a.Wo;
     float* const outB = a.out + (a.ksplit > 1 ? blockIdx.y * a.wsStride : 0) + opb * a.ldO + j0;
     const float* const resB = a.res ? a.res + opb * a.ldR + j0 : nullptr;
     const float* const mskB = a.mask ? a.mask + opb * a.ldM + j0 : nullptr;
-    const int stepO[2] = {a.Wo * a.ldO, 16 * a.ldO}, stepR[2] = {a.Wo * a.ldR, 16 * a.ldR}, stepM[2] = {a.Wo * a.ldM, 16 * a.ldM};
+    const int stepO[2] = {a.Wo * a.ldO, PPT * a.ldO}, stepR[2] = {a.Wo * a.ldR, PPT * a.ldR}, stepM[2] = {a.Wo * a.ldM, PPT * a.ldM};
     const bool pre = REFID_WINO6_ABLATE != 4 && REFID_WINO6_ABLATE != 10 && vec && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
     f32x4 pres[NIT], pmask[NIT];
     if (pre) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const bool ok = (oy0 + (it >> 1) < a.Ho) && cok[it & 1];
+            const bool ok = (oy0 + it / CPR < a.Ho) && cok[it % CPR];
             pres[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             pmask[it] = f32x4{1.f, 1.f, 1.f, 1.f};
-            if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(resB + (it >> 1) * stepR[0] + (it & 1) * stepR[1]);
-            if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(mskB + (it >> 1) * stepM[0] + (it & 1) * stepM[1]);
+            if (ok && a.res) pres[it] = *reinterpret_cast<const f32x4*>(resB + (it / CPR) * stepR[0] + (it % CPR) * stepR[1]);
+            if (ok && a.mask) pmask[it] = *reinterpret_cast<const f32x4*>(mskB + (it / CPR) * stepM[0] + (it % CPR) * stepM[1]);
         }
     }
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};                        // the same four output channels for all of a thread's items
@@ -312,13 +325,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int row = it >> 1, colb = it & 1;
-        const int col = colb * 16 + p0;
+        const int row = it / CPR, colb = it % CPR;
+        const int col = colb * PPT + p0;
         const int oa = row & 1, tile = ((row & 3) >> 1) * 16 + (col >> 1), ob = col & 1;
         if (oy0 + row >= a.Ho || !cok[colb] || !jok) continue;
-        const f32x4* xp = xch + (((oa * 2 + ob) * 2 + nt) * 4 + rq) * XL + ckh * 33 + tile;   // row i0 = oa
+        const f32x4* xp = xch + (((oa * 2 + ob) * NT + nt) * 4 + rq) * XL + ckh * 33 + tile;   // row i0 = oa
         const float sg = oa ? -1.f : 1.f;                   // a=0: R0+R1+R2 ; a=1: R1-R2-R3
-        f32x4 v = xp[0] + (xp[16 * XL] + xp[32 * XL]) * sg;
+        f32x4 v = xp[0] + (xp[TI_STRIDE] + xp[2 * TI_STRIDE]) * sg;
         float* const outp = outB + row * stepO[0] + colb * stepO[1];
         if (a.ksplit > 1) {                                 // raw partial sums; the finishing pass applies the epilogue
             *reinterpret_cast<f32x4*>(outp) = v;
@@ -353,15 +366,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino6_kernel(const ConvKArgs a) {
     }
 }
 
-struct Wino6Plan { int ks; dim3 grid; };
+struct Wino6Plan { int ks; int nt; dim3 grid; };
 
 // same small-grid policy as the fp32 tile (conv_wino.hip::wino_plan), in chunks of 16 channels
-Wino6Plan wino6_plan(ConvKArgs& a, int split_mode) {
+Wino6Plan wino6_plan(ConvKArgs& a, int split_mode, int tile_hint = 0) {
     Wino6Plan p;
+    // (tile_hint 4, an experiment switch: the 32-channel form for every layer -- three instead of two workgroups per CU,
+    //  twice the V transforms / splits per product)
+    p.nt = (a.Cout > 32 && tile_hint != 4) ? 2 : 1;
+    const int bn = 32 * p.nt;
     a.tilesX = cdiv(a.Wo, TW);
     a.tilesY = cdiv(a.Ho, TH);
     a.nchunks = cdiv(a.Ctot, KC);
-    a.ncot = cdiv(a.Cout, BN);
+    a.ncot = cdiv(a.Cout, bn);
     p.grid = dim3(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
     const int nwg = (split_mode == 2) ? (int)p.grid.x : a.tilesX * a.tilesY * a.ncot * 8;   // "sample": as if N = 8
     int ks = 1;
@@ -375,43 +392,49 @@ Wino6Plan wino6_plan(ConvKArgs& a, int split_mode) {
     return p;
 }
 
+template <int NT>
+int launch_wino6(const ConvKArgs& a, dim3 grid, hipStream_t st, const char* what) {
+    static std::atomic<unsigned long long> done{0};
+    if (int rc = refid_lds_attr_once(done, &conv_wino6_kernel<NT>, lds_bytes(NT), "conv_wino6")) return rc;
+    hipLaunchKernelGGL(conv_wino6_kernel<NT>, grid, dim3(256), lds_bytes(NT), st, a);
+    REFID_LAUNCH_CHECK(what);
+    return 0;
+}
+
 }  // namespace
 
 bool refid_wino6_eligible(const ConvKArgs& a) {
     const long long lim = 0x7fffffffLL;
-    return a.Cout > 32 && a.Ctot % 4 == 0 && (a.inB == nullptr || a.Ca % KC == 0) &&
+    return a.Cout >= 8 && a.Ctot % 4 == 0 && (a.inB == nullptr || a.Ca % KC == 0) &&
            (long long)a.N * a.H * a.W * a.ldA * 4 < lim && (!a.inB || (long long)a.N * a.H * a.W * a.ldB * 4 < lim) &&
            (long long)cdiv(a.Ctot, KC) * 16 * 3 * a.CoutPad * KC * 2 < lim;
 }
 
 size_t refid_wino6_workspace_bytes(const ConvKArgs& ka, int split_mode) {
-    ConvKArgs a = ka;
-    const Wino6Plan p = wino6_plan(a, split_mode);
-    if (p.ks == 1) return 0;
-    return (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float);
+    size_t need = 0;
+    for (int hint = 0; hint <= 4; hint += 4) {             // either tile form may be asked for (wino_tile = 4): the larger need
+        ConvKArgs a = ka;
+        const Wino6Plan p = wino6_plan(a, split_mode, hint);
+        if (p.ks > 1) need = std::max(need, (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float));
+    }
+    return need;
 }
 
 int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
     ConvKArgs a = ka;
     REFID_CHECK(refid_wino6_eligible(a),
-                "conv2d: the Winograd six-product tile needs more than 32 output channels, channel counts that are multiples "
+                "conv2d: the Winograd six-product tile needs at least 8 output channels, channel counts that are multiples "
                 "of 4 (two sources: c_a a multiple of 16) and tensors below 2 GiB");
     // Wide tile (experimental/conv_wino6w.hip: 8x32 pixels, 8 waves, weight fragments shared through an LDS ring, same
     // bits): measured 0-10 % slower, only in libraries built with REFID_EXPERIMENTAL_TILES=1 and only on request
     // (refid_conv_desc.wino_tile = 3)
 #ifdef REFID_EXPERIMENTAL_TILES
-    if (tile_hint == 3) return refid_launch_wino6w(a, 1, st);
+    if (tile_hint == 3 && a.Cout > 32) return refid_launch_wino6w(a, 1, st);
 #endif
-    const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0);
+    const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0, tile_hint);
     dim3 grid = pl.grid;
-    static std::atomic<unsigned long long> done{0};
-    if (int rc = refid_lds_attr_once(done, &conv_wino6_kernel, LDS_BYTES, "conv_wino6")) return rc;
     const int ks = pl.ks;
-    if (ks == 1) {
-        hipLaunchKernelGGL(conv_wino6_kernel, grid, dim3(256), LDS_BYTES, st, a);
-        REFID_LAUNCH_CHECK("conv_wino6");
-        return 0;
-    }
+    if (ks == 1) return pl.nt == 2 ? launch_wino6<2>(a, grid, st, "conv_wino6") : launch_wino6<1>(a, grid, st, "conv_wino6/32");
     const long long npix = (long long)a.N * a.Ho * a.Wo;
     const int ldW = round_up(a.Cout, 4);
     const size_t need = (size_t)ks * npix * ldW * sizeof(float);
@@ -423,8 +446,8 @@ int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int spli
     ConvKArgs p = a;                       // partial pass: raw sums into the workspace
     p.ksplit = ks; p.wsStride = npix * ldW; p.out = ws; p.ldO = ldW;
     grid.y = ks;
-    hipLaunchKernelGGL(conv_wino6_kernel, grid, dim3(256), LDS_BYTES, st, p);
-    REFID_LAUNCH_CHECK("conv_wino6/splitk");
+    if (int rc = pl.nt == 2 ? launch_wino6<2>(p, grid, st, "conv_wino6/splitk") : launch_wino6<1>(p, grid, st, "conv_wino6/32/splitk"))
+        return rc;
     ConvKArgs f = a;
     f.ksplit = ks; f.wsStride = npix * ldW;
     return refid_launch_splitk_finish(f, ws, ldW, npix, st);

@@ -191,6 +191,7 @@ MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
 # bf16 products per fp32 product (refid_conv2d algo 5, csrc/conv_wino6.hip): same error class as the fp32 Winograd tile at
 # 2.67x fewer matrix-pipe cycles.  0 = fp32 Winograd tile everywhere.
 WINO6 = os.environ.get("REFID_WINO6", "1") != "0"
+WINO6_MIN_CO = int(os.environ.get("REFID_WINO6_MIN_CO", "32"))
 # conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
 # fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
 # split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
@@ -345,13 +346,14 @@ class ConvOp:
             if need_dgrad and self.ci > 32:
                 self.wdp6 = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, 3) // 2,
                                         dtype=torch.bfloat16, device=dev)
-        # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T
+        # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T.  From 32 output channels
+        # on (round 4: the tile's 32-channel form; REFID_WINO6_MIN_CO=33 restores round 3's choice for an A/B)
         self.wp6 = self.wd6 = None
-        if WINO6 and not bf16 and self.f_algo == 1 and self.co > 32 and self.ci % 4 == 0 and \
+        if WINO6 and not bf16 and self.f_algo == 1 and self.co >= WINO6_MIN_CO and self.ci % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) < 2 ** 31 - 1:
             self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) // 2,
                                    dtype=torch.bfloat16, device=dev)
-        if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci > 32 and self.co % 4 == 0 and \
+        if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci >= WINO6_MIN_CO and self.co % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) < 2 ** 31 - 1:
             self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) // 2,
                                    dtype=torch.bfloat16, device=dev)
@@ -520,7 +522,7 @@ class ConvOp:
             ops.conv2d(g, self.wds, out, kh=kh, kw=kw, stride=st, pad=1, mode=md, cout=cnt, cout_pad=self.sd_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split)
             return out
-        if self.wd6 is not None and self.split == 0 and cnt > 32:
+        if self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO:
             ops.conv2d(g, self.wd6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=5)
             return out

@@ -233,7 +233,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     if algo == 1:
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
     if algo == 5:
-        name = "conv_wino6_kernel"
+        name = "conv_wino6_kernel<2>" if cout > 32 else "conv_wino6_kernel<1>"     # 64- / 32-channel workgroup tile
     if algo == 4:
         name = "conv_split_kernel<%d>" % (terms or 6)
     if algo == 3:

@@ -329,18 +329,21 @@ def test_winograd_fused_epilogues():
 
 
 # ---------------------------------------------------------------------------------------------
-# Winograd x six bf16 products (algo=5, csrc/conv_wino6.hip): same contract, more than 32 output channels
+# Winograd x six bf16 products (algo=5, csrc/conv_wino6.hip): same contract, 8 output channels or more
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", [
     (2, 16, 32, 32, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 128, 128, 128), (1, 12, 20, 64, 0, 256),
     (1, 5, 3, 64, 0, 64), (1, 7, 33, 32, 0, 96), (1, 9, 17, 36, 0, 64), (1, 8, 32, 16, 16, 64), (1, 6, 10, 8, 0, 40),
     (3, 4, 64, 48, 0, 128), (1, 8, 8, 256, 256, 256),
+    # the 32-output-channel form (round 4: one column tile per wave, three workgroups per CU): decoder 2's trunk shapes,
+    # ragged sizes, a partial channel tile (24, 12 of 32), two sources, a split-K grid (256 -> 32 at 8x8)
+    (2, 16, 32, 32, 0, 32), (1, 24, 40, 32, 32, 32), (1, 7, 33, 64, 0, 24), (1, 5, 3, 36, 0, 12), (1, 8, 8, 256, 0, 32),
 ])
 @pytest.mark.parametrize("tile", [1, 3])
 def test_wino6_forward_geometries(cfg, tile):
     """Ragged tiles, a partial last 16-channel chunk (36, 8, 48 channels), a partial channel tile (96, 40), two sources,
     and a small grid that takes the split-K form (512 -> 256 at 8x8); on the 4-wave tile (1) and the wide 8-wave tile with
-    the LDS-shared weight ring (3)."""
+    the LDS-shared weight ring (3; more than 32 output channels only -- smaller layers stay on the 4-wave tile)."""
     ops = _ops()
     if tile == 3:
         _need_experimental()
@@ -391,6 +394,13 @@ def test_wino6_fused_epilogues(tile):
         run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0, algo=5)
         run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1, algo=5)
         run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True, algo=5)
+        # the 32-output-channel form: decoder 2's trunk (main.0 two-source + LeakyReLU(.1), ReLU, + identity) and its
+        # input gradients (residual + activation mask), a ragged size with a partial channel tile
+        run_wino(1, 16, 32, 32, 32, 32, slope_pre=0.1, algo=5)
+        run_wino(1, 16, 32, 32, 0, 32, slope_pre=0.0, algo=5)
+        run_wino(1, 16, 32, 32, 0, 32, res=True, algo=5)
+        run_wino(1, 8, 32, 32, 0, 32, bias=False, res=True, mask=True, algo=5)
+        run_wino(1, 9, 37, 64, 0, 20, bias=False, res=True, mask=True, slope_post=0.0, algo=5)
     finally:
         ops.WINO_TILE = old
 
@@ -444,10 +454,10 @@ def test_wino6_rejects_bad_arguments():
     ops = _ops()
     from refid_amd._lib import RefidHipError
     x = torch.randn(1, 8, 32, 64, device="cuda")
-    w = torch.randn(32, 64, 3, 3, device="cuda")
-    with pytest.raises(RefidHipError, match="more than 32 output channels"):
-        ops.conv2d(x, ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, 32, 64), torch.empty(1, 8, 32, 32, device="cuda"),
-                   kh=3, kw=3, pad=1, cout=32, cout_pad=64, algo=5)
+    w = torch.randn(4, 64, 3, 3, device="cuda")
+    with pytest.raises(RefidHipError, match="at least 8 output channels"):
+        ops.conv2d(x, ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, 4, 64), torch.empty(1, 8, 32, 4, device="cuda"),
+                   kh=3, kw=3, pad=1, cout=4, cout_pad=64, algo=5)
     w = torch.randn(64, 48, 3, 3, device="cuda")
     xa, xb = torch.randn(1, 8, 32, 24, device="cuda"), torch.randn(1, 8, 32, 24, device="cuda")
     with pytest.raises(RefidHipError, match="multiple of 16"):

@@ -32,7 +32,7 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
     ops.WINO_TILE = 1
     t6n = timeit(lambda: ops.conv2d(a, w6, o6, algo=5, **kw))
     o6n = o6.clone()
-    ops.WINO_TILE = 3 if lib().refid_experimental_tiles() else 0
+    ops.WINO_TILE = 3 if lib().refid_experimental_tiles() else 4
     t6 = timeit(lambda: ops.conv2d(a, w6, o6, algo=5, **kw))
     same = bool(torch.equal(o6, o6n))
     diff = (o1 - o6).abs().max().item()
@@ -47,7 +47,7 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
         ref = ref * torch.where(m[:1, :crop - 2].cpu() > 0, 1.0, 0.2)
     e1 = (o1[:1, :crop - 2].double().cpu() - ref).abs().max().item()
     e6 = (o6[:1, :crop - 2].double().cpu() - ref).abs().max().item()
-    wide = "wide 8-wave tile" if lib().refid_experimental_tiles() else "repeat"
+    wide = "wide 8-wave tile" if lib().refid_experimental_tiles() else "32-channel form"
     print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us | x6 {t6n*1e6:7.1f} us {fl/t6n/1e12:6.1f} TF(eff) x{t1/t6n:4.2f} | x6 {wide} {t6*1e6:7.1f} us "
           f"(same bits: {same}) | x6 vs fp32 {diff:.1e}  err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}", flush=True)
 
@@ -66,3 +66,9 @@ if __name__ == "__main__":
     one("L2 first 128->256 @64", 64, 128, 0, 256)
     one("bottleneck 256->256 @32", 32, 256, 0, 256)
     one("D1 main.0 128->64 @128", 128, 64, 64, 64)
+    # 32 output channels: the tile's one-column-tile form (round 4)
+    one("D2 main.0 64->32 @256", 256, 32, 32, 32)
+    one("D2 res 32->32 @256", 256, 32, 0, 32)
+    one("D2 res 32->32 @256 +res", 256, 32, 0, 32, res=True)
+    one("D2 res dgrad +res +mask", 256, 32, 0, 32, res=True, mask=True)
+    one("L0 first dgrad 64->32 @256", 256, 64, 0, 32)

@@ -31,6 +31,17 @@ def lib_path(v):
     return os.path.join(BIN, f"librefid_w6abl{v}{TAG}.so")
 
 
+def check_fresh(path):
+    """A variant library links the objects of the product build it was made from: refuse one that is older than any
+    kernel source or header (a stale one fails with `undefined symbol` at best and measures yesterday's kernel at worst)."""
+    if not os.path.exists(path):
+        raise SystemExit(f"{path} is missing: run tools/build_probes.sh in the CPU container before gpurun")
+    newest = max(os.path.getmtime(f) for pat in ("refid_amd/csrc/*.hip", "refid_amd/csrc/*.h", "include/*.h")
+                 for f in glob.glob(os.path.join(ROOT, pat)))
+    if os.path.getmtime(path) < newest:
+        raise SystemExit(f"{os.path.basename(path)} is older than the kernel sources: run tools/build_probes.sh again")
+
+
 def build():
     from refid_amd.build import FLAGS, HIPCC, build as build_main
     build_main()
@@ -47,6 +58,7 @@ def build():
 def run(v):
     import torch
     from refid_amd import _lib
+    check_fresh(lib_path(v))
     _lib.LIB_PATH = lib_path(v)
     from refid_amd import ops
     sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -6,6 +6,12 @@
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+# the ablation libraries must have been built from the current sources (tools/build_probes.sh, CPU container)
+python - <<PY || { echo "profile_round: stale or missing probe libraries -- run tools/build_probes.sh first"; exit 1; }
+import sys; sys.path.insert(0, "$R/tools/probes")
+import wino6_ablate as a, wgrad_wino_ablate as b
+a.check_fresh(a.lib_path(0)); b.check_fresh(b.lib_path(0))
+PY
 bash $R/tools/prof_step.sh ${tag}_bench_n1 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 bash $R/tools/prof_step.sh ${tag}_bench_n1_nooverlap --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
 bash $R/tools/prof_step.sh ${tag}_b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
@@ -37,4 +43,15 @@ python tools/probes/wino6_ablate.py > gpurun_out/${tag}_wino6_ablation.txt 2>&1
 tools/probes/bin/wino6_loop > gpurun_out/${tag}_wino6_loop_probe.txt 2>&1
 python tools/grad_error_report.py > gpurun_out/${tag}_grad_error_report.txt 2>&1
 for d in fp32 bf16x3 bf16; do python bench.py --dtype $d --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_$d.json; done
+# GPU busy fraction without a tracer in the timed run: serial kernel time (traced durations) / untraced single-stream step
+REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_single_stream_untraced.json
+python tools/busy_report.py --stats gpurun_out/${tag}_bench_n1_nooverlap_kernel_stats.csv --stat-steps 4 \
+  --single gpurun_out/${tag}_bench_n1_single_stream_untraced.json --default gpurun_out/${tag}_bench_n1_fp32.json > gpurun_out/${tag}_gpu_busy.txt 2>&1
+# inference lines (BASELINE configs[3] / configs[4])
+python bench.py --mode infer --config 4 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${tag}_infer_config4.json
+python bench.py --mode infer --config 5 --steps 3 --warmup 1 2>/dev/null | tail -1 > gpurun_out/${tag}_infer_config5.json
 ls -la gpurun_out | tail -30
+# an artefact that is a traceback (or empty) is a FAILED collection, never something to commit
+bad=$(grep -l -E "Traceback|Error:|error:" gpurun_out/${tag}_*.txt gpurun_out/${tag}_*.json 2>/dev/null; find gpurun_out -name "${tag}_*" -size 0)
+if [ -n "$bad" ]; then echo "profile_round: FAILED artefacts:"; echo "$bad"; exit 1; fi
+echo "profile_round: all ${tag} artefacts collected"

@@ -29,7 +29,7 @@ def norm(name):
 
 def algo_key(k):
     """rocprof kernel name -> name used by refid_amd.ops.PROFILE (tools/profile_step.py)."""
-    if k.startswith("conv_wino6_kernel"): return "conv_wino6_kernel"
+    if k.startswith("conv_wino6_kernel"): return k if "<" in k else "conv_wino6_kernel<2>"
     if k.startswith("conv_wino_kernel"): return k
     if k.startswith("wgrad_wino_kernel"): return "wgrad_wino_kernel"
     if k.startswith("conv_pw_kernel"):

@@ -421,6 +421,11 @@ int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch
 /* out = a + b (skip sums: XXNet_final_attenfusion_arch.py:16-17,199-203,211,215;
  * recurrent_sub_modules.py:278). count = number of floats, multiple of 4. */
 int refid_add(const float* a, const float* b, float* out, long long count, void* stream);
+/* out = in[0] + ... + in[n-1] in index order (n <= REFID_SUM_MAX host pointers to device tensors of `count` floats; out may
+ * alias in[0]).  The sums autograd accumulates over the T steps that share a tensor (x_blocks, head, the final backward
+ * states: SURVEY.md A.2 "residual / skip adds") in one launch after BPTT. */
+#define REFID_SUM_MAX 48
+int refid_sum_n(const float* const* in, int n, float* out, long long count, void* stream);
 /* out = (acc ? out : 0) + g * (y > 0 ? 1 : slope): activation derivative. */
 int refid_act_bwd(const float* g, const float* y, float* out, float slope, int accumulate,
                   long long count, void* stream);

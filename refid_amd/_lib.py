@@ -104,6 +104,7 @@ def lib():
         [C.c_void_p]
     L.refid_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong] + [C.c_int] * 4 + [C.c_void_p]
     L.refid_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
+    L.refid_sum_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
     L.refid_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_longlong, C.c_void_p]
     _bind_extra(L)
     if L.refid_abi_version() != ABI_VERSION:

@@ -93,6 +93,18 @@ __global__ __launch_bounds__(256) void add_kernel(const f32x4* __restrict__ a, c
     }
 }
 
+// out = in[0] + in[1] + ... + in[n-1], added in index order (deterministic).  Gradients that several time steps contribute to
+// (the image branch's x_blocks, the final backward states) are summed ONCE after BPTT from the per-step tensors -- (n + 1)
+// tensor passes instead of the 3 (n - 1) of n - 1 in-place accumulations, one launch instead of n - 1.
+struct SumNArgs { const f32x4* in[REFID_SUM_MAX]; int n; };
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumNArgs a, f32x4* __restrict__ out, long long n4) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 s = a.in[0][i];
+        for (int k = 1; k < a.n; ++k) s += a.in[k][i];
+        out[i] = s;
+    }
+}
+
 __global__ __launch_bounds__(256) void act_bwd_kernel(const f32x4* __restrict__ g, const f32x4* __restrict__ y,
                                                      f32x4* __restrict__ out, float slope, int acc,
                                                      long long n4) {
@@ -550,6 +562,20 @@ extern "C" int refid_add(const float* a, const float* b, float* out, long long c
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4*)a, (const f32x4*)b, (f32x4*)out, count / 4);
     REFID_LAUNCH_CHECK("add");
+    return 0;
+}
+
+extern "C" int refid_sum_n(const float* const* in, int n, float* out, long long count, void* stream) {
+    REFID_CHECK(in && out && n >= 1 && n <= REFID_SUM_MAX && count > 0 && count % 4 == 0,
+                "sum_n: 1..%d inputs, count a positive multiple of 4 (n=%d, count=%lld)", REFID_SUM_MAX, n, count);
+    SumNArgs a;
+    for (int k = 0; k < REFID_SUM_MAX; ++k) {
+        a.in[k] = reinterpret_cast<const f32x4*>(k < n ? in[k] : in[0]);
+        REFID_CHECK(a.in[k] != nullptr && (reinterpret_cast<uintptr_t>(a.in[k]) & 15) == 0, "sum_n: input %d is null or not 16-byte aligned", k);
+    }
+    a.n = n;
+    hipLaunchKernelGGL(sum_n_kernel, dim3(grid_for(count / 4)), dim3(256), 0, (hipStream_t)stream, a, (f32x4*)out, count / 4);
+    REFID_LAUNCH_CHECK("sum_n");
     return 0;
 }
 

@@ -152,6 +152,16 @@ EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
 # stream then has to wait for every chain).  REFID_PIPELINE=0: one chain.
 PIPELINE = os.environ.get("REFID_PIPELINE", "1") != "0"
 PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
+# Linearity of the convolutions (round 4).  Three input sums of the reference have a term that does not depend on the time
+# step:  C3(a_t + x_blocks[1])  (level-2 first conv, rsm:278-281),  C1([s_t | S_b])  (fuse_two_dir, rsm:291-293; S_b is the
+# FINAL backward state for every t -- arch:181) and  pred(z_t + head)  (arch:215).  W(a_t + c) + bias = W a_t + (W c + bias):
+# the second term is computed ONCE per sweep and rides in as the per-step conv's residual, so the sum tensor is never built
+# (no add kernel) and the per-step fuse conv reads half its K.  In BPTT the gradient of the constant operand is
+# W^T (sum_t g_t) and its weight-gradient share is (sum_t g_t) (x) c: one input-gradient and one weight-gradient launch on
+# the summed gradient (ops.sum_n: one pass over the kept per-step tensors) instead of one accumulation per step.  The same
+# deferred sum replaces the per-step `+=` into the image branch's gradients.  Results differ from the one-GEMM form only in
+# summation order (parity tests unchanged).  REFID_LINEAR_SPLIT=0: the reference's op sequence.
+LINEAR_SPLIT = os.environ.get("REFID_LINEAR_SPLIT", "1") != "0"
 
 
 class _SideStreams:
@@ -220,8 +230,8 @@ def flush_wgrads(device):
     side = WGRAD_STREAM.get(device)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for op, g, a, b in pend:
-            op._wgrad(g, a, b)
+        for op, g, a, b, bias in pend:
+            op._wgrad(g, a, b, bias)
     pend.clear()
 
 
@@ -397,6 +407,7 @@ class ConvOp:
         self.w_calls = 0
         self.w_last = None
         self.w_pend = []                      # weight-gradient calls waiting for their group
+        self.w_algo, self.w_bias = 0, True
         # time steps per weight-gradient launch: 1 = launch immediately (every op by default: an op called once per
         # backward -- the image branch, every EvhinetEngine op -- must not wait for finish_wgrad); Engine sets
         # min(WGRAD_GROUP, T) on the convs the T recurrent steps share (Engine._set_wgrad_groups)
@@ -448,8 +459,12 @@ class ConvOp:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 
     # ---- forward ---------------------------------------------------------------------------
-    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None, pw=None):
+    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None, pw=None, bias=True):
+        """out = post(pre(conv([a|b]) + bias) + res).  bias=False leaves the bias out (a conv is linear: where one operand of
+        an input sum does not depend on the time step, W (a_t + c) + bias is issued as W a_t + (W c + bias) with the second
+        term computed once and passed as `res` -- Engine.forward)."""
         n, h, w, _ = a.shape
+        bv = self.b_eff if bias else None
         if self.kind == "conv":
             ho, wo, oc = h, w, self.co
         elif self.kind == "down":
@@ -470,7 +485,7 @@ class ConvOp:
             for i in range(0, n, step):
                 j = min(n, i + step)
                 self.fwd(a[i:j], None if b is None else b[i:j], None if res is None else res[i:j], slope_pre, slope_post,
-                         out[i:j])
+                         out[i:j], bias=bias)
             return out
         kh, kw, st, md = self.f_geo
         if self.wps is not None and (self.split > 1 or b is None) and a.shape[3] % 8 == 0 and pw is None and \
@@ -478,18 +493,18 @@ class ConvOp:
             # (one product = plain bf16 operands: only where this tile beats the LDS-staged one -- single-source convs;
             #  conv_down: only when the grid gives every CU a workgroup -- the fp32 MFMA tile has a split-K form for less)
             ops.conv2d(a, self.wps, out, kh=kh, kw=kw, stride=st, pad=1, mode=0, cout=self.co, cout_pad=self.sf_pad, in_b=b,
-                       bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split)
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split)
             return out
         if self.wp6 is not None and self.split == 0 and (b is None or a.shape[3] % 16 == 0):
             ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
-                       bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5)
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5)
             return out
         if self.wpp6 is not None and a.shape[3] % 16 == 0 and (b is None or b.shape[3] % 16 == 0):
             ops.conv2d(a, self.wpp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
-                       bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=3, pw=pw, terms=6)
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=3, pw=pw, terms=6)
             return out
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
-                   cout_pad=self.f_pad, in_b=b, bias=self.b_eff, res=res, slope_pre=slope_pre, slope_post=slope_post,
+                   cout_pad=self.f_pad, in_b=b, bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post,
                    algo=self.f_algo, pw=pw)
         return out
 
@@ -535,30 +550,32 @@ class ConvOp:
         return out
 
     # ---- weight / bias gradient ----------------------------------------------------------------
-    def wgrad(self, g, a, b=None):
-        """g: gradient w.r.t. this conv's (pre-epilogue) output; (a|b): its input sources.
+    def wgrad(self, g, a, b=None, bias=True):
+        """g: gradient w.r.t. this conv's (pre-epilogue) output; (a|b): its input sources.  bias=False: no bias-gradient
+        contribution from this call (the extra call of a linearity split: the per-step calls already hold sum g).
 
         Weight gradients are off BPTT's critical path (only input gradients feed the next step), so they are
         issued on a side stream: their kernels fill the tails/gaps of the dependent dgrad chain."""
         side = WGRAD_STREAM.get(g.device) if OVERLAP_WGRAD else None
         if side is None:
-            return self._wgrad(g, a, b)
+            return self._wgrad(g, a, b, bias)
         for t in (g, a, b):
             if t is not None:
                 t.record_stream(side)                       # allocator must not recycle them early
         # deferred: the launch happens at the next flush_wgrads() -- ONE cross-stream dependency per batch instead
         # of one event record + wait per weight-gradient call (~1500 per step; each left a ~7 us bubble)
-        WGRAD_STREAM.pending.append((self, g, a, b))
+        WGRAD_STREAM.pending.append((self, g, a, b, bias))
         if len(WGRAD_STREAM.pending) >= WGRAD_BATCH:
             flush_wgrads(g.device)
 
-    def _wgrad(self, g, a, b=None):
+    def _wgrad(self, g, a, b=None, bias=True):
         if self.kind == "convT":
             # roles swapped (refid_hip.h): "g" := layer input (low res), "src" := output gradient
             ops.conv2d_wgrad(a, g, self.gw, kh=2, kw=2, stride=2, pad=0)
-            if self.has_bias:
+            if self.has_bias and bias:
                 ops.colsum(g, self.gb)
             return
+        gb = self.gb if bias else None
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
         if algo == 1 and b is not None and a.shape[3] % 32 != 0:
             algo = 0          # the Winograd weight-gradient tile picks the source per 32-channel tile (base 24, 40, 48 ...)
@@ -567,17 +584,17 @@ class ConvOp:
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):
-            # same source split and same algorithm as the waiting calls (the first recurrent step has no second source yet)?
-            if self.w_pend and ((self.w_pend[0][2] is None) != (b is None) or self.w_algo != algo):
+            # same source split, algorithm and bias mode as the waiting calls (the first recurrent step has no second source yet)?
+            if self.w_pend and ((self.w_pend[0][2] is None) != (b is None) or self.w_algo != algo or self.w_bias != bias):
                 self._launch_group()
             self.w_pend.append((g, a, b))
-            self.w_algo = algo
+            self.w_algo, self.w_bias = algo, bias
             if len(self.w_pend) >= self.w_group:
                 self._launch_group()
             return
         self._slab_layout(algo)
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                                      db=self.gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
+                                      db=gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
                                       slabs=self.wslab)
         self.w_calls += 1
         self.w_last = (g, a, b, algo)
@@ -598,8 +615,8 @@ class ConvOp:
         (g, a, b), more = self.w_pend[0], self.w_pend[1:]
         self._slab_layout(self.w_algo)
         self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                                      db=self.gb, i_total=self.ci, algo=self.w_algo, phase=1 if self.w_calls == 0 else 2,
-                                      slabs=self.wslab, more=more)
+                                      db=self.gb if self.w_bias else None, i_total=self.ci, algo=self.w_algo,
+                                      phase=1 if self.w_calls == 0 else 2, slabs=self.wslab, more=more)
         self.w_calls += 1
         self.w_last = (g, a, b, self.w_algo)
         self.w_pend = []
@@ -649,6 +666,18 @@ class _Egaca:
         self.conv5 = ConvOp(arena, a + ".conv5", scale_name=a + ".gamma", bf16=bf16)
         self.side = ConvOp(arena, a + ".conv_y_side", bf16=bf16)
         self.c = self.conv1.ci
+        # conv_y_side(y) + gamma * conv5(f4) (fm:331) as ONE 1x1 conv over the concatenated operand [f4 | y]: the two packed
+        # weights are chunk-major ([chunk][row][8]) with the same row padding, so conv5's chunks followed by side's ARE the
+        # packing of [gamma * W5 | W_side]; the `side` tensor (a write + a read of the widest EGACA tensor per call) and its
+        # launch disappear from the forward pass.  Backward keeps the two convs (their gradients are separate tensors anyway).
+        self.wp_cat = self.b_cat = None
+        c5, sd = self.conv5, self.side
+        if LINEAR_SPLIT and c5.f_algo == 3 and sd.f_algo == 3 and not c5.bf16 and (c5.f_pad, c5.f_kc, c5.f_bn) == (sd.f_pad, sd.f_kc, sd.f_bn) \
+                and c5.ci % 8 == 0 and c5.has_bias and sd.has_bias:
+            n5 = c5.wp.numel()
+            self.wp_cat = torch.empty(n5 + sd.wp.numel(), dtype=torch.float32, device=c5.wp.device)
+            c5.wp, sd.wp = self.wp_cat[:n5], self.wp_cat[n5:]          # (before the pack plan is built: it packs into these views)
+            self.b_cat = torch.empty_like(sd.b)
         self.names = {n: (P(f"{a}.{n}"), G(f"{a}.{n}")) for n in (
             "norm1.weight", "norm1.bias", "norm1_e.weight", "norm1_e.bias", "norm2.weight", "norm2.bias",
             "conv2.weight", "conv2.bias", "conv2_e.weight", "conv2_e.bias",
@@ -673,6 +702,7 @@ class _EvrLevel:
         self.fuse = ConvOp(arena, prefix + ".fuse_two_dir.conv2d", bf16=bf16) if fuse else None
         self.down = None if dead_down else ConvOp(arena, prefix + ".down", kind="down", bf16=bf16)
         self.C = self.trunk.C
+        self.q_const = self.p_fuse = self.zero_s = None     # per-forward constants of the linearity split (Engine.forward)
 
     def ops(self):
         r = self.trunk.ops()
@@ -789,6 +819,9 @@ class Engine:
         else:
             for o in self.all_ops:
                 o.repack()
+        for lv in self.enc_b + self.enc_f:
+            if lv.att is not None and lv.att.wp_cat is not None:
+                ops.add(lv.att.conv5.b_eff, lv.att.side.b, out=lv.att.b_cat)      # bias of the merged conv5 + conv_y_side
         self.packed_version = self.param_version
 
     # -------------------------------------------------------------------------------------------
@@ -857,14 +890,20 @@ class Engine:
         ln2 = new(n, h, w, c) if save else None
         f4 = new(n, h, w, A.conv4.co)
         c4 = A.conv4.fwd(y, pw=dict(ln_gamma=A.p("norm2.weight"), ln_beta=A.p("norm2.bias"), ln_out=ln2, out2=f4))
-        side = A.side.fwd(y)
-        out = A.conv5.fwd(f4, res=side)
+        if A.wp_cat is not None:
+            out = new(n, h, w, A.conv5.co)
+            ops.conv2d(f4, A.wp_cat, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=A.conv5.co, cout_pad=A.conv5.f_pad, in_b=y,
+                       bias=A.b_cat, algo=3)
+        else:
+            side = A.side.fwd(y)
+            out = A.conv5.fwd(f4, res=side)
         if save:
             st["eg"] = dict(ev=ev, ln_e=ln_e, c1e=c1e, dwe=dwe, xe=xe, m=m, z1=z1, s=s, xs=xs, y=y, ln2=ln2, c4=c4, f4=f4)
         return out
 
-    def _egaca_bwd(self, A, g_u, img_grad, ip, st):
-        """Returns gradient w.r.t. the event input; adds the image-input gradient into img_grad."""
+    def _egaca_bwd(self, A, g_u, img_grad, ip, st, gy_keep=None):
+        """Returns gradient w.r.t. the event input; adds the image-input gradient into img_grad -- or, with gy_keep, appends
+        it to that list (summed once per sweep: Engine.backward_early / backward_late)."""
         e = st["eg"]
         A.conv5.wgrad(g_u, e["f4"])
         g_f4 = A.conv5.dgrad(g_u)
@@ -887,7 +926,10 @@ class Engine:
         g_c1e = ops.dwconv3x3_bwd(g_dwe, e["c1e"], A.p("conv2_e.weight"), A.g("conv2_e.weight"), A.g("conv2_e.bias"))
         A.conv1_e.wgrad(g_c1e, e["ln_e"])
         g_lne = A.conv1_e.dgrad(g_c1e)
-        ops.add(img_grad, g_y, out=img_grad)              # y = ev + img + ...: image gets g_y
+        if gy_keep is not None:
+            gy_keep.append(g_y)                           # y = ev + img + ...: image gets g_y (deferred sum)
+        else:
+            ops.add(img_grad, g_y, out=img_grad)
         # NOT in place: conv3's weight-gradient kernel may still be reading g_y on the side stream
         g_ev = ops.layernorm2d_bwd(g_lne, e["ev"], A.p("norm1_e.weight"), torch.empty_like(g_y),
                                    A.g("norm1_e.weight"), A.g("norm1_e.bias"), res=g_y)
@@ -942,15 +984,22 @@ class Engine:
             src = a
             u = L.conv.fwd(a, slope_pre=0.04)                 # LeakyReLU(.2) twice (rsm:81-82,284-285)
         elif i == 2:
-            src = ops.add(a, xb[1])
-            u = L.conv.fwd(src, slope_pre=0.04)
+            if L.q_const is not None:                         # C3(a + x_blocks[1]) + bias = C3(a) + q_const
+                src = a
+                u = L.conv.fwd(a, res=L.q_const, slope_post=0.04, bias=False)
+            else:
+                src = ops.add(a, xb[1])
+                u = L.conv.fwd(src, slope_pre=0.04)
         else:
             src = a
             u = self._egaca_fwd(L.att, a, xb[0], ip, st)
         s = self._trunk_fwd(L.trunk, u, h_prev, st)
         f = s
         if L.fuse is not None:
-            f = L.fuse.fwd(s, Sb, slope_pre=0.2)
+            if L.p_fuse is not None:                          # C1([s | S_b]) + bias = C1_s(s) + p_fuse
+                f = L.fuse.fwd(s, res=L.p_fuse, slope_post=0.2, bias=False)
+            else:
+                f = L.fuse.fwd(s, Sb, slope_pre=0.2)
         o = L.down.fwd(f) if L.down is not None else None
         if st is not None:
             st.update(src=src, f=f, Sb=Sb)
@@ -992,6 +1041,18 @@ class Engine:
         ip_b = self._egaca_img_path(self.enc_b[1].att, xb[0])
         ip_f = self._egaca_img_path(self.enc_f[1].att, xb[0])
 
+        # linearity split: the time-independent halves of the level-2 first conv and of pred (the fuse convs' follow the
+        # backward sweep, which produces their operand)
+        lin = LINEAR_SPLIT
+        for L in (self.enc_b[2], self.enc_f[2]):
+            L.q_const = L.conv.fwd(xb[1]) if lin else None                 # C3(x_blocks[1]) + bias
+        for L in self.enc_f:
+            L.p_fuse = None
+        q_pred = None
+        if lin:
+            q_pred = torch.zeros((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
+            self.pred.fwd(head, out=q_pred[..., :self.out_chn])            # pred(head) + bias
+
         main = torch.cuda.current_stream()
         lvs = [main, LV_STREAMS[0].get(dev), LV_STREAMS[1].get(dev)] if PIPELINE else [main, main, main]
         for s_ in lvs[1:]:
@@ -1019,6 +1080,13 @@ class Engine:
                 sts.append(st)
             steps_b.append((t, sts))
         Sb = hb                                                            # aliasing: final states only
+        if lin:
+            # fuse_two_dir's constant half, C1_b(S_b,i) + bias, on the stream that produced S_b,i and runs level i next
+            for i, L in enumerate(self.enc_f):
+                with torch.cuda.stream(lvs[i]):
+                    if L.zero_s is None or L.zero_s.shape != Sb[i].shape:
+                        L.zero_s = torch.zeros_like(Sb[i])                 # (stands in for the s_t half; cached across steps)
+                    L.p_fuse = L.fuse.fwd(L.zero_s, Sb[i])
 
         out = torch.empty((B, T, self.out_chn, H, W), dtype=torch.float32, device=dev)
         out4 = torch.zeros((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
@@ -1048,8 +1116,12 @@ class Engine:
                 if save:
                     dst["di"] = di
                 ds.append(dst)
-            pi = ops.add(z, head)
-            self.pred.fwd(pi, out=out4[..., :self.out_chn])                # arch:215 (no activation)
+            if q_pred is not None:                                         # pred(z + head) = pred(z) + q_pred
+                pi = z
+                self.pred.fwd(z, res=q_pred[..., :self.out_chn], out=out4[..., :self.out_chn], bias=False)
+            else:
+                pi = ops.add(z, head)
+                self.pred.fwd(pi, out=out4[..., :self.out_chn])            # arch:215 (no activation)
             ops.nhwc_to_nchw(out4[..., :self.out_chn], self.out_chn, out[:, t],
                              dst_batch_stride=T * self.out_chn * H * W)
             if save:
@@ -1076,7 +1148,7 @@ class Engine:
                 main.wait_stream(s_)
         if save:
             self.ctx = dict(B=B, T=T, H=H, W=W, x_in=x_in, ev_in=ev_in, head=head, e_all=e_all, xb=xb,
-                            img_saved=img_saved, ip_b=ip_b, ip_f=ip_f, steps_b=steps_b, steps_f=steps_f, Sb=Sb)
+                            img_saved=img_saved, ip_b=ip_b, ip_f=ip_f, steps_b=steps_b, steps_f=steps_f, Sb=Sb, lin=lin)
         else:
             self.ctx = None
         return out
@@ -1116,11 +1188,16 @@ class Engine:
         gout = gout.contiguous()
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]
         zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)  # noqa: E731
+        lin = c["lin"]
         # pred has no activation (arch:215), so head's share sum_t dgrad(g_t) is dgrad(sum_t g_t): one launch
-        g_head = self.pred.dgrad(ops.nchw_tsum_to_nhwc(gout, _pad4(self.out_chn)))
-        g_xb = [zeros(t) for t in xb]
+        g4sum = ops.nchw_tsum_to_nhwc(gout, _pad4(self.out_chn))
+        g_head = self.pred.dgrad(g4sum)
+        # gradients of the image branch's x_blocks: with the linearity split they are assembled once per sweep from the kept
+        # per-step tensors (ops.sum_n / one input-gradient launch on the summed gradient), never accumulated step by step
+        g_xb = [None, None, None] if lin else [zeros(t) for t in xb]
         g_Sb = [None, None, None]
         g_e = torch.empty_like(e_all)
+        keep = dict(gy=[], gu=[], gb0=[], gf=([], [], []))     # per-step gradients the deferred sums read
 
         # ---------------- forward sweep, t = T-1 .. 0 -------------------------------------------
         g_hf = [None, None, None]
@@ -1153,21 +1230,38 @@ class Engine:
                     g_z = c1.dgrad(g_b1, res=gz)              # b0 is the previous block's output
                 else:
                     g_b0 = c1.dgrad(g_b1, res=gz)
-            ops.add(g_xb[2], g_b0, out=g_xb[2])
+            if lin:
+                keep["gb0"].append(g_b0)
+            else:
+                ops.add(g_xb[2], g_b0, out=g_xb[2])
             g_o = ops.add(g_b0, g_skip[2])
             for i in (2, 1, 0):
                 L, st = self.enc_f[i], S["lv"][i]
                 C = L.C
                 L.down.wgrad(g_o, st["f"])
                 g_f = L.down.dgrad(g_o, mask=st["f"], slope_mask=0.2)
-                L.fuse.wgrad(g_f, st["s"], st["Sb"])
-                g_s = L.fuse.dgrad(g_f, rows=(0, C), res=g_hf[i])
-                if g_Sb[i] is None:
-                    g_Sb[i] = L.fuse.dgrad(g_f, rows=(C, C))
+                if lin:
+                    L.fuse.wgrad(g_f, st["s"])                # the S_b half: once, on sum_t g_f (below)
+                    keep["gf"][i].append(g_f)
                 else:
-                    L.fuse.dgrad(g_f, rows=(C, C), res=g_Sb[i], out=g_Sb[i])
-                g_o = self._evr_first_bwd(L, g_s, st, g_hf, g_xb, g_e, t, B, c["ip_f"], g_skip, first_writer=True)
+                    L.fuse.wgrad(g_f, st["s"], st["Sb"])
+                    if g_Sb[i] is None:
+                        g_Sb[i] = L.fuse.dgrad(g_f, rows=(C, C))
+                    else:
+                        L.fuse.dgrad(g_f, rows=(C, C), res=g_Sb[i], out=g_Sb[i])
+                g_s = L.fuse.dgrad(g_f, rows=(0, C), res=g_hf[i])
+                g_o = self._evr_first_bwd(L, g_s, st, g_hf, g_xb, g_e, t, B, c["ip_f"], g_skip, True, keep if lin else None)
 
+        if lin:
+            # the time-independent operands' shares, from the summed per-step gradients
+            self.pred.wgrad(g4sum, head, bias=False)                      # (sum_t g4) (x) head; bias: the per-step calls
+            g_xb[2] = ops.sum_n(keep["gb0"])
+            for i, L in enumerate(self.enc_f):
+                gsum = ops.sum_n(keep["gf"][i])
+                L.fuse.wgrad(gsum, L.zero_s, Sb[i], bias=False)           # (sum_t g_f) (x) S_b
+                g_Sb[i] = L.fuse.dgrad(gsum, rows=(L.C, L.C))             # dL/dS_b = W_b^T sum_t g_f
+            self._lin_level2_tail(self.enc_f[2], keep["gu"], xb, g_xb, first=True)
+            g_xb[0] = ops.sum_n(keep["gy"])
         # forward-sweep, bottleneck, decoder and pred weights are final from here on -- except the
         # folded EGACA convs, un-folded now so the early bucket is complete
         self._egaca_img_bwd(self.enc_f[1].att, xb[0], g_xb[0], c["ip_f"])
@@ -1183,6 +1277,8 @@ class Engine:
         xb, head, e_all = c["xb"], c["head"], c["e_all"]
         # ---------------- backward sweep (executed t = T-1..0), BPTT in reverse: t = 0 .. T-1 ----
         g_hb = [None, None, None]
+        lin = c["lin"]
+        keep = dict(gy=[], gu=[])
         for t, sts in reversed(c["steps_b"]):
             g_o = None
             for i in (2, 1, 0):
@@ -1193,7 +1289,10 @@ class Engine:
                 else:
                     L.down.wgrad(g_o, st["s"])
                     g_s = L.down.dgrad(g_o, res=carry)
-                g_o = self._evr_first_bwd(L, g_s, st, g_hb, g_xb, g_e, t, B, c["ip_b"], None, first_writer=False)
+                g_o = self._evr_first_bwd(L, g_s, st, g_hb, g_xb, g_e, t, B, c["ip_b"], None, False, keep if lin else None)
+        if lin:
+            self._lin_level2_tail(self.enc_b[2], keep["gu"], xb, g_xb, first=False)
+            ops.sum_n([g_xb[0]] + keep["gy"], out=g_xb[0])
 
         # ---------------- t-independent tails ----------------------------------------------------
         self._egaca_img_bwd(self.enc_b[1].att, xb[0], g_xb[0], c["ip_b"])
@@ -1222,19 +1321,34 @@ class Engine:
         WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_b[1].att)
 
-    def _evr_first_bwd(self, L, g_s, st, g_h, g_xb, g_e, t, B, ip, g_skip, first_writer):
+    def _lin_level2_tail(self, L, gu, xb, g_xb, first):
+        """Level-2 first conv, linearity split: the share of the constant operand x_blocks[1] -- its weight-gradient term
+        (sum_t g_u) (x) x_blocks[1] and its input gradient W^T sum_t g_u -- from ONE summed gradient per sweep."""
+        gsum = ops.sum_n(gu)
+        L.conv.wgrad(gsum, xb[1], bias=False)
+        if first:
+            g_xb[1] = L.conv.dgrad(gsum)
+        else:
+            L.conv.dgrad(gsum, res=g_xb[1], out=g_xb[1])
+
+    def _evr_first_bwd(self, L, g_s, st, g_h, g_xb, g_e, t, B, ip, g_skip, first_writer, keep=None):
         """Trunk + first op of an EvR level; returns the gradient w.r.t. the level's input
-        (already including the decoder skip gradient when g_skip is given)."""
+        (already including the decoder skip gradient when g_skip is given).  keep: the linearity split's lists of per-step
+        gradients (None / the split switched off: accumulate step by step as the reference's autograd does)."""
         i = L.level
+        lin = keep is not None
         if i == 1:
             g_u, g_h[i] = self._trunk_bwd(L.trunk, g_s, st)
-            g_in = self._egaca_bwd(L.att, g_u, g_xb[0], ip, st)
+            g_in = self._egaca_bwd(L.att, g_u, None if lin else g_xb[0], ip, st, keep["gy"] if lin else None)
             if g_skip is not None:
                 g_in = ops.add(g_in, g_skip[0], out=g_in)
             return g_in
         g_u, g_h[i] = self._trunk_bwd(L.trunk, g_s, st, mask_u=st["u"], slope_u=0.04)
         L.conv.wgrad(g_u, st["src"])
         if i == 2:
+            if lin:
+                keep["gu"].append(g_u)                        # x_blocks[1]'s share: _lin_level2_tail
+                return L.conv.dgrad(g_u, res=g_skip[1] if g_skip is not None else None)
             g_a2 = L.conv.dgrad(g_u)
             ops.add(g_xb[1], g_a2, out=g_xb[1])
             if g_skip is not None:

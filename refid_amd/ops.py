@@ -382,6 +382,29 @@ def add(a, b, out=None):
     return out
 
 
+SUM_MAX = 48
+
+
+def sum_n(tensors, out=None):
+    """out = tensors[0] + tensors[1] + ... (index order; any number of same-shape contiguous tensors; out may be
+    tensors[0]).  More than SUM_MAX inputs are summed in passes."""
+    ts = list(tensors)
+    if not ts:
+        raise _lib.RefidHipError("sum_n: no inputs")
+    if out is None:
+        out = torch.empty_like(ts[0])
+    for t in ts + [out]:
+        if not t.is_contiguous() or t.shape != ts[0].shape or t.dtype != torch.float32:
+            raise _lib.RefidHipError("sum_n: contiguous same-shape float32 tensors required")
+    while True:
+        part, ts = ts[:SUM_MAX], ts[SUM_MAX:]
+        ptrs = (C.c_void_p * len(part))(*[t.data_ptr() for t in part])
+        check(lib().refid_sum_n(ptrs, len(part), out.data_ptr(), out.numel(), _stream()), "refid_sum_n")
+        if not ts:
+            return out
+        ts = [out] + ts
+
+
 def act_bwd(g, y, slope, out=None, accumulate=False):
     """out (+)= g * (y > 0 ? 1 : slope)."""
     if out is None:

@@ -255,7 +255,8 @@ def test_egaca_fused_forward_six_launches(shape):
             for k in names:
                 setattr(ops, k, saved[k])
             E.EGACA_FUSED = old
-    assert len(counts[True]) == 6 and len(counts[False]) == 12, (counts[True], counts[False])
+    # (round 4: conv_y_side rides in conv5's launch as a second operand source -> 5 launches; REFID_LINEAR_SPLIT=0: 6)
+    assert len(counts[True]) == (5 if A.wp_cat is not None else 6) and len(counts[False]) == 12, (counts[True], counts[False])
     close(outs[True].permute(0, 3, 1, 2), ref, rtol=1e-3, atol=1e-4)
     close(outs[False].permute(0, 3, 1, 2), ref, rtol=1e-3, atol=1e-4)
     for k in stash[False]:

@@ -157,6 +157,11 @@ typedef struct refid_conv_desc {
     float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
                                                    aligned, private to this stream until the call's work has run;
                                                    NULL: never split                                            */
+    const float* add2; int ld_add2;             /* second output (algo 0 / 1 / 2 / 4 / 5; NULL = off): out2 = out + add2, same shape */
+    float* out2;       int ld_out2;             /* as `out` -- the skip sum the reference forms right after this conv
+                                                   (XXNet_final_attenfusion_arch.py:16-17,199-203,211) or, in BPTT, the sum of
+                                                   this input gradient with another branch's, written by the producing tile
+                                                   instead of a separate add kernel.  `out` is still written.            */
 } refid_conv_desc;
 
 /* Scratch bytes refid_conv2d(d) wants in d->ws (0 = none); depends on the geometry fields and split_k only. */

@@ -19,6 +19,9 @@ struct ConvKArgs {
     int ksplit = 1;            // Winograd tile: K (input-channel chunk) ranges per output tile, grid.y (small grids)
     long long wsStride = 0;    // floats between the partial outputs of two K ranges
     int gridTiles = 0;         // persistent Winograd tile: number of virtual blocks (XCD-aware tile enumeration)
+    // second output: out2 = out + add2 (the skip sums the reference builds right after a conv -- arch:16-17,199-203,211 --
+    // and their backward counterparts leave with the producing tile instead of a separate add kernel); NULL = off
+    const float* add2 = nullptr; float* out2 = nullptr; int ldA2 = 0, ldO2 = 0;
 };
 
 

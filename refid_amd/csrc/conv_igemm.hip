@@ -288,6 +288,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                         for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
                     }
                     *reinterpret_cast<f32x4*>(a.out + op * a.ldO + ch) = v;
+                    if (a.out2)
+                        *reinterpret_cast<f32x4*>(a.out2 + op * a.ldO2 + ch) = v + *reinterpret_cast<const f32x4*>(a.add2 + op * a.ldA2 + ch);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                         t = lrelu(t, a.slopePost);
                         if (a.mask) t *= (a.mask[op * a.ldM + ch + k] > 0.f) ? 1.f : a.slopeMask;
                         a.out[op * a.ldO + ch + k] = t;
+                        if (a.out2) a.out2[op * a.ldO2 + ch + k] = t + a.add2[op * a.ldA2 + ch + k];
                     }
                 }
             }
@@ -496,6 +499,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     a.out = d->out; a.ldO = d->ld_out;
     a.res = d->res; a.ldR = d->ld_res;
     a.mask = d->mask; a.ldM = d->ld_mask;
+    a.add2 = d->add2; a.ldA2 = d->ld_add2; a.out2 = d->out2; a.ldO2 = d->ld_out2;
+    REFID_CHECK(d->out2 == nullptr || (d->add2 != nullptr && d->algo != 3),
+                "conv2d: out2 needs add2 and is not implemented by the pointwise tile (algo 3)");
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
     a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
     a.pad = d->pad; a.nchunks = 0; a.tilesX = a.tilesY = 0;
@@ -503,6 +509,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     a.vecOK = al16(d->out) && d->ld_out % 4 == 0 && (!d->res || (al16(d->res) && d->ld_res % 4 == 0)) &&
               (!d->mask || (al16(d->mask) && d->ld_mask % 4 == 0)) && (!d->bias || al16(d->bias)) &&
+              (!d->out2 || (al16(d->out2) && d->ld_out2 % 4 == 0 && al16(d->add2) && d->ld_add2 % 4 == 0)) &&
               d->co_base % 4 == 0 && (d->mode != 1 || (d->cout / 4) % 4 == 0);
     a.bf16 = (d->algo == 2);
     a.ncot = 0;

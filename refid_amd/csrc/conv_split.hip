@@ -403,6 +403,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
                     for (int k = 0; k < 4; ++k) v[k] *= (pmask[it][k] > 0.f) ? 1.f : a.slopeMask;
                 }
                 *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+                if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + op * a.ldO2 + j0) = v + *reinterpret_cast<const f32x4*>(a.add2 + op * a.ldA2 + j0);
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
                     tv = lrelu(tv, a.slopePost);
                     if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
                     a.out[op * a.ldO + j0 + k] = tv;
+                    if (a.out2) a.out2[op * a.ldO2 + j0 + k] = tv + a.add2[op * a.ldA2 + j0 + k];
                 }
             }
         }

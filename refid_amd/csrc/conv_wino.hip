@@ -341,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
                 for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
             }
             *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+            if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + op * a.ldO2 + j0) = v + *reinterpret_cast<const f32x4*>(a.add2 + op * a.ldA2 + j0);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const ConvKArgs a) {
                 tv = lrelu(tv, a.slopePost);
                 if (a.mask) tv *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
                 a.out[op * a.ldO + j0 + k] = tv;
+                if (a.out2) a.out2[op * a.ldO2 + j0 + k] = tv + a.add2[op * a.ldA2 + j0 + k];
             }
         }
     }
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(256) void wino_splitk_finish_kernel(const ConvKArgs
                 for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
             }
             *reinterpret_cast<f32x4*>(a.out + op * a.ldO + j0) = v;
+            if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + op * a.ldO2 + j0) = v + *reinterpret_cast<const f32x4*>(a.add2 + op * a.ldA2 + j0);
             continue;
         }
 #pragma unroll
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256) void wino_splitk_finish_kernel(const ConvKArgs
             t = lrelu(t, a.slopePost);
             if (a.mask) t *= (a.mask[op * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
             a.out[op * a.ldO + j0 + k] = t;
+            if (a.out2) a.out2[op * a.ldO2 + j0 + k] = t + a.add2[op * a.ldA2 + j0 + k];
         }
     }
 }
@@ -476,7 +480,7 @@ int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int sp
     // Built only with REFID_EXPERIMENTAL_TILES=1 (csrc/experimental/conv_wino2.hip); the product library always runs the
     // two-wave tile (same bits).
 #ifdef REFID_EXPERIMENTAL_TILES
-    if (tile_hint == 2 && a.vecOK && a.Cout % 4 == 0) {
+    if (tile_hint == 2 && a.vecOK && a.Cout % 4 == 0 && a.out2 == nullptr) {
         const int cus = device_cus();
         if (cus > 0 && refid_wino3x3_p_eligible(a, 0)) return refid_launch_wino3x3_p(a, cus, st);
     }

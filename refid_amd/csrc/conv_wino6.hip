@@ -301,6 +301,11 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     const float* const resB = a.res ? a.res + opb * a.ldR + j0 : nullptr;
     const float* const mskB = a.mask ? a.mask + opb * a.ldM + j0 : nullptr;
     const int stepO[2] = {a.Wo * a.ldO, PPT * a.ldO}, stepR[2] = {a.Wo * a.ldR, PPT * a.ldR}, stepM[2] = {a.Wo * a.ldM, PPT * a.ldM};
+    // second output out2 = out + add2 (a skip sum leaves with the tile): same item addressing as the other epilogue tensors
+    const bool two = a.out2 != nullptr && a.ksplit == 1;
+    float* const out2B = two ? a.out2 + opb * a.ldO2 + j0 : nullptr;
+    const float* const add2B = two ? a.add2 + opb * a.ldA2 + j0 : nullptr;
+    const int stepO2[2] = {a.Wo * a.ldO2, PPT * a.ldO2}, stepA2[2] = {a.Wo * a.ldA2, PPT * a.ldA2};
     const bool pre = REFID_WINO6_ABLATE != 4 && REFID_WINO6_ABLATE != 10 && vec && a.ksplit == 1 && (a.res != nullptr || a.mask != nullptr);
     f32x4 pres[NIT], pmask[NIT];
     if (pre) {
@@ -352,6 +357,9 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
                 for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
             }
             *reinterpret_cast<f32x4*>(outp) = v;
+            if (two)
+                *reinterpret_cast<f32x4*>(out2B + row * stepO2[0] + colb * stepO2[1]) =
+                    v + *reinterpret_cast<const f32x4*>(add2B + row * stepA2[0] + colb * stepA2[1]);
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
                 tv = lrelu(tv, a.slopePost);
                 if (a.mask) tv *= (mskB[row * stepM[0] + colb * stepM[1] + k] > 0.f) ? 1.f : a.slopeMask;
                 outp[k] = tv;
+                if (two) out2B[row * stepO2[0] + colb * stepO2[1] + k] = tv + add2B[row * stepA2[0] + colb * stepA2[1] + k];
             }
         }
     }
@@ -429,7 +438,7 @@ int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int spli
     // bits): measured 0-10 % slower, only in libraries built with REFID_EXPERIMENTAL_TILES=1 and only on request
     // (refid_conv_desc.wino_tile = 3)
 #ifdef REFID_EXPERIMENTAL_TILES
-    if (tile_hint == 3 && a.Cout > 32) return refid_launch_wino6w(a, 1, st);
+    if (tile_hint == 3 && a.Cout > 32 && a.out2 == nullptr) return refid_launch_wino6w(a, 1, st);   // (no second output there)
 #endif
     const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0, tile_hint);
     dim3 grid = pl.grid;
@@ -443,8 +452,8 @@ int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int spli
                         "refid_conv_workspace_bytes)", ws_bytes, need);
         return 1;
     }
-    ConvKArgs p = a;                       // partial pass: raw sums into the workspace
-    p.ksplit = ks; p.wsStride = npix * ldW; p.out = ws; p.ldO = ldW;
+    ConvKArgs p = a;                       // partial pass: raw sums into the workspace (the finishing pass writes out / out2)
+    p.ksplit = ks; p.wsStride = npix * ldW; p.out = ws; p.ldO = ldW; p.out2 = nullptr;
     grid.y = ks;
     if (int rc = pl.nt == 2 ? launch_wino6<2>(p, grid, st, "conv_wino6/splitk") : launch_wino6<1>(p, grid, st, "conv_wino6/32/splitk"))
         return rc;

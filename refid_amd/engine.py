@@ -152,6 +152,10 @@ EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
 # stream then has to wait for every chain).  REFID_PIPELINE=0: one chain.
 PIPELINE = os.environ.get("REFID_PIPELINE", "1") != "0"
 PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
+# The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
+# 199-203,211) and their BPTT counterparts (g_di + g_hd, g_b0 + g_skip) leave with the PRODUCING tile as a second output
+# (refid_conv_desc.out2 = out + add2) instead of a separate add kernel each.  0: one add kernel per sum.
+FUSE_SUMS = os.environ.get("REFID_FUSE_SUMS", "1") != "0"
 # Linearity of the convolutions (round 4).  Three input sums of the reference have a term that does not depend on the time
 # step:  C3(a_t + x_blocks[1])  (level-2 first conv, rsm:278-281),  C1([s_t | S_b])  (fuse_two_dir, rsm:291-293; S_b is the
 # FINAL backward state for every t -- arch:181) and  pred(z_t + head)  (arch:215).  W(a_t + c) + bias = W a_t + (W c + bias):
@@ -459,10 +463,11 @@ class ConvOp:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 
     # ---- forward ---------------------------------------------------------------------------
-    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None, pw=None, bias=True):
+    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None, pw=None, bias=True, plus=None):
         """out = post(pre(conv([a|b]) + bias) + res).  bias=False leaves the bias out (a conv is linear: where one operand of
         an input sum does not depend on the time step, W (a_t + c) + bias is issued as W a_t + (W c + bias) with the second
-        term computed once and passed as `res` -- Engine.forward)."""
+        term computed once and passed as `res` -- Engine.forward).  plus: a tensor of the output's shape; returns
+        (out, out + plus) -- the skip sum the next layer reads leaves with this tile (refid_conv_desc.out2)."""
         n, h, w, _ = a.shape
         bv = self.b_eff if bias else None
         if self.kind == "conv":
@@ -476,6 +481,8 @@ class ConvOp:
             if _pad4(oc) != oc:
                 out.zero_()
                 out = out[..., :oc]
+        o2 = torch.empty_like(out) if plus is not None else None
+        two = dict(add2=plus, out2=o2) if plus is not None else {}
         if n * a.stride(0) >= _LIM4 or n * out.stride(0) >= _LIM4 or (b is not None and n * b.stride(0) >= _LIM4):
             step = _batch_step(n, a, b, res, out)
             # the tiles address their tensors with 32-bit byte offsets (hardware range-checked buffer loads): a batch whose
@@ -486,30 +493,35 @@ class ConvOp:
                 j = min(n, i + step)
                 self.fwd(a[i:j], None if b is None else b[i:j], None if res is None else res[i:j], slope_pre, slope_post,
                          out[i:j], bias=bias)
-            return out
+            return out if plus is None else (out, ops.add(out, plus, out=o2))
         kh, kw, st, md = self.f_geo
         if self.wps is not None and (self.split > 1 or b is None) and a.shape[3] % 8 == 0 and pw is None and \
                 (self.kind == "conv" or (b is None and _fills_gpu(n, ho, wo, self.co, 1))):
             # (one product = plain bf16 operands: only where this tile beats the LDS-staged one -- single-source convs;
             #  conv_down: only when the grid gives every CU a workgroup -- the fp32 MFMA tile has a split-K form for less)
             ops.conv2d(a, self.wps, out, kh=kh, kw=kw, stride=st, pad=1, mode=0, cout=self.co, cout_pad=self.sf_pad, in_b=b,
-                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split)
-            return out
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split, **two)
+            return out if plus is None else (out, o2)
         if self.wp6 is not None and self.split == 0 and (b is None or a.shape[3] % 16 == 0):
             ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
-                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5)
-            return out
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5, **two)
+            return out if plus is None else (out, o2)
         if self.wpp6 is not None and a.shape[3] % 16 == 0 and (b is None or b.shape[3] % 16 == 0):
             ops.conv2d(a, self.wpp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
                        bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=3, pw=pw, terms=6)
-            return out
+            return out if plus is None else (out, ops.add(out, plus, out=o2))
+        if self.f_algo == 3:                                      # (the pointwise tile has no second output)
+            two = {}
         ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
                    cout_pad=self.f_pad, in_b=b, bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post,
-                   algo=self.f_algo, pw=pw)
-        return out
+                   algo=self.f_algo, pw=pw, **two)
+        if plus is not None and not two:
+            ops.add(out, plus, out=o2)
+        return out if plus is None else (out, o2)
 
     # ---- input gradient ----------------------------------------------------------------------
-    def dgrad(self, g, rows=None, res=None, mask=None, slope_mask=1.0, out=None):
+    def dgrad(self, g, rows=None, res=None, mask=None, slope_mask=1.0, out=None, plus=None):
+        """Input gradient (+ res, masked).  plus: returns (out, out + plus) -- see fwd."""
         if self.wd is None:
             raise RefidHipError(f"{self.name}: dgrad weights were not requested")
         base, cnt = rows if rows is not None else (0, self.d_rows)
@@ -522,32 +534,38 @@ class ConvOp:
             ho, wo = h // 2, w // 2
         if out is None:
             out = torch.empty((n, ho, wo, cnt), dtype=torch.float32, device=g.device)
+        o2 = torch.empty_like(out) if plus is not None else None
+        two = dict(add2=plus, out2=o2) if plus is not None else {}
         if n * g.stride(0) >= _LIM4 or n * out.stride(0) >= _LIM4:      # (see fwd)
             step = _batch_step(n, g, res, mask, out)
             for i in range(0, n, step):
                 j = min(n, i + step)
                 self.dgrad(g[i:j], rows, None if res is None else res[i:j], None if mask is None else mask[i:j], slope_mask,
                            out[i:j])
-            return out
+            return out if plus is None else (out, ops.add(out, plus, out=o2))
         kh, kw, st, md = self.d_geo
         pad = self.pad if self.kind == "conv" else (1 if self.kind == "down" else 0)
         if self.kind == "conv":
             pad = self.k - 1 - self.pad
         if self.wds is not None and (self.kind == "conv" or _fills_gpu(n, h, w, cnt, 4)):
             ops.conv2d(g, self.wds, out, kh=kh, kw=kw, stride=st, pad=1, mode=md, cout=cnt, cout_pad=self.sd_pad, co_base=base,
-                       res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split)
-            return out
+                       res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split, **two)
+            return out if plus is None else (out, o2)
         if self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO:
             ops.conv2d(g, self.wd6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
-                       res=res, mask=mask, slope_mask=slope_mask, algo=5)
-            return out
+                       res=res, mask=mask, slope_mask=slope_mask, algo=5, **two)
+            return out if plus is None else (out, o2)
         if self.wdp6 is not None and cnt > 32 and g.shape[3] % 16 == 0:
             ops.conv2d(g, self.wdp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=3, terms=6)
-            return out
+            return out if plus is None else (out, ops.add(out, plus, out=o2))
+        if self.d_algo == 3:
+            two = {}
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
-                   co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo)
-        return out
+                   co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo, **two)
+        if plus is not None and not two:
+            ops.add(out, plus, out=o2)
+        return out if plus is None else (out, o2)
 
     # ---- weight / bias gradient ----------------------------------------------------------------
     def wgrad(self, g, a, b=None, bias=True):
@@ -954,13 +972,17 @@ class Engine:
     # trunk = EvR hidden-state update (rsm:659-678, 719-726, 755-758)
     # -------------------------------------------------------------------------------------------
     @staticmethod
-    def _trunk_fwd(T, u, h, st):
+    def _trunk_fwd(T, u, h, st, plus=None):
+        """plus: also returns s + plus (the next decoder's input sum, written by the last conv's tile)."""
         v = T.c0.fwd(u, h, slope_pre=0.1)
         r = T.c1.fwd(v, slope_pre=0.0)
-        s = T.c2.fwd(r, res=v)
+        s = T.c2.fwd(r, res=v, plus=plus)
+        sp = None
+        if plus is not None:
+            s, sp = s
         if st is not None:
             st.update(u=u, h=h, v=v, r=r, s=s)
-        return s
+        return s if plus is None else (s, sp)
 
     @staticmethod
     def _trunk_bwd(T, g_s, st, mask_u=None, slope_u=1.0):
@@ -978,7 +1000,8 @@ class Engine:
     # -------------------------------------------------------------------------------------------
     # EvR level (rsm:270-296)
     # -------------------------------------------------------------------------------------------
-    def _evr_fwd(self, L, a, xb, h_prev, Sb, ip, st):
+    def _evr_fwd(self, L, a, xb, h_prev, Sb, ip, st, plus=None):
+        """Returns (level output, new state) -- and, with plus, (level output + plus) as a third element."""
         i = L.level
         if i == 0:
             src = a
@@ -1000,10 +1023,14 @@ class Engine:
                 f = L.fuse.fwd(s, res=L.p_fuse, slope_post=0.2, bias=False)
             else:
                 f = L.fuse.fwd(s, Sb, slope_pre=0.2)
-        o = L.down.fwd(f) if L.down is not None else None
+        o = op = None
+        if L.down is not None:
+            o = L.down.fwd(f, plus=plus)
+            if plus is not None:
+                o, op = o
         if st is not None:
             st.update(src=src, f=f, Sb=Sb)
-        return o, s
+        return (o, s) if plus is None else (o, s, op)
 
     # -------------------------------------------------------------------------------------------
     def forward(self, x, event, save=True):
@@ -1059,15 +1086,15 @@ class Engine:
             if s_ is not main:
                 s_.wait_stream(main)                   # image branch, event head: everything issued so far
 
-        def level(L, i, cur, h_prev, Sb_i, ip, st):
+        def level(L, i, cur, h_prev, Sb_i, ip, st, plus=None):
             """EvR level i on its stream, after the producer of `cur` (level i-1 of the same step)."""
             if lvs[i] is main and i == 0:
-                return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st)
+                return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st, plus)
             if lvs[i] is not lvs[i - 1]:
                 lvs[i].wait_stream(lvs[i - 1])
                 cur.record_stream(lvs[i])
             with torch.cuda.stream(lvs[i]):
-                return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st)
+                return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st, plus)
 
         hb = [None, None, None]
         steps_b = []
@@ -1097,24 +1124,35 @@ class Engine:
         if dstream is not None:
             dstream.wait_stream(main)                  # xb, head ...: everything issued so far
 
-        def decode(t, eb, sts):
+        fuse = FUSE_SUMS
+
+        def decode(t, eb, sts, b0_in):
             bs = []
             z = eb[2]
+            di = None
             for i, (c1, c2) in enumerate(self.res):                        # arch:199-203, rsm:488-503
-                b0 = ops.add(z, xb[2]) if i == 0 else z
+                b0 = (b0_in if b0_in is not None else ops.add(z, xb[2])) if i == 0 else z
                 b1 = c1.fwd(b0, slope_pre=0.0)
-                z = c2.fwd(b1, res=b0, slope_post=0.0)
+                if fuse and i == self.nres - 1:                            # decoder 0's input sum leaves with this tile
+                    z, di = c2.fwd(b1, res=b0, slope_post=0.0, plus=eb[2])
+                else:
+                    z = c2.fwd(b1, res=b0, slope_post=0.0)
                 bs.append((b0, b1, z))
             ds = []
             for j in range(3):                                             # arch:210-212, rsm:386-408
                 D = self.dec[j]
-                di = ops.add(z, eb[2 - j])
+                if di is None:
+                    di = ops.add(z, eb[2 - j])
                 q = D["t2"].fwd(di)
                 dst = {} if save else None
-                z = self._trunk_fwd(D["trunk"], q, hd[j], dst)
-                hd[j] = z
                 if save:
                     dst["di"] = di
+                di = None
+                if fuse and j < 2:                                         # the next decoder's input sum
+                    z, di = self._trunk_fwd(D["trunk"], q, hd[j], dst, plus=eb[1 - j])
+                else:
+                    z = self._trunk_fwd(D["trunk"], q, hd[j], dst)
+                hd[j] = z
                 ds.append(dst)
             if q_pred is not None:                                         # pred(z + head) = pred(z) + q_pred
                 pi = z
@@ -1130,19 +1168,25 @@ class Engine:
         for t in range(T):                                                 # arch:185-216
             cur = e_all[t * B:(t + 1) * B]
             sts, eb = [], []
+            b0_in = None
             for i in range(3):
                 st = {} if save else None
-                cur, hf[i] = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st)
+                if fuse and i == 2:                    # b0 = e_blocks[2] + x_blocks[2] (arch:199-203) from the down tile
+                    cur, hf[i], b0_in = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st, plus=xb[2])
+                else:
+                    cur, hf[i] = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st)
                 sts.append(st)
                 eb.append(cur)
             if dstream is None:
-                decode(t, eb, sts)
+                decode(t, eb, sts, b0_in)
             else:
                 for i in range(3):
                     dstream.wait_stream(lvs[i])        # step t's encoder outputs
                     eb[i].record_stream(dstream)       # (allocated on another stream's pool)
+                if b0_in is not None:
+                    b0_in.record_stream(dstream)
                 with torch.cuda.stream(dstream):
-                    decode(t, eb, sts)
+                    decode(t, eb, sts, b0_in)
         for s_ in lvs[1:] + ([dstream] if dstream is not None else []):
             if s_ is not main:
                 main.wait_stream(s_)
@@ -1213,10 +1257,13 @@ class Engine:
                 D, dst = self.dec[j], S["ds"][j]
                 g_q, g_hd[j] = self._trunk_bwd(D["trunk"], g_sd, dst)
                 D["t2"].wgrad(g_q, dst["di"])
-                g_di = D["t2"].dgrad(g_q)
+                if j > 0 and g_hd[j - 1] is not None and FUSE_SUMS:
+                    g_di, g_sd = D["t2"].dgrad(g_q, plus=g_hd[j - 1])       # + the previous decoder's state gradient
+                else:
+                    g_di = D["t2"].dgrad(g_q)
+                    if j > 0:
+                        g_sd = g_di if g_hd[j - 1] is None else ops.add(g_di, g_hd[j - 1])
                 g_skip[2 - j] = g_di
-                if j > 0:
-                    g_sd = g_di if g_hd[j - 1] is None else ops.add(g_di, g_hd[j - 1])
             # bottleneck
             g_z = g_skip[2]                                   # decoder 0's di = z + e_blocks[2]
             for i in range(self.nres - 1, -1, -1):
@@ -1228,13 +1275,15 @@ class Engine:
                 c1.wgrad(g_b1, b0)
                 if i > 0:
                     g_z = c1.dgrad(g_b1, res=gz)              # b0 is the previous block's output
+                elif FUSE_SUMS:
+                    g_b0, g_o = c1.dgrad(g_b1, res=gz, plus=g_skip[2])     # level 2's output gradient leaves with the tile
                 else:
                     g_b0 = c1.dgrad(g_b1, res=gz)
+                    g_o = ops.add(g_b0, g_skip[2])
             if lin:
                 keep["gb0"].append(g_b0)
             else:
                 ops.add(g_xb[2], g_b0, out=g_xb[2])
-            g_o = ops.add(g_b0, g_skip[2])
             for i in (2, 1, 0):
                 L, st = self.enc_f[i], S["lv"][i]
                 C = L.C

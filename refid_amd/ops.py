@@ -171,10 +171,10 @@ def _pw_extras(pw, out):
 
 def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_pad, co_base=0,
            in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0, pw=None,
-           terms=0):
+           terms=0, add2=None, out2=None):
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc.  pw: dict of the pointwise tile's
     EGACA fusions (refid_pw_extras); terms: algo 4's product count (0 / 6, or 3); algo 3: 0 = fp32 MFMA, 6 = six bf16 products
-    (w_packed from pack_conv_weights_split with kh = kw = 1)."""
+    (w_packed from pack_conv_weights_split with kh = kw = 1).  add2 / out2: second output out2 = out + add2 (not algo 3)."""
     d = ConvDesc()
     d.mfma_terms = terms
     if pw is not None:
@@ -194,6 +194,11 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.out, d.ld_out = _nhwc(out, "out")
     d.res, d.ld_res = _nhwc(res, "res")
     d.mask, d.ld_mask = _nhwc(mask, "mask")
+    if out2 is not None:
+        if add2 is None or add2.shape != out.shape or out2.shape != out.shape:
+            raise _lib.RefidHipError("conv2d: out2 needs add2, both of the output's shape")
+        d.add2, d.ld_add2 = _nhwc(add2, "add2")
+        d.out2, d.ld_out2 = _nhwc(out2, "out2")
     d.n, d.h, d.w = in_a.shape[0], in_a.shape[1], in_a.shape[2]
     if mode == 0:
         d.ho, d.wo = out.shape[1], out.shape[2]

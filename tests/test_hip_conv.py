@@ -1237,3 +1237,55 @@ def test_split_tile_conv_down_dgrad(cfg, terms):
                slope_mask=0.3, algo=4, terms=terms)
     rtol, atol = (RTOL, ATOL) if terms != 3 else (2e-4, 2e-4)
     np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("case", [
+    # (kind, co, ci, k, N, H, W, two_source, what)
+    ("conv", 64, 64, 3, 2, 20, 36, False, "wino6 64-channel tile, ragged"),
+    ("conv", 32, 64, 3, 1, 16, 32, True, "wino6 32-channel tile, two sources"),
+    ("conv", 256, 256, 3, 1, 8, 8, False, "wino6 split-K: the finishing pass writes both outputs"),
+    ("conv", 16, 16, 3, 1, 12, 20, False, "fp32 Winograd tile"),
+    ("conv", 3, 32, 3, 1, 16, 16, False, "direct 3x3 tile, 3 output channels (scalar epilogue path)"),
+    ("down", 64, 64, 4, 8, 32, 64, False, "conv_down on the split tile"),
+    ("down", 64, 64, 4, 1, 16, 16, False, "conv_down on the fp32 tile (small grid, split-K)"),
+    ("convT", 32, 64, 2, 1, 8, 16, False, "ConvTranspose: forward (pixel shuffle store) and its 2x2/s2 input gradient"),
+    ("conv", 64, 128, 1, 1, 16, 16, True, "pointwise tile: no second output in the kernel -> add kernel fallback"),
+])
+def test_second_output_is_out_plus_add(case):
+    """refid_conv_desc.out2 = out + add2 (ConvOp.fwd / dgrad `plus=`): the skip sums of arch:16-17,199-203,211 and their BPTT
+    counterparts leave with the producing tile.  For every tile family: `out` is bit-identical to the call without a second
+    output, and out2 == out + plus exactly (one fp32 add per element, as the add kernel does)."""
+    from refid_amd import engine as E, ops
+    kind, co, ci, k, N, H, W, two, _ = case
+    name = "t"
+    shapes = {"t.weight": (ci, co, 2, 2) if kind == "convT" else (co, ci, k, k)}
+    if kind != "down":
+        shapes["t.bias"] = (co,)
+    arena = E.ParamArena(shapes, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    arena.flat_p.copy_(torch.randn(arena.total, device="cuda", generator=g) * 0.1)
+    op = E.ConvOp(arena, name, kind=kind)
+    op.repack()
+    ca = ci // 2 if two else ci
+    a = torch.randn(N, H, W, ca, device="cuda", generator=g)
+    b = torch.randn(N, H, W, ci - ca, device="cuda", generator=g) if two else None
+    ref = op.fwd(a, b, slope_pre=0.1)
+    plus = torch.randn(ref.shape, device="cuda", generator=g)[..., :ref.shape[3]]
+    if ref.shape[3] % 4:                                          # channel-padded output: views of padded buffers
+        pad = torch.randn(*ref.shape[:3], E._pad4(ref.shape[3]), device="cuda", generator=g)
+        plus = pad[..., :ref.shape[3]]
+    if plus.is_contiguous() or ref.shape[3] % 4 == 0:
+        out, o2 = op.fwd(a, b, slope_pre=0.1, plus=plus)
+        assert torch.equal(out, ref)
+        assert torch.equal(o2, ref + plus)
+    # input gradient with residual + mask + second output
+    gout = torch.randn(ref.shape, device="cuda", generator=g).contiguous() if ref.shape[3] % 4 == 0 else None
+    if gout is not None and (kind != "conv" or not two):
+        gin_ref = op.dgrad(gout)
+        r = torch.randn_like(gin_ref)
+        m = torch.randn_like(gin_ref)
+        p2 = torch.randn_like(gin_ref)
+        want = op.dgrad(gout, res=r, mask=m, slope_mask=0.2)
+        got, got2 = op.dgrad(gout, res=r, mask=m, slope_mask=0.2, plus=p2)
+        assert torch.equal(got, want)
+        assert torch.equal(got2, want + p2)

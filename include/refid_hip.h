@@ -162,6 +162,9 @@ typedef struct refid_conv_desc {
                                                    (XXNet_final_attenfusion_arch.py:16-17,199-203,211) or, in BPTT, the sum of
                                                    this input gradient with another branch's, written by the producing tile
                                                    instead of a separate add kernel.  `out` is still written.            */
+    int mask_mode;                              /* 0: the activation-derivative mask above.  1 (algo 3 only): multiply by
+                                                   GELU_erf'(mask) instead -- the input gradient of conv5 leaves the tile as
+                                                   the gradient of conv4's output (fusion_modules.py:327-329 backward)   */
 } refid_conv_desc;
 
 /* Scratch bytes refid_conv2d(d) wants in d->ws (0 = none); depends on the geometry fields and split_k only. */

@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
         ("mfma_terms", C.c_int),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
         ("add2", C.c_void_p), ("ld_add2", C.c_int), ("out2", C.c_void_p), ("ld_out2", C.c_int),
+        ("mask_mode", C.c_int),
     ]
 
 

@@ -22,6 +22,7 @@ struct ConvKArgs {
     // second output: out2 = out + add2 (the skip sums the reference builds right after a conv -- arch:16-17,199-203,211 --
     // and their backward counterparts leave with the producing tile instead of a separate add kernel); NULL = off
     const float* add2 = nullptr; float* out2 = nullptr; int ldA2 = 0, ldO2 = 0;
+    int maskMode = 0;          // 0: out *= (mask > 0 ? 1 : slopeMask);  1 (pointwise tile): out *= GELU'(mask)
 };
 
 

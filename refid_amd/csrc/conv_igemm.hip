@@ -500,6 +500,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     a.res = d->res; a.ldR = d->ld_res;
     a.mask = d->mask; a.ldM = d->ld_mask;
     a.add2 = d->add2; a.ldA2 = d->ld_add2; a.out2 = d->out2; a.ldO2 = d->ld_out2;
+    a.maskMode = d->mask_mode;
+    REFID_CHECK(d->mask_mode == 0 || (d->mask_mode == 1 && d->algo == 3 && d->mask != nullptr),
+                "conv2d: mask_mode 1 (GELU derivative) belongs to the pointwise tile (algo 3) and needs a mask tensor");
     REFID_CHECK(d->out2 == nullptr || (d->add2 != nullptr && d->algo != 3),
                 "conv2d: out2 needs add2 and is not implemented by the pointwise tile (algo 3)");
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;

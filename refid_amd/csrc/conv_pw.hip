@@ -54,6 +54,11 @@ __device__ __forceinline__ void pw_split8(const f32x4& v0, const f32x4& v1, f32x
 constexpr int OOB = -1;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_d(float x) {      // d/dx GELU_erf = Phi(x) + x phi(x)   (as egaca.hip::gelu_d)
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
 
 // NT: 32-channel column tiles per wave (Cout tile = 32*NT); XD: activation prefetch depth; EX: the EGACA fusions of
 // PwExtra are compiled in (fusion_modules.py:290-333):
@@ -307,8 +312,13 @@ __global__ __launch_bounds__(256, SIX ? 3 : 4) void conv_pw_kernel(const ConvKAr
                 lrelu4(v, a.slopePost, a.slopePost != 1.f);
                 if (a.mask) {
                     const f32x4 mv = *reinterpret_cast<const f32x4*>(a.mask + pp * a.ldM + j0);
+                    if (a.maskMode == 1) {                  // (workgroup-uniform) GELU backward fused into conv5's input gradient
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+                        for (int k = 0; k < 4; ++k) v[k] *= gelu_erf_d(mv[k]);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] *= (mv[k] > 0.f) ? 1.f : a.slopeMask;
+                    }
                 }
                 *reinterpret_cast<f32x4*>(a.out + pp * a.ldO + j0) = v;
                 if constexpr (EX) {
@@ -337,7 +347,7 @@ __global__ __launch_bounds__(256, SIX ? 3 : 4) void conv_pw_kernel(const ConvKAr
                 tv = lrelu(tv, a.slopePre);
                 if (a.res) tv += a.res[p * a.ldR + j0 + k];
                 tv = lrelu(tv, a.slopePost);
-                if (a.mask) tv *= (a.mask[p * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask;
+                if (a.mask) tv *= a.maskMode == 1 ? gelu_erf_d(a.mask[p * a.ldM + j0 + k]) : ((a.mask[p * a.ldM + j0 + k] > 0.f) ? 1.f : a.slopeMask);
                 a.out[p * a.ldO + j0 + k] = tv;
             }
         }

@@ -520,8 +520,9 @@ class ConvOp:
         return out if plus is None else (out, o2)
 
     # ---- input gradient ----------------------------------------------------------------------
-    def dgrad(self, g, rows=None, res=None, mask=None, slope_mask=1.0, out=None, plus=None):
-        """Input gradient (+ res, masked).  plus: returns (out, out + plus) -- see fwd."""
+    def dgrad(self, g, rows=None, res=None, mask=None, slope_mask=1.0, out=None, plus=None, gelu_mask=False):
+        """Input gradient (+ res, masked).  plus: returns (out, out + plus) -- see fwd.  gelu_mask: multiply by GELU'(mask)
+        instead of the leaky-step derivative (pointwise tile; elsewhere a separate gelu_bwd launch does it)."""
         if self.wd is None:
             raise RefidHipError(f"{self.name}: dgrad weights were not requested")
         base, cnt = rows if rows is not None else (0, self.d_rows)
@@ -561,6 +562,8 @@ class ConvOp:
             return out if plus is None else (out, ops.add(out, plus, out=o2))
         if self.d_algo == 3:
             two = {}
+            if gelu_mask:
+                two = dict(mask_mode=1)
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
                    co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo, **two)
         if plus is not None and not two:
@@ -924,8 +927,11 @@ class Engine:
         it to that list (summed once per sweep: Engine.backward_early / backward_late)."""
         e = st["eg"]
         A.conv5.wgrad(g_u, e["f4"])
-        g_f4 = A.conv5.dgrad(g_u)
-        g_c4 = ops.gelu_bwd(g_f4, e["c4"], out=g_f4)
+        if A.conv5.d_algo == 3 and A.conv5.wdp6 is None and LINEAR_SPLIT:
+            g_c4 = A.conv5.dgrad(g_u, mask=e["c4"], gelu_mask=True)      # GELU' rides in the tile's mask epilogue
+        else:
+            g_f4 = A.conv5.dgrad(g_u)
+            g_c4 = ops.gelu_bwd(g_f4, e["c4"], out=g_f4)
         A.conv4.wgrad(g_c4, e["ln2"])
         g_ln2 = A.conv4.dgrad(g_c4)
         A.side.wgrad(g_u, e["y"])

@@ -171,7 +171,7 @@ def _pw_extras(pw, out):
 
 def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_pad, co_base=0,
            in_b=None, bias=None, res=None, mask=None, slope_pre=1.0, slope_post=1.0, slope_mask=1.0, algo=0, pw=None,
-           terms=0, add2=None, out2=None):
+           terms=0, add2=None, out2=None, mask_mode=0):
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc.  pw: dict of the pointwise tile's
     EGACA fusions (refid_pw_extras); terms: algo 4's product count (0 / 6, or 3); algo 3: 0 = fp32 MFMA, 6 = six bf16 products
     (w_packed from pack_conv_weights_split with kh = kw = 1).  add2 / out2: second output out2 = out + add2 (not algo 3)."""
@@ -216,6 +216,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.cout, d.cout_pad, d.co_base = cout, cout_pad, co_base
     d.kh, d.kw, d.stride, d.pad, d.mode = kh, kw, stride, pad, mode
     d.slope_pre, d.slope_post, d.slope_mask = slope_pre, slope_post, slope_mask
+    d.mask_mode = mask_mode
     d.algo = algo
     d.wino_tile = WINO_TILE
     if WINO_SPLIT and algo in (0, 1, 2, 5):

@@ -156,8 +156,9 @@ def cpu_baseline(args):
                       f"{_cpu_model()}"}
 
 
-def roofline_from_profile(prof, step_seconds, dtype, unit_note):
-    """Dominant kernel (largest accumulated HIP-event time in one instrumented single-stream pass) against its roof."""
+def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=True):
+    """Dominant kernel (largest accumulated HIP-event time in one instrumented single-stream pass) against its roof.
+    traffic_lookup: the committed PMC passes were collected on the configs[1] train step; other workloads report null."""
     agg = {}
     for name, fl, e0, e1, _shape, nb in prof:
         a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
@@ -167,7 +168,7 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note):
     # separate runs, tools/pmc_traffic.py); bench.py cannot collect hardware counters itself
     traffic = None
     import glob
-    suffix = {"fp32": "", "bf16": "_bf16"}.get(dtype)
+    suffix = {"fp32": "", "bf16": "_bf16"}.get(dtype) if traffic_lookup else None
     pats = [] if suffix is None else sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")),
                                             reverse=True)
     for path in pats:
@@ -323,7 +324,8 @@ def infer_main(args, model, dev, rank, world, use_dist, sync):
         if rank == 0:
             prof, ops.PROFILE = ops.PROFILE, None
             roof = roofline_from_profile(prof, dt / args.steps, args.dtype,
-                                         "per-kernel timing from one extra single-stream inference pass")
+                                         "per-kernel timing from one extra single-stream inference pass; no PMC traffic pass was "
+                                         "collected for this workload (traffic: null)", traffic_lookup=False)
     if use_dist:
         torch.distributed.barrier()
     if rank == 0:

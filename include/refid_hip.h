@@ -190,7 +190,7 @@ int refid_conv_bn(int kh, int kw, int stride, int mode, int cout);
  * that ACCUMULATES into dw/db (gradients of weights shared over the T steps add up,
  * SURVEY.md A.2 first row).
  * ---------------------------------------------------------------------------------- */
-#define REFID_WGRAD_MAX_GROUPS 8
+#define REFID_WGRAD_MAX_GROUPS 24
 typedef struct refid_wgrad_desc {
     const float* g;      int ld_g;   int c_o;   /* output-gradient, (n,ho,wo,c_o)       */
     const float* in_a;   const float* in_b;     /* conv input sources, (n,h,w,c_a|c_b)  */

@@ -52,6 +52,9 @@ class ConvDesc(C.Structure):
     ]
 
 
+WGRAD_MAX_GROUPS = 24    # == REFID_WGRAD_MAX_GROUPS in include/refid_hip.h
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("g", C.c_void_p), ("ld_g", C.c_int), ("c_o", C.c_int),
@@ -64,7 +67,8 @@ class WgradDesc(C.Structure):
         ("i_base", C.c_int), ("i_total", C.c_int), ("o_real", C.c_int), ("algo", C.c_int),
         ("phase", C.c_int),
         ("groups", C.c_int),
-        ("g_more", C.c_void_p * 7), ("in_a_more", C.c_void_p * 7), ("in_b_more", C.c_void_p * 7),
+        ("g_more", C.c_void_p * (WGRAD_MAX_GROUPS - 1)), ("in_a_more", C.c_void_p * (WGRAD_MAX_GROUPS - 1)),
+        ("in_b_more", C.c_void_p * (WGRAD_MAX_GROUPS - 1)),
     ]
 
 

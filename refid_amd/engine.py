@@ -218,7 +218,10 @@ DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
 PW6 = os.environ.get("REFID_PW6", "0") == "1"
 # smallest output-channel count whose 3x3 weight gradient goes to the Winograd tile (64 x 32 channel tiles)
 WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
-WGRAD_GROUP = max(1, min(8, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
+# (round 4: the ABI takes up to 24 steps per launch.  All T steps of a sweep in ONE launch write the partial-sum slabs once
+#  instead of read-modify-writing them per group -- measured: B=8 460.5 vs 458.3 ms, B=1 109.3 vs 106.0 ms at 24 vs 8 steps: the
+#  later start of the weight-gradient kernels costs more overlap than the slab passes save.  8 stays.)
+WGRAD_GROUP = max(1, min(24, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 # Experiment (REFID_EXPERIMENTAL_TILES builds only): Winograd weight gradient with six exact-split bf16 products per fp32
 # product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
 # are transformed and split on the fly, ~19 VALU per MFMA.  Off.

@@ -39,8 +39,9 @@ constexpr int PX = TH * TW;
 constexpr int HWD = TW + 2, HP = (TH + 2) * HWD;
 constexpr int G4 = COT / 4, X4 = CIT / 4;
 constexpr int G_TOTAL = PX * G4, X_TOTAL = HP * X4;
-constexpr int G_ITEMS = G_TOTAL / 256, X_ITEMS = (X_TOTAL + 255) / 256;
-constexpr int LDS_BYTES = (G_TOTAL + X_TOTAL) * 16 + COT * 4;
+constexpr int X_ITEMS = (X_TOTAL + 255) / 256;
+constexpr int lds_bytes_ww(int iw) { return (G_TOTAL + iw * X_TOTAL) * 16 + COT * 4; }
+constexpr int LDS_BYTES = lds_bytes_ww(1);
 
 struct WwArgs {
     // up to REFID_WGRAD_MAX_GROUPS time steps of the same convolution (same geometry): their tiles are one K range
@@ -55,22 +56,34 @@ struct WwArgs {
     int accum;
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
+// IW = 32-channel input sub-tiles per workgroup.  IW = 1: 4 waves, two workgroups per CU (the product form).  IW = 2 (round 4
+// experiment, REFID_WGRAD_WINO_IW=2): 8 waves, one workgroup per CU -- waves 0-3 and 4-7 are two copies of the tile above for two
+// NEIGHBOURING input-channel tiles that share ONE staged gradient tile (the 64 x 32-pixel dY tile is fetched once per
+// input-channel tile: 2 x at 64 input channels, 8 x at 256): same waves per SIMD, same per-wave loop, 28 % fewer staged bytes
+// per MFMA at 64 channels -- and measured 0-4 % slower (see the launcher).  Each half stages its own input halo with its own
+// (wave-uniform) source descriptor, so a two-source conv may change source between the halves.
+template <int IW>
+__global__ __launch_bounds__(256 * IW, IW == 1 ? 2 : 1) void wgrad_wino_kernel(const WwArgs a) {
+    constexpr int NT = 256 * IW;
+    constexpr int GI = G_TOTAL / NT;                       // gradient-tile items per thread
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid0 = threadIdx.x;
+    const int half = IW == 2 ? __builtin_amdgcn_readfirstlane(tid0 >> 8) : 0;     // wave-uniform
     f32x4* sG4 = reinterpret_cast<f32x4*>(smem);
-    f32x4* sX4 = sG4 + G_TOTAL;
-    float* sBias = reinterpret_cast<float*>(sX4 + X_TOTAL);
+    f32x4* sX4 = sG4 + G_TOTAL + half * X_TOTAL;
+    float* sBias = reinterpret_cast<float*>(sG4 + G_TOTAL + IW * X_TOTAL);
     const float* sG = reinterpret_cast<const float*>(sG4);
     const float* sX = reinterpret_cast<const float*>(sX4);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = tid0 & 255;                            // thread inside its half (input-halo staging, compute roles)
+    const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int ti = wave;                                   // transform row owned by this wave
-    const int co0 = blockIdx.z * COT, ci0 = blockIdx.y * CIT;
+    const int co0 = blockIdx.z * COT, ci0 = (blockIdx.y * IW + half) * CIT;
     const int split = blockIdx.x;
 
 
-    const int gq = tid % G4, xq = tid % X4;
+    const int gq = tid0 % G4, xq = tid % X4;
     const int gco = co0 + gq * 4;
     const bool gcok = gco < a.Co;
     const int xc = ci0 + xq * 4;
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][sm][r] = 0.f;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
-    f32x4 rg[G_ITEMS], rx[X_ITEMS];
+    f32x4 rg[GI], rx[X_ITEMS];
 
     // Tile loads: buffer loads with 32-bit offsets.  A thread's pixel inside the tile never changes, so its offset is
     // (tile origin pixel) * pitch + a per-thread constant; out-of-image pixels / channels get the out-of-range offset
@@ -111,8 +124,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
         const int gbase = ((n * a.Ho + oy0) * a.Wo + ox0) * a.ldG * 4 + gco * 4;          // bytes, < 2^31 (host check)
         const int xbase = ((n * a.H + iy0) * a.W + ix0) * xld * 4 + xcc * 4;
 #pragma unroll
-        for (int it = 0; it < G_ITEMS; ++it) {
-            const int p = tid / G4 + it * (256 / G4);
+        for (int it = 0; it < GI; ++it) {
+            const int p = tid0 / G4 + it * (NT / G4);
             const int dy = p / TW, dx = p % TW;
             const bool ok = gcok && oy0 + dy < a.Ho && ox0 + dx < a.Wo;
             const int vo = ok ? gbase + (dy * a.Wo + dx) * a.ldG * 4 : -1;
@@ -130,8 +143,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int it = 0; it < G_ITEMS; ++it) {
-            const int p = tid / G4 + it * (256 / G4);
+        for (int it = 0; it < GI; ++it) {
+            const int p = tid0 / G4 + it * (NT / G4);
             sG4[p * G4 + gq] = rg[it];
             bsum += rg[it];          // bias partial: summed HERE, not at load time -- using a prefetched register right
                                      // after its load was issued forced a vmcnt(0) before the MFMA section
@@ -262,12 +275,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino_kernel(const WwArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float v = refid_wave_rows_sum<G4>(bsum[k]);
-            if ((tid & 63) < G4) sred[(tid >> 6) * COT + gq * 4 + k] = v;
+            if ((tid0 & 63) < G4) sred[(tid0 >> 6) * COT + gq * 4 + k] = v;
         }
         __syncthreads();
-        if (tid < COT) {
-            const float tot = ((sred[tid] + sred[COT + tid]) + sred[2 * COT + tid]) + sred[3 * COT + tid];
-            float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid;
+        if (tid0 < COT) {
+            float tot = ((sred[tid0] + sred[COT + tid0]) + sred[2 * COT + tid0]) + sred[3 * COT + tid0];
+            if (IW == 2) tot += ((sred[4 * COT + tid0] + sred[5 * COT + tid0]) + sred[6 * COT + tid0]) + sred[7 * COT + tid0];
+            float* dst = a.bslabs + (long long)split * a.CoP + co0 + tid0;
             *dst = a.accum ? *dst + tot : tot;
         }
     }
@@ -877,8 +891,9 @@ size_t refid_wgrad_wino_workspace_bytes(const refid_wgrad_desc* d) {
 }
 
 int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0}, attr_done6{0};
-    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino_kernel, LDS_BYTES, "wgrad_wino")) return rc;
+    static std::atomic<unsigned long long> attr_done{0}, attr_done6{0}, attr_doneW{0};
+    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino_kernel<1>, lds_bytes_ww(1), "wgrad_wino")) return rc;
+    if (int rc = refid_lds_attr_once(attr_doneW, &wgrad_wino_kernel<2>, lds_bytes_ww(2), "wgrad_wino/8 waves")) return rc;
 #ifdef REFID_EXPERIMENTAL_TILES
     static std::atomic<unsigned long long> attr_done62{0}, attr_done2{0};
     if (int rc = refid_lds_attr_once(attr_done2, &wgrad_wino_dma_kernel, LDS2_BYTES, "wgrad_wino_dma")) return rc;
@@ -937,7 +952,16 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st) {
             hipLaunchKernelGGL(wgrad_wino_dma_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS2_BYTES, st, a);
 #endif
         } else {
-            hipLaunchKernelGGL(wgrad_wino_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS_BYTES, st, a);
+            // REFID_WGRAD_WINO_IW=2: two neighbouring input-channel tiles per workgroup (8 waves, the gradient tile staged once
+            // for both) whenever the tile count is even.  Measured (tools/bench_wgrad_wino.py regs, round 4): 0-4 % SLOWER than
+            // the 4-wave form on every config-2 shape (95.6 vs 95.3 TF/s at 64->64 @256^2, 105-106 vs 109-110 at the 128- and
+            // 256-channel layers; train step 472-474 vs 471 ms) -- the staged bytes it saves were not what limits this tile,
+            // the eight-wave barriers cost more.  Off; same weight-gradient bits, bias partials in a different fixed order.
+            static const int iw_max = []() { const char* e = getenv("REFID_WGRAD_WINO_IW"); return e ? atoi(e) : 1; }();
+            if (iw_max >= 2 && g.nciT % 2 == 0)
+                hipLaunchKernelGGL(wgrad_wino_kernel<2>, dim3(g.nsplit, g.nciT / 2, g.ncoT), dim3(512), lds_bytes_ww(2), st, a);
+            else
+                hipLaunchKernelGGL(wgrad_wino_kernel<1>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds_bytes_ww(1), st, a);
         }
         REFID_LAUNCH_CHECK("wgrad_wino");
     }

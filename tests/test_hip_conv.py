@@ -1289,3 +1289,36 @@ def test_second_output_is_out_plus_add(case):
         got, got2 = op.dgrad(gout, res=r, mask=m, slope_mask=0.2, plus=p2)
         assert torch.equal(got, want)
         assert torch.equal(got2, want + p2)
+
+
+def test_winograd_wgrad_eight_wave_form_subprocess():
+    """REFID_WGRAD_WINO_IW=2 (an experiment that measured 0-4 % slower: two input-channel tiles per 8-wave workgroup sharing one
+    staged gradient tile) must give the 4-wave form's weight gradient bit for bit -- a wave's arithmetic is unchanged -- and the
+    bias gradient within rounding (its partials are summed in a different fixed order).  The switch is read once per process."""
+    import subprocess, sys, os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from refid_amd import ops
+torch.manual_seed(3)
+out = {}
+for (N, H, W, Ca, Cb, Co) in ((2, 12, 40, 64, 0, 64), (1, 8, 32, 64, 64, 128), (1, 9, 33, 32, 32, 64)):
+    a = torch.randn(N, H, W, Ca, device="cuda"); b = torch.randn(N, H, W, Cb, device="cuda") if Cb else None
+    g = torch.randn(N, H, W, Co, device="cuda")
+    dw = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")
+    ops.conv2d_wgrad(g, a, dw, kh=3, kw=3, pad=1, in_b=b, db=db, algo=1)
+    out[(N, H, W, Ca, Cb, Co)] = (dw.cpu(), db.cpu())
+torch.save(out, sys.argv[1])
+''' % ROOT
+    res = {}
+    for iw in ("1", "2"):
+        path = f"/tmp/refid_wgrad_iw{iw}_{os.getpid()}.pt"
+        env = dict(os.environ, REFID_WGRAD_WINO_IW=iw)
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[iw] = torch.load(path)
+        os.remove(path)
+    for k in res["1"]:
+        assert torch.equal(res["1"][k][0], res["2"][k][0]), k
+        np.testing.assert_allclose(res["2"][k][1].numpy(), res["1"][k][1].numpy(), rtol=1e-5, atol=1e-5)

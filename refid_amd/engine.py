@@ -242,13 +242,16 @@ def flush_wgrads(device):
     pend.clear()
 
 
+FILL_MIN_WG = int(os.environ.get("REFID_FILL_MIN_WG", "256"))     # workgroups from which conv_down takes the split tile
+
+
 def _fills_gpu(n, ho, wo, cout, classes):
     """Does the split tile's smallest grid (4 x 32 pixel tiles x 64 channels) give each of the 256 CUs a workgroup?
     Same policy switch as the split-K of the other tiles (refid_conv_desc.split_k): decided by the total grid under
     'auto', by the per-sample geometry (as if 8 samples) otherwise, so that a sample's bits do not depend on the batch."""
     if ops.WINO_SPLIT != 2:
         n = 8
-    return n * -(-ho // 4) * -(-wo // 32) * -(-cout // 64) * classes >= 256
+    return n * -(-ho // 4) * -(-wo // 32) * -(-cout // 64) * classes >= FILL_MIN_WG
 
 
 _LIM4 = (2 ** 31 - 1) // 4                    # fp32 elements below 2 GiB

@@ -24,6 +24,7 @@
 // engine keeps the fp32 form (REFID_PW6=1 switches).
 #include "common.h"
 #include "conv_args.h"
+#include <cstdlib>
 
 namespace {
 
@@ -73,7 +74,7 @@ __device__ __forceinline__ float gelu_erf_d(float x) {      // d/dx GELU_erf = P
 //     gradient);
 //   * a second residual (y = ev + img + beta*conv3(.), fm:319) and a GELU second output (fm:327-329).
 template <int NT, int XD, bool EX, bool SIX = false>
-__global__ __launch_bounds__(256, SIX ? 3 : 4) void conv_pw_kernel(const ConvKArgs a, const PwExtra e) {
+__global__ __launch_bounds__(256, (SIX || NT > 2) ? 3 : 4) void conv_pw_kernel(const ConvKArgs a, const PwExtra e) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const long long npix = (long long)a.N * a.H * a.W;
@@ -382,7 +383,16 @@ int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* e
     // wider layers run as 64-channel column tiles (grid.y): 4 waves/SIMD beat re-using the activations
     if (six) hipLaunchKernelGGL((conv_pw_kernel<2, 4, false, true>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, none);
     else if (a.Cout <= 32) hipLaunchKernelGGL((conv_pw_kernel<1, 8, false>), dim3(nb, 1), dim3(256), 0, st, a, none);
-    else hipLaunchKernelGGL((conv_pw_kernel<2, 4, false>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, none);
+    else {
+        // REFID_PW_NT4=1 (experiment, round 4): 128-channel column tiles -- a wave computes four 32-channel tiles from ONE pass
+        // over its activations (half the workgroups, no second read of the operand) at 3 instead of 4 waves per SIMD.
+        // Measured slower: 42.1 vs 39.4 us at 64 -> 128 @128^2 (warm), train step 463.0 vs 461.0 ms.  Occupancy beats re-use.
+        static const bool nt4 = []() { const char* e = getenv("REFID_PW_NT4"); return e && e[0] == '1'; }();
+        if (nt4 && a.Cout % 128 == 0)
+            hipLaunchKernelGGL((conv_pw_kernel<4, 4, false>), dim3(nb, a.Cout / 128), dim3(256), 0, st, a, none);
+        else
+            hipLaunchKernelGGL((conv_pw_kernel<2, 4, false>), dim3(nb, cdiv(a.Cout, 64)), dim3(256), 0, st, a, none);
+    }
     REFID_LAUNCH_CHECK("conv_pw");
     return 0;
 }

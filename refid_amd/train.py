@@ -22,6 +22,10 @@ from .archs import define_network
 from .dist import GradSync, get_dist_info
 
 
+# REFID_RUN_AHEAD_BOUND=0: let the host enqueue as many steps ahead as the HIP queue takes (A/B only; see _bound_run_ahead)
+RUN_AHEAD_BOUND = os.environ.get("REFID_RUN_AHEAD_BOUND", "1") != "0"
+
+
 def scheduler_lr(kind, cfg, epoch, base_lr, prev_lr, total_iter=None):
     """Learning rate after `epoch` scheduler steps -- the schedulers base_model.py:77-108 can build
     (models/lr_scheduler.py:6-177 + torch CosineAnnealingLR), restated per step for ONE param group.
@@ -252,9 +256,27 @@ class TwoImageEventRecurrentRestorationModel:
         self._loss_sum, self._loss_n = g["loss_sum"], g["n"]
         self.log_dict = None
 
+    def _bound_run_ahead(self):
+        """At most ONE step in flight.  The host enqueues a step ~5x faster than the GPU executes it; left alone it runs many
+        steps ahead, and every step's BPTT stash (~90 GB at B=8) is then allocated before the previous step's blocks -- freed by
+        Python, but still recorded on the side streams that read them -- may be reused: the caching allocator grows to the whole
+        288 GB (284 GiB reserved in a 20-step run), and one more tensor per step (the prefetched batch) tips it into
+        free-everything-and-retry, 3 s per step.  Waiting for the previous step's end event costs one launch latency (the GPU is
+        fed again within microseconds) and keeps the footprint at one step's 154 GiB.  The reference's loop has the same bound:
+        its `reduce_loss_dict` calls `.item()` every iteration (base_model.py:325-350)."""
+        ev = getattr(self, "_step_done", None)
+        if ev is not None and RUN_AHEAD_BOUND:
+            ev.synchronize()
+
+    def _mark_step_end(self):
+        self._step_done = torch.cuda.Event()
+        self._step_done.record()
+
     def optimize_parameters(self, current_iter):
+        self._bound_run_ahead()
         if getattr(self, "graph_on", False):
-            return self._step_graph()
+            self._step_graph()
+            return self._mark_step_end()
         eng = self.net_g.engine
         eng.zero_grad()                                          # optimizer_g.zero_grad()
         pred = eng.forward(self.lq, self.voxel, save=True)       # net_g(x=lq, event=voxel)
@@ -276,6 +298,7 @@ class TwoImageEventRecurrentRestorationModel:
             torch.distributed.all_reduce(loss_sum)          # 8 bytes; every rank ends up with the mean, not only rank 0
         self._loss_sum, self._loss_n = loss_sum, n
         self.log_dict = None
+        self._mark_step_end()
 
     def _loss_and_grad(self, pred):
         """Returns (dL/dpred, un-weighted loss sum (1-element tensor), count): l_pix = weight * sum / count."""

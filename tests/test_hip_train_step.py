@@ -260,3 +260,48 @@ def test_graph_replayed_steps_equal_eager_steps():
     assert mg._graph is None
     mg.optimize_parameters(6)
     assert mg.step_count == 6
+
+
+def test_at_most_one_step_in_flight_and_prefetcher_hand_over():
+    """The host enqueues a step ~5x faster than the GPU runs it; unbounded, it ran many steps ahead in round 4 and the caching
+    allocator reached the whole 288 GB (a 20-step bench.py run: 3 s per step with the prefetched batch as the last straw).
+    optimize_parameters therefore waits for the PREVIOUS step's end event before enqueuing (the reference synchronises every
+    iteration through reduce_loss_dict's .item(), base_model.py:325-350).  Also: batches handed over by CUDAPrefetcher
+    (data/prefetch_dataloader.py:84-125 mirror) give the same trajectory as resident ones."""
+    from refid_amd.data import CUDAPrefetcher
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    P = O.make_params(6, base_num_channels=8, mode="hash", seed=9)
+    batches = []
+    for s in (4, 5):
+        x, ev, gt = O.make_inputs(1, 2, 16, 16, 6, seed=s, mode="hash")
+        batches.append({"lq": x.pin_memory(), "voxel": ev.pin_memory(), "gt": gt.pin_memory(), "seq": "name"})
+
+    class Loader:
+        def __iter__(self):
+            return iter([dict(b) for b in batches] * 2)
+
+    def run(prefetch):
+        m = TwoImageEventRecurrentRestorationModel(_opt(6, 8))
+        m.net_g.load_state_dict(P)
+        pre = CUDAPrefetcher(Loader(), {"num_gpu": 1}) if prefetch else None
+        ends = []
+        for it in range(1, 5):
+            data = pre.next() if prefetch else {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batches[(it - 1) % 2].items()}
+            assert data is not None and data["lq"].is_cuda and data["seq"] == "name"
+            m.feed_data(data)
+            m.update_learning_rate(it)
+            prev = getattr(m, "_step_done", None)
+            m.optimize_parameters(it)
+            if prev is not None:
+                assert prev.query()                      # the step before this one had finished when this one was enqueued
+            ends.append(m._step_done)
+        if prefetch:
+            assert pre.next() is None                    # end of the epoch, like the reference's prefetcher
+            pre.reset()
+            assert pre.next() is not None
+            assert pre.exposed_ms() >= 0.0
+        return {k: v.clone() for k, v in m.net_g.state_dict().items()}
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -348,7 +348,7 @@ def infer_main(args, model, dev, rank, world, use_dist, sync):
             out["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = infer_cpu_baseline(args, cfg)
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if use_dist:
         torch.distributed.destroy_process_group()
 
@@ -449,11 +449,34 @@ class _DryModel:
         return {"l_pix": 0.0}
 
 
+_JSON_FD = None
+
+
+def _claim_stdout():
+    """stdout carries ONE JSON line and nothing else.  RCCL prints a banner (HIP / ROCm version, host, library path) on the
+    C-level stdout when its first communicator comes up, and C stdio flushes it at exit -- i.e. AFTER the JSON line when stdout
+    is a pipe.  So file descriptor 1 is pointed at stderr for everything native (and for stray Python prints), and the JSON
+    line goes to a private duplicate of the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    if _JSON_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_JSON_FD, (line + "\n").encode())
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, argv))
+    _claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -652,7 +675,7 @@ def main(argv=None):
             out["strong"] = strong
         if not args.no_cpu_baseline and world == 1 and not args.dry_run:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if use_dist:
         torch.distributed.destroy_process_group()
 

@@ -102,3 +102,15 @@ def test_inference_bench_modes():
     out = _json_line(r.stdout)
     assert "configs[4]" in out["config"]["workload"] and "12 tiles" in out["config"]["workload"]
     assert out["config"]["psnr_mean_dB"] > 0 and 0 < out["config"]["ssim_mean"] < 1
+
+
+@pytest.mark.gpu
+def test_stdout_is_one_json_line_even_with_rccl_up():
+    """RCCL prints a banner on the C-level stdout when its first communicator comes up (flushed at exit, i.e. after the JSON line
+    when stdout is a pipe): bench.py keeps file descriptor 1 for the JSON line alone."""
+    r = _run(["--steps", "1", "--warmup", "1", "--batch", "1", "--T", "3", "--size", "64", "--no-cpu-baseline", "--no-roofline"],
+             {"REFID_FORCE_GRADSYNC": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-1000:]
+    assert json.loads(lines[0])["rccl_ranks"] == 1

@@ -231,7 +231,7 @@ def _c5_worker(rank, world, port, out_path):
 
 def test_config5_full_resolution_tiled_inference(tmp_path):
     """configs[4]: 1224x1632, T=15, the reference's 512x512 tile grid (twoImage_event_recurrent_model.py:190-270 made 5-D
-    aware).  (1) two tiles (a corner and the clamped last one) vs the oracle at full tile size; (2) the overlap-averaged
+    aware).  (1) the clamped last tile vs the oracle at full tile size; (2) the overlap-averaged
     assembly: single rank == two ranks sharing the tile list (gloo, the GPU is shared); (3) the validation tail
     (metrics.py PSNR / 3-D SSIM) on the assembled frames vs the oracle's restatement, on two 512x512 regions."""
     from refid_amd.metrics import calculate_psnr_frames, calculate_ssim_frames
@@ -246,7 +246,7 @@ def test_config5_full_resolution_tiled_inference(tmp_path):
     xc, ec = x.cuda(), ev.cuda()
     # (1)
     with torch.no_grad():
-        for d in (idx[0], idx[-1]):
+        for d in (idx[-1],):                  # (the clamped last tile; one 512 x 512, T = 15 oracle forward costs 20-40 s of CPU)
             i, j = d["i"], d["j"]
             ref = O.forward(P, x[..., i:i + 512, j:j + 512], ev[..., i:i + 512, j:j + 512])
             got = net(x=xc[..., i:i + 512, j:j + 512].contiguous(), event=ec[..., i:i + 512, j:j + 512].contiguous())

@@ -158,7 +158,8 @@ def cpu_baseline(args):
 
 def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=True):
     """Dominant kernel (largest accumulated HIP-event time in one instrumented single-stream pass) against its roof.
-    traffic_lookup: the committed PMC passes were collected on the configs[1] train step; other workloads report null."""
+    traffic_lookup: True = the PMC passes of the configs[1] train step (profiles/r*_pmc_traffic[_bf16].json); a string =
+    that workload's own passes (profiles/r*_pmc_traffic_<string>.json, tools/profile_infer.sh); False = report null."""
     agg = {}
     for name, fl, e0, e1, _shape, nb in prof:
         a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
@@ -169,6 +170,8 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
     traffic = None
     import glob
     suffix = {"fp32": "", "bf16": "_bf16"}.get(dtype) if traffic_lookup else None
+    if isinstance(traffic_lookup, str):
+        suffix = "_" + traffic_lookup if dtype == "fp32" else None
     pats = [] if suffix is None else sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")),
                                             reverse=True)
     for path in pats:
@@ -198,6 +201,8 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
     # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
     # the SURVEY 8(d) direct-convolution figure beside it.
     executed = fl * (16.0 / 36.0) if "wino" in name else fl
+    if "wino4" in name:
+        executed = fl * (9.0 / 36.0)                             # Winograd F(3x3,4x4) weight gradient: 36 MFMAs per 16 pixels x 9 taps
     peak = FP32_MFMA_PEAK_TFLOPS
     ach = executed / sec / 1e12
     bound, unit = "mfma", "TFLOP/s"
@@ -324,8 +329,9 @@ def infer_main(args, model, dev, rank, world, use_dist, sync):
         if rank == 0:
             prof, ops.PROFILE = ops.PROFILE, None
             roof = roofline_from_profile(prof, dt / args.steps, args.dtype,
-                                         "per-kernel timing from one extra single-stream inference pass; no PMC traffic pass was "
-                                         "collected for this workload (traffic: null)", traffic_lookup=False)
+                                         "per-kernel timing from one extra single-stream inference pass; traffic: this "
+                                         "workload's own FETCH_SIZE / WRITE_SIZE passes (tools/profile_infer.sh), fp32 only",
+                                         traffic_lookup=f"infer_config{args.config}")
     if use_dist:
         torch.distributed.barrier()
     if rank == 0:
@@ -471,12 +477,15 @@ def _emit(line):
         os.write(_JSON_FD, (line + "\n").encode())
 
 
-def main(argv=None):
+def main(argv=None, claim_stdout=False):
+    """claim_stdout: only the process that IS the benchmark (`python bench.py`, every spawned rank) redirects file descriptor
+    1; an in-process caller (tests, tools importing bench) keeps its stdout and gets the JSON line through print()."""
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(self_launch(args, argv))
-    _claim_stdout()
+    if claim_stdout and not args.dry_run:
+        _claim_stdout()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -556,7 +565,7 @@ def main(argv=None):
         if not args.dry_run:
             if args.h2d == "prefetch":
                 from refid_amd.data import CUDAPrefetcher
-                pre = CUDAPrefetcher(_HostBatches(per_gpu_batch), device=dev)
+                pre = CUDAPrefetcher(_HostBatches(per_gpu_batch), device=dev, time_waits=True)
             else:
                 x, ev, gt = synthetic_batch(per_gpu_batch, args.T, args.size, args.size, args.img_chn, 100 + rank, dev)
                 model.feed_data({"lq": x, "voxel": ev, "gt": gt})
@@ -681,4 +690,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    main(claim_stdout=True)

@@ -213,7 +213,12 @@ typedef struct refid_wgrad_desc {
                                                    bf16 MFMAs on exactly split operands, as refid_conv2d algo 5;
                                                    4 = experiment (same builds; measured equal to algo 1 in the train step):
                                                    algo 1's fp32 tile fed by LDS-DMA into two buffers, one barrier per K
-                                                   tile (pitches multiples of 4 floats, 16-byte aligned tensors)  */
+                                                   tile (pitches multiples of 4 floats, 16-byte aligned tensors);
+                                                   5 = Winograd F(3x3,4x4) (3x3 stride 1): the weight gradient as a 3x3-output
+                                                   correlation over 4x4 tiles of g -- 36 instead of 64 fp32 MFMAs per 16
+                                                   pixels (wgrad_wino4.hip; slabs [split][36][o][i]; pitches / channel counts
+                                                   multiples of 4 floats, 16-byte aligned tensors, c_a % 32 == 0 for two
+                                                   sources); deviation from the float64 gradient 4e-6 .. 8e-6 of scale  */
     int phase;                                  /* 0 = partial products + reduction in one call;
                                                    weights shared over the T recurrent steps can instead
                                                    keep accumulating in their own `slabs`:

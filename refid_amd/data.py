@@ -53,10 +53,10 @@ class CUDAPrefetcher:
     pinned) host memory; ``next()`` returns the batch on the device, or None at the end of an epoch; ``reset()`` starts
     the next epoch.  Additions over the reference: the returned tensors are tied to the consumer stream
     (``record_stream``: the caching allocator must not hand their memory to the NEXT copy while the step still reads
-    them), and the time the compute stream actually had to wait for a copy is measured with events
-    (``exposed_ms()``)."""
+    them), and -- only with ``time_waits=True`` (bench.py) -- the time the compute stream actually had to wait for a copy
+    is measured with events (``exposed_ms()``); a training loop keeps no per-iteration state, like the reference class."""
 
-    def __init__(self, loader, opt=None, device=None):
+    def __init__(self, loader, opt=None, device=None, time_waits=False):
         self.ori_loader = loader
         self.loader = iter(loader)
         self.opt = opt
@@ -66,7 +66,9 @@ class CUDAPrefetcher:
         if self.device.type != "cuda":
             raise RefidHipError("CUDAPrefetcher: a GPU device is required (the HIP path has no CPU fallback)")
         self.stream = torch.cuda.Stream(device=self.device)
-        self._waits = []                     # (event before the wait, event after it) on the consumer stream
+        self.time_waits = bool(time_waits)
+        self._waits = []                     # (event before the wait, event after it) on the consumer stream; time_waits only
+        self._waited_ms = 0.0                # completed pairs are folded in here, so the list stays bounded
         self.preload()
 
     def preload(self):
@@ -81,12 +83,18 @@ class CUDAPrefetcher:
 
     def next(self):
         cur = torch.cuda.current_stream(self.device)
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        e0.record(cur)
-        cur.wait_stream(self.stream)
-        e1.record(cur)
-        self._waits.append((e0, e1))
+        if self.time_waits:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+            cur.wait_stream(self.stream)
+            e1.record(cur)
+            self._waits.append((e0, e1))
+            while len(self._waits) > 64 and self._waits[0][1].query():        # fold finished pairs: no unbounded event list
+                a, b = self._waits.pop(0)
+                self._waited_ms += a.elapsed_time(b)
+        else:
+            cur.wait_stream(self.stream)
         batch = self.batch
         if batch is not None:
             for v in batch.values():
@@ -101,9 +109,12 @@ class CUDAPrefetcher:
 
     def exposed_ms(self, clear=True):
         """Total time (ms) the consumer stream spent waiting for host -> device copies since the last call
-        (synchronises the device)."""
+        (synchronises the device).  Needs ``time_waits=True``."""
+        if not self.time_waits:
+            raise RefidHipError("CUDAPrefetcher.exposed_ms: construct with time_waits=True")
         torch.cuda.synchronize(self.device)
-        t = sum(a.elapsed_time(b) for a, b in self._waits)
+        t = self._waited_ms + sum(a.elapsed_time(b) for a, b in self._waits)
         if clear:
             self._waits = []
+            self._waited_ms = 0.0
         return t

@@ -226,6 +226,12 @@ WGRAD_GROUP = max(1, min(24, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 # product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
 # are transformed and split on the fly, ~19 VALU per MFMA.  Off.
 WGRAD_WINO6 = os.environ.get("REFID_WGRAD_WINO6", "0") == "1"
+# Round 5: 3x3 weight gradients on the Winograd F(3x3,4x4) tile (refid_wgrad_desc.algo = 5: 36 instead of 64 fp32 MFMAs per
+# 16 output pixels) wherever the F(2x2,3x3) tile (algo 1) was used and the output has at least WGRAD_F4_MIN_HW rows and
+# columns (below that a 4x4 tile grid is mostly zero padding and the F(2x2) tile's smaller transform error is free).
+# REFID_WGRAD_F4=0 is the A/B switch back to algo 1.
+WGRAD_F4 = os.environ.get("REFID_WGRAD_F4", "1") != "0"
+WGRAD_F4_MIN_HW = int(os.environ.get("REFID_WGRAD_F4_MIN_HW", "16"))
 
 
 def flush_wgrads(device):
@@ -237,8 +243,8 @@ def flush_wgrads(device):
     side = WGRAD_STREAM.get(device)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for op, g, a, b, bias in pend:
-            op._wgrad(g, a, b, bias)
+        for op, g, a, b, bias, i_base in pend:
+            op._wgrad(g, a, b, bias, i_base)
     pend.clear()
 
 
@@ -525,6 +531,22 @@ class ConvOp:
             ops.add(out, plus, out=o2)
         return out if plus is None else (out, o2)
 
+    def can_fwd_from(self):
+        """Can fwd_from() address a block of input channels of this conv directly?  (fp32 pointwise tile, chunk-major packing)"""
+        return self.kind == "conv" and self.k == 1 and self.f_algo == 3 and self.wpp6 is None and not self.bf16
+
+    def fwd_from(self, a, k_base):
+        """conv over the input channels k_base .. k_base + C_a only (+ bias): the packing is [chunk][row][kc], so the block's
+        weights are the packed array from chunk k_base / kc on, and `a` is the single source (the time-independent half of
+        fuse_two_dir, rsm:291-293, needs no stand-in zero tensor for the other half)."""
+        if not self.can_fwd_from() or k_base % self.f_kc or a.shape[3] % self.f_kc:
+            raise RefidHipError(f"{self.name}: fwd_from needs the fp32 pointwise tile and chunk-aligned channel blocks")
+        n, h, w, _ = a.shape
+        out = torch.empty((n, h, w, self.co), dtype=torch.float32, device=a.device)
+        ops.conv2d(a, self.wp[(k_base // self.f_kc) * self.f_pad * self.f_kc:], out, kh=1, kw=1, stride=1, pad=0, mode=0,
+                   cout=self.f_rows, cout_pad=self.f_pad, bias=self.b_eff, algo=3)
+        return out
+
     # ---- input gradient ----------------------------------------------------------------------
     def dgrad(self, g, rows=None, res=None, mask=None, slope_mask=1.0, out=None, plus=None, gelu_mask=False):
         """Input gradient (+ res, masked).  plus: returns (out, out + plus) -- see fwd.  gelu_mask: multiply by GELU'(mask)
@@ -548,12 +570,19 @@ class ConvOp:
             for i in range(0, n, step):
                 j = min(n, i + step)
                 self.dgrad(g[i:j], rows, None if res is None else res[i:j], None if mask is None else mask[i:j], slope_mask,
-                           out[i:j])
+                           out[i:j], gelu_mask=gelu_mask)
             return out if plus is None else (out, ops.add(out, plus, out=o2))
         kh, kw, st, md = self.d_geo
         pad = self.pad if self.kind == "conv" else (1 if self.kind == "down" else 0)
         if self.kind == "conv":
             pad = self.k - 1 - self.pad
+        # GELU' rides only in the fp32 pointwise tile (refid_conv_desc.mask_mode = 1); every other tile would silently apply
+        # the leaky-step mask instead, so a request that cannot be honoured is an error, never a wrong gradient
+        gelu_ok = self.d_algo == 3 and self.wds is None and not (self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO) \
+            and not (self.wdp6 is not None and cnt > 32 and g.shape[3] % 16 == 0)
+        if gelu_mask and not gelu_ok:
+            raise RefidHipError(f"{self.name}: gelu_mask needs the fp32 pointwise input-gradient tile (d_algo {self.d_algo}); "
+                                f"apply ops.gelu_bwd separately")
         if self.wds is not None and (self.kind == "conv" or _fills_gpu(n, h, w, cnt, 4)):
             ops.conv2d(g, self.wds, out, kh=kh, kw=kw, stride=st, pad=1, mode=md, cout=cnt, cout_pad=self.sd_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=4, terms=self.split, **two)
@@ -566,36 +595,45 @@ class ConvOp:
             ops.conv2d(g, self.wdp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
                        res=res, mask=mask, slope_mask=slope_mask, algo=3, terms=6)
             return out if plus is None else (out, ops.add(out, plus, out=o2))
-        if self.d_algo == 3:
-            two = {}
+        fused_two = bool(two)                                    # was the second output handed to the tile?
+        if self.d_algo == 3:                                      # (the pointwise tile has no second output)
+            two, fused_two = {}, False
             if gelu_mask:
                 two = dict(mask_mode=1)
         ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
                    co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo, **two)
-        if plus is not None and not two:
+        if plus is not None and not fused_two:
             ops.add(out, plus, out=o2)
         return out if plus is None else (out, o2)
 
     # ---- weight / bias gradient ----------------------------------------------------------------
-    def wgrad(self, g, a, b=None, bias=True):
+    def wgrad(self, g, a, b=None, bias=True, i_base=0):
         """g: gradient w.r.t. this conv's (pre-epilogue) output; (a|b): its input sources.  bias=False: no bias-gradient
         contribution from this call (the extra call of a linearity split: the per-step calls already hold sum g).
+        i_base > 0: `a` holds the input channels i_base .. i_base + C_a of the conv (the time-independent half of a
+        linearity split): one-shot launch straight into that column block of the gradient, no bias share.
 
         Weight gradients are off BPTT's critical path (only input gradients feed the next step), so they are
         issued on a side stream: their kernels fill the tails/gaps of the dependent dgrad chain."""
         side = WGRAD_STREAM.get(g.device) if OVERLAP_WGRAD else None
         if side is None:
-            return self._wgrad(g, a, b, bias)
+            return self._wgrad(g, a, b, bias, i_base)
         for t in (g, a, b):
             if t is not None:
                 t.record_stream(side)                       # allocator must not recycle them early
         # deferred: the launch happens at the next flush_wgrads() -- ONE cross-stream dependency per batch instead
         # of one event record + wait per weight-gradient call (~1500 per step; each left a ~7 us bubble)
-        WGRAD_STREAM.pending.append((self, g, a, b, bias))
+        WGRAD_STREAM.pending.append((self, g, a, b, bias, i_base))
         if len(WGRAD_STREAM.pending) >= WGRAD_BATCH:
             flush_wgrads(g.device)
 
-    def _wgrad(self, g, a, b=None, bias=True):
+    def _wgrad(self, g, a, b=None, bias=True, i_base=0):
+        if i_base:
+            if self.kind != "conv" or b is not None or bias:
+                raise RefidHipError(f"{self.name}: a column-block weight gradient is one source, no bias, stride-1 conv")
+            ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=1, pad=self.pad, i_base=i_base, i_total=self.ci,
+                             algo=0, phase=0)
+            return
         if self.kind == "convT":
             # roles swapped (refid_hip.h): "g" := layer input (low res), "src" := output gradient
             ops.conv2d_wgrad(a, g, self.gw, kh=2, kw=2, stride=2, pad=0)
@@ -606,6 +644,9 @@ class ConvOp:
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
         if algo == 1 and b is not None and a.shape[3] % 32 != 0:
             algo = 0          # the Winograd weight-gradient tile picks the source per 32-channel tile (base 24, 40, 48 ...)
+        if algo == 1 and WGRAD_F4 and min(g.shape[1], g.shape[2]) >= WGRAD_F4_MIN_HW and g.shape[3] % 4 == 0 and \
+                a.shape[3] % 4 == 0 and (b is None or b.shape[3] % 4 == 0):
+            algo = 5          # Winograd F(3x3,4x4): 1.78x fewer fp32 MFMAs than algo 1
         if algo == 1 and WGRAD_WINO6 and not self.bf16:
             algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
@@ -1123,9 +1164,13 @@ class Engine:
             # fuse_two_dir's constant half, C1_b(S_b,i) + bias, on the stream that produced S_b,i and runs level i next
             for i, L in enumerate(self.enc_f):
                 with torch.cuda.stream(lvs[i]):
-                    if L.zero_s is None or L.zero_s.shape != Sb[i].shape:
-                        L.zero_s = torch.zeros_like(Sb[i])                 # (stands in for the s_t half; cached across steps)
-                    L.p_fuse = L.fuse.fwd(L.zero_s, Sb[i])
+                    if L.fuse.can_fwd_from() and L.C % L.fuse.f_kc == 0 and _pad4(L.fuse.co) == L.fuse.co:
+                        L.zero_s = None
+                        L.p_fuse = L.fuse.fwd_from(Sb[i], L.C)             # the S_b block of the packed weights, one source
+                    else:
+                        if L.zero_s is None or L.zero_s.shape != Sb[i].shape:
+                            L.zero_s = torch.zeros_like(Sb[i])             # (stands in for the s_t half; cached across steps)
+                        L.p_fuse = L.fuse.fwd(L.zero_s, Sb[i])
 
         out = torch.empty((B, T, self.out_chn, H, W), dtype=torch.float32, device=dev)
         out4 = torch.zeros((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
@@ -1319,7 +1364,10 @@ class Engine:
             g_xb[2] = ops.sum_n(keep["gb0"])
             for i, L in enumerate(self.enc_f):
                 gsum = ops.sum_n(keep["gf"][i])
-                L.fuse.wgrad(gsum, L.zero_s, Sb[i], bias=False)           # (sum_t g_f) (x) S_b
+                if L.zero_s is None:
+                    L.fuse.wgrad(gsum, Sb[i], bias=False, i_base=L.C)     # (sum_t g_f) (x) S_b, into columns C .. 2C
+                else:
+                    L.fuse.wgrad(gsum, L.zero_s, Sb[i], bias=False)
                 g_Sb[i] = L.fuse.dgrad(gsum, rows=(L.C, L.C))             # dL/dS_b = W_b^T sum_t g_f
             self._lin_level2_tail(self.enc_f[2], keep["gu"], xb, g_xb, first=True)
             g_xb[0] = ops.sum_n(keep["gy"])

@@ -492,10 +492,10 @@ def test_winograd_dgrad(cfg):
     (2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 256, 256, 256), (1, 5, 3, 64, 0, 128),
     (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 32, 32), (1, 8, 32, 32, 0, 3),
 ])
-@pytest.mark.parametrize("algo", [1, 3, 4])
+@pytest.mark.parametrize("algo", [1, 3, 4, 5])
 def test_winograd_wgrad(cfg, algo):
-    """algo 1: fp32 MFMA; experimental builds: algo 3 = six exact-split bf16 products per fp32 product, algo 4 = the fp32
-    tile fed by LDS-DMA into two buffers."""
+    """algo 1: fp32 MFMA, F(2x2,3x3); algo 5: fp32 MFMA, F(3x3,4x4) (wgrad_wino4.hip); experimental builds: algo 3 = six
+    exact-split bf16 products per fp32 product, algo 4 = the fp32 tile fed by LDS-DMA into two buffers."""
     ops = _ops()
     if algo in (3, 4):
         _need_experimental()
@@ -524,6 +524,30 @@ def test_winograd_wgrad(cfg, algo):
     np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=2 * ATOL * scale)
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 0, 64), (1, 48, 80, 64, 64, 64), (1, 32, 32, 128, 128, 128), (4, 32, 32, 32, 0, 32)])
+def test_wgrad_f4_accuracy_class(cfg):
+    """Winograd F(3x3,4x4) weight gradient (algo 5) against the float64 gradient on O(1) activations (offset, like the
+    LeakyReLU outputs it reads) and small output gradients: its deviation is in the fp32 class -- below 2e-5 of the
+    tensor's largest entry and within 10x of the F(2x2,3x3) tile's (algo 1); the bias gradient is a plain sum."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    x = rnd(N, Ca + Cb, H, W, seed=1)
+    x = torch.where(x > -0.3, x, 0.1 * x) + 0.2
+    w = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, 1, 1)
+    g = rnd(*y.shape, seed=4, scale=1e-3)
+    y.backward(g)
+    xa = nhwc(x[:, :Ca]); xb = nhwc(x[:, Ca:]) if Cb else None
+    err = {}
+    for algo in (1, 5):
+        dw = torch.zeros(Co, Ca + Cb, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")
+        ops.conv2d_wgrad(nhwc(g), xa, dw, kh=3, kw=3, stride=1, pad=1, in_b=xb, db=db, algo=algo)
+        err[algo] = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+        assert float((db.double().cpu() - b.grad).abs().max() / b.grad.abs().max()) < 1e-5
+    assert err[5] < 2e-5 and err[5] < 10 * max(err[1], 1e-6), err
+
+
 @pytest.mark.parametrize("ca,cb,group", [(48, 48, 1), (48, 48, 3), (40, 24, 1), (64, 64, 3)])
 def test_convop_two_source_weight_gradient_any_split(ca, cb, group):
     """engine.ConvOp: a two-source 3x3 conv whose first source is not a multiple of 32 channels (the Winograd
@@ -550,6 +574,7 @@ def test_convop_two_source_weight_gradient_any_split(ca, cb, group):
 
 
 @pytest.mark.parametrize("algo,cfg", [(0, (1, 16, 32, 64, 64, 64, 3)), (1, (1, 16, 32, 64, 64, 64, 3)),
+                                      (5, (1, 16, 32, 64, 64, 64, 3)), (5, (2, 20, 36, 32, 32, 96, 3)),
                                       (0, (2, 8, 16, 128, 0, 128, 1)), (0, (1, 16, 32, 64, 0, 64, 4))])
 def test_wgrad_slab_phases(algo, cfg):
     """Persistent slabs: overwrite (1), add (2, here with the second source missing as at the first
@@ -982,7 +1007,7 @@ def test_bf16_weight_gradient_tile(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 33, 64, 64, 128)])
-@pytest.mark.parametrize("algo", [1, 3, 4])
+@pytest.mark.parametrize("algo", [1, 3, 4, 5])
 def test_winograd_wgrad_grouped_time_steps(cfg, algo):
     """refid_wgrad_desc.groups: the Winograd weight gradients of several time steps of one conv in ONE launch (the weights
     are shared over T) == the same calls one by one -- persistent-slab phases included."""

@@ -283,7 +283,7 @@ def test_at_most_one_step_in_flight_and_prefetcher_hand_over():
     def run(prefetch):
         m = TwoImageEventRecurrentRestorationModel(_opt(6, 8))
         m.net_g.load_state_dict(P)
-        pre = CUDAPrefetcher(Loader(), {"num_gpu": 1}) if prefetch else None
+        pre = CUDAPrefetcher(Loader(), {"num_gpu": 1}, time_waits=True) if prefetch else None
         ends = []
         for it in range(1, 5):
             data = pre.next() if prefetch else {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batches[(it - 1) % 2].items()}

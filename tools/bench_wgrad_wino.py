@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""fp32 Winograd weight gradient at the config-2 shapes, 8 grouped time steps per launch as in the train step: the product
-tile (algo 1, register-staged single LDS buffer) against the LDS-DMA double-buffered experiment (algo 4; libraries built with
-REFID_EXPERIMENTAL_TILES=1).  Different K order, so not bit-equal: the largest relative difference is printed."""
+"""fp32 Winograd weight gradient at the config-2 shapes, 8 grouped time steps per launch as in the train step: the F(2x2,3x3)
+tile (algo 1, "regs") against the F(3x3,4x4) tile (algo 5, "f4"; default) or, with OTHER=dma, the LDS-DMA double-buffered
+experiment (algo 4; libraries built with REFID_EXPERIMENTAL_TILES=1).  Not bit-equal: the largest relative difference is
+printed."""
 import os
 import subprocess
 import sys
@@ -40,7 +41,7 @@ def run(tag, algo):
         dw.zero_(); db.zero_()
         slabs = go()
         ops.conv2d_wgrad(g0, a0, dw, kh=3, kw=3, pad=1, in_b=b0, db=db, algo=algo, phase=3, slabs=slabs)
-        fl = 2.0 * G * B * H * H * Co * Ci * 16 / 4
+        fl = 2.0 * G * B * H * H * Co * Ci * (36 / 16 if algo == 5 else 16 / 4)
         print(f"{tag} {name:26s} {t*1e6:8.1f} us  {fl/t/1e12:6.1f} TF/s issued", flush=True)
         out[name] = (dw.cpu(), db.cpu())
     torch.save(out, f"/tmp/wgrad_wino_{tag}.pt")
@@ -48,12 +49,13 @@ def run(tag, algo):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        run(sys.argv[1], {"regs": 1, "dma": 4}[sys.argv[1]])
+        run(sys.argv[1], {"regs": 1, "dma": 4, "f4": 5}[sys.argv[1]])
     else:
-        for tag in ("regs", "dma"):
+        other = os.environ.get("OTHER", "f4")                 # "dma": the LDS-DMA experiment (experimental builds)
+        for tag in ("regs", other):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), tag])
         import torch
-        a, b = torch.load("/tmp/wgrad_wino_regs.pt"), torch.load("/tmp/wgrad_wino_dma.pt")
+        a, b = torch.load("/tmp/wgrad_wino_regs.pt"), torch.load(f"/tmp/wgrad_wino_{other}.pt")
         for k in a:
             dwd = ((a[k][0] - b[k][0]).abs().max() / a[k][0].abs().max()).item()
             dbd = ((a[k][1] - b[k][1]).abs().max() / a[k][1].abs().max()).item()

@@ -28,7 +28,7 @@ class HB:
 
 
 hb = HB()
-pre = CUDAPrefetcher(hb, device=dev)
+pre = CUDAPrefetcher(hb, device=dev, time_waits=True)
 dev_batches = [{k: v.to(dev) for k, v in b.items()} for b in hb.b]
 it = 0
 

@@ -201,8 +201,8 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
     # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
     # the SURVEY 8(d) direct-convolution figure beside it.
     executed = fl * (16.0 / 36.0) if "wino" in name else fl
-    if "wino4" in name:
-        executed = fl * (9.0 / 36.0)                             # Winograd F(3x3,4x4) weight gradient: 36 MFMAs per 16 pixels x 9 taps
+    if "wino24" in name:
+        executed = fl * (12.0 / 36.0)                            # Winograd over 2x4 tiles: 24 MFMA-units per 8 pixels x 9 taps
     peak = FP32_MFMA_PEAK_TFLOPS
     ach = executed / sec / 1e12
     bound, unit = "mfma", "TFLOP/s"

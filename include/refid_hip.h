@@ -214,11 +214,14 @@ typedef struct refid_wgrad_desc {
                                                    4 = experiment (same builds; measured equal to algo 1 in the train step):
                                                    algo 1's fp32 tile fed by LDS-DMA into two buffers, one barrier per K
                                                    tile (pitches multiples of 4 floats, 16-byte aligned tensors);
-                                                   5 = Winograd F(3x3,4x4) (3x3 stride 1): the weight gradient as a 3x3-output
-                                                   correlation over 4x4 tiles of g -- 36 instead of 64 fp32 MFMAs per 16
-                                                   pixels (wgrad_wino4.hip; slabs [split][36][o][i]; pitches / channel counts
-                                                   multiples of 4 floats, 16-byte aligned tensors, c_a % 32 == 0 for two
-                                                   sources); deviation from the float64 gradient 4e-6 .. 8e-6 of scale  */
+                                                   5 = Winograd over 2x4 tiles of g (3x3 stride 1): F(3,2) down the rows,
+                                                   F(3,4) along them -- 24 instead of 32 fp32 MFMAs per 8 pixels, packed
+                                                   transforms (wgrad_wino24.hip; slabs [split][24][o][i]; pitches / channel
+                                                   counts multiples of 4 floats, 16-byte aligned tensors, c_a % 32 == 0 for two
+                                                   sources); deviation from the float64 gradient 3e-6 .. 6e-6 of scale;
+                                                   6 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured no faster
+                                                   than algo 1): Winograd F(3x3,4x4), 36 MFMAs per 16 pixels, six-wave
+                                                   workgroups (experimental/wgrad_wino4.hip)                          */
     int phase;                                  /* 0 = partial products + reduction in one call;
                                                    weights shared over the T recurrent steps can instead
                                                    keep accumulating in their own `slabs`:

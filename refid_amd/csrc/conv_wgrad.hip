@@ -668,14 +668,22 @@ int launch_w(const WgKArgs& a, const Geo& g, hipStream_t st) {
 // wgrad_wino.hip
 size_t refid_wgrad_wino_workspace_bytes(const refid_wgrad_desc* d);
 int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st);
-// wgrad_wino4.hip: Winograd F(3x3,4x4) (algo 5)
+// wgrad_wino24.hip: Winograd over 2x4 tiles, F(3,2) x F(3,4) (algo 5)
+size_t refid_wgrad_wino24_workspace_bytes(const refid_wgrad_desc* d);
+int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st);
+#ifdef REFID_EXPERIMENTAL_TILES
+// experimental/wgrad_wino4.hip: Winograd F(3x3,4x4) (algo 6)
 size_t refid_wgrad_wino4_workspace_bytes(const refid_wgrad_desc* d);
 int refid_wgrad_wino4_launch(const refid_wgrad_desc* d, hipStream_t st);
+#endif
 
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
-    if (d->algo == 5) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino4_workspace_bytes(d) : 0;
+    if (d->algo == 5) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
+#ifdef REFID_EXPERIMENTAL_TILES
+    if (d->algo == 6) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino4_workspace_bytes(d) : 0;
+#endif
     if (thin_ok(d)) return (size_t)thin_nsplit(d) * 4 * (WT_MAXG * 1024 + 32) * sizeof(float);
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     if (!p.ok) return 0;
@@ -699,7 +707,7 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
                 d->wo, eh, ew);
     REFID_CHECK(d->i_total > d->i_base && d->i_base >= 0 && d->o_real > 0 && d->o_real <= d->c_o,
                 "wgrad: i_base/i_total/o_real inconsistent");
-    REFID_CHECK(d->algo == 0 || ((d->algo >= 1 && d->algo <= 5) && d->kh == 3 && d->kw == 3 && d->stride == 1),
+    REFID_CHECK(d->algo == 0 || ((d->algo >= 1 && d->algo <= 6) && d->kh == 3 && d->kw == 3 && d->stride == 1),
                 "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
     REFID_CHECK(d->groups <= REFID_WGRAD_MAX_GROUPS, "wgrad: at most %d grouped time steps", REFID_WGRAD_MAX_GROUPS);
     REFID_CHECK(d->groups <= 1 || (d->phase != 3 && !thin_ok(d) && (d->algo != 0 || p.id != P_PW)),
@@ -707,7 +715,13 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     REFID_CHECK(d->algo != 2 || (p.id == P_W3 && d->pad == 1),
                 "wgrad: algo 2 (bf16 operands) needs more than 32 output and input channels and pad 1");
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return refid_wgrad_wino_launch(d, st);
-    if (d->algo == 5) return refid_wgrad_wino4_launch(d, st);
+    if (d->algo == 5) return refid_wgrad_wino24_launch(d, st);
+#ifdef REFID_EXPERIMENTAL_TILES
+    if (d->algo == 6) return refid_wgrad_wino4_launch(d, st);
+#else
+    REFID_CHECK(d->algo != 6, "wgrad: algo 6 (Winograd F(3x3,4x4)) is an experiment that did not beat algo 5; build with "
+                              "REFID_EXPERIMENTAL_TILES=1 to run it");
+#endif
     if (thin_ok(d)) {
         REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
         const int ns = thin_nsplit(d), nslab = ns * 4;

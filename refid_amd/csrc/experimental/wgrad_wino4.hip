@@ -32,11 +32,24 @@
 // i.e. on ONE XCD, so a tile is fetched from HBM once and re-read from that XCD's L2.
 // Split-K slabs [split][36][o][i] persist over the T recurrent steps exactly like wgrad_wino.hip's (phase 1 / 2 / 3); the
 // bias gradient is the transform point (1, 1) of G dY G^T (rows {1,1,1,1}: the tile sum), summed by wave 1 as it goes by.
-#include "common.h"
+#include "../common.h"
 #include <cstdlib>
 #include <type_traits>
 
+// Timing experiments only (tools/probes/w4_ablate.py builds the variants; results are wrong for n != 0):
+//   1: no DMA requests (stale tiles: no global traffic, no LDS writes)   2: no MFMAs (operands kept alive)
+//   3: no LDS reads (operands from opaque registers)   4: no barrier   5: 1 + 4   6: 1 + 3 + 4 (transforms + MFMAs alone)
+#ifndef REFID_W4_ABLATE
+#define REFID_W4_ABLATE 0
+#endif
+#define W4_NO_DMA (REFID_W4_ABLATE == 1 || REFID_W4_ABLATE == 5 || REFID_W4_ABLATE == 6)
+#define W4_NO_MFMA (REFID_W4_ABLATE == 2)
+#define W4_NO_LDS (REFID_W4_ABLATE == 3 || REFID_W4_ABLATE == 6)
+#define W4_NO_BAR (REFID_W4_ABLATE == 4 || REFID_W4_ABLATE == 5 || REFID_W4_ABLATE == 6)
+
 namespace {
+
+__device__ __forceinline__ float w4_fake(float seed) { asm volatile("" : "+v"(seed)); return seed; }
 
 constexpr int OT = 32, IT = 32;                // channel tile (o x i)
 constexpr int TC = 4;                          // Winograd tile columns per K tile (tile rows: 2 = the MFMA K halves)
@@ -64,81 +77,84 @@ struct W4Args {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const float lds_cf4;     // typed LDS pointers: 32-bit, ds_read instructions
 
-// one K tile out of one LDS buffer.  xb[k] -> X[4 kh][column k][li], gb[k] -> dY[4 kh][column k][li] (k = column mod 4), xe / xo =
-// columns 0 / 1 again: every read is base + a multiple of 256 bytes (a row is 9 x 256 B resp. 8 x 256 B, four columns are
-// 512 B), i.e. ds_read2st64_b32 with no address arithmetic; the bases are opaque to the compiler, which would otherwise
-// re-base with a v_add per 1 KB window.
-// The transforms are PACKED over two consecutive tile columns (steps s, s+1): a ds_read2st64 of (column c, column c + 4)
-// lands in a register pair, every transform instruction is a v_pk_* on such pairs (half the vector instructions -- they
-// do not hide under fp32 MFMAs on gfx950), and the MFMAs of step s / s+1 take the low / high halves.
+// The transforms of one wave (transform row I), PACKED over two consecutive tile columns (steps s, s+1): a ds_read2st64 of
+// (column c, column c + 4) lands in a register pair, every transform instruction is a v_pk_* on such pairs (half the vector
+// instructions -- they do not hide under fp32 MFMAs on gfx950), and the MFMAs of step s / s+1 take the low / high
+// halves.  LDS bases: xb[k] -> X[4 kh][column k][li], gb[k] -> dY[4 kh][column k][li] (k = column mod 4), xe / xo = columns
+// 0 / 1 again: every read is base + a multiple of 256 bytes (a row is 9 x 256 B resp. 8 x 256 B, four columns are 512 B),
+// i.e. ds_read2st64_b32 with no address arithmetic.  The bases are opaque to the compiler (it would re-base with a v_add per
+// 1 KB window), and one base per column residue makes the offset-NEIGHBOURS it pairs exactly (column c, column c + 4).
 template <int I>
-__device__ __forceinline__ void w4_tile(lds_cf4* const (&xb)[4], lds_cf4* xe, lds_cf4* xo, lds_cf4* const (&gb)[4],
-                                        f32x16 (&acc)[6], float& bs, f32x2& c0, f32x2& c1) {
-    constexpr int XR = XW * IT, GR = GW * OT;
-    const f32x2 k4 = {4.f, 4.f}, k5 = {-5.f, -5.f}, k2 = {2.f, 2.f};
-    // row I of B^T over the window rows, window columns (c, c + 4)
-    auto xrow = [&](int c) -> f32x2 {
-        lds_cf4* p = xb[c & 3] + (c & ~3) * IT;
-        auto ld = [&](int r) -> f32x2 { return f32x2{p[r * XR], p[r * XR + 4 * IT]}; };
-        if constexpr (I == 0) return k4 * ld(0) + (k5 * ld(2) + ld(4));
-        else if constexpr (I == 1) return (ld(3) + ld(4)) - k4 * (ld(1) + ld(2));
-        else if constexpr (I == 2) return k4 * (ld(1) - ld(2)) + (ld(4) - ld(3));
-        else if constexpr (I == 3) return k2 * (ld(3) - ld(1)) + (ld(4) - ld(2));
-        else if constexpr (I == 4) return (ld(4) - ld(2)) - k2 * (ld(3) - ld(1));
-        else return k4 * ld(1) + (k5 * ld(3) + ld(5));
-    };
-    // row I of G over the tile rows, tile columns (c, c + 4)
-    auto grow = [&](int c) -> f32x2 {
-        lds_cf4* p = gb[c & 3] + (c & ~3) * OT;
-        auto ld = [&](int r) -> f32x2 { return f32x2{p[r * GR], p[r * GR + 4 * OT]}; };
-        if constexpr (I == 0) return ld(0);
-        else if constexpr (I == 1) return (ld(0) + ld(2)) + (ld(1) + ld(3));
-        else if constexpr (I == 2) return (ld(0) + ld(2)) - (ld(1) + ld(3));
-        else if constexpr (I == 3) return k2 * (k4 * ld(3) + ld(1)) + (k4 * ld(2) + ld(0));
-        else if constexpr (I == 4) return (k4 * ld(2) + ld(0)) - k2 * (k4 * ld(3) + ld(1));
-        else return ld(3);
-    };
+struct W4Row {
+    static constexpr int XR = XW * IT, GR = GW * OT;
+    static constexpr int NX = (I == 0 || I == 5) ? 3 : 4;          // window rows this B^T row reads
+    static constexpr int X0 = I == 0 ? 0 : 1, XS = (I == 0 || I == 5) ? 2 : 1;
+    static constexpr int NG = (I == 0 || I == 5) ? 1 : 4;          // tile rows this G row reads
+    static constexpr int G0 = I == 5 ? 3 : 0;
+
+    // raw reads of one pair iteration: window columns 4s+2 .. 4s+5 (and their partners four columns on)
+    static __device__ __forceinline__ void x_issue(lds_cf4* const (&xb)[4], int s, f32x2 (&r)[4][NX]) {
 #pragma unroll
-    for (int s = 0; s < TC; s += 2) {
-        // window columns 4s+k (low half) and 4s+4+k (high half); columns 0 / 1 of the low half are the previous pair's
-        // columns 4 / 5 of the high half (c0 / c1 carry them; the tile's first two columns are computed)
-        const f32x2 t2 = xrow(4 * s + 2), t3 = xrow(4 * s + 3), t4 = xrow(4 * s + 4), t5 = xrow(4 * s + 5);
-        f32x2 t0, t1;
-        if (s == 0) {
-            lds_cf4* pe = xe; lds_cf4* po = xo;
-            auto l1 = [&](lds_cf4* p, int r) -> float { return p[r * XR]; };
-            float a0, a1;
-            if constexpr (I == 0) { a0 = 4.f * l1(pe, 0) + (-5.f * l1(pe, 2) + l1(pe, 4)); a1 = 4.f * l1(po, 0) + (-5.f * l1(po, 2) + l1(po, 4)); }
-            else if constexpr (I == 1) { a0 = (l1(pe, 3) + l1(pe, 4)) - 4.f * (l1(pe, 1) + l1(pe, 2)); a1 = (l1(po, 3) + l1(po, 4)) - 4.f * (l1(po, 1) + l1(po, 2)); }
-            else if constexpr (I == 2) { a0 = 4.f * (l1(pe, 1) - l1(pe, 2)) + (l1(pe, 4) - l1(pe, 3)); a1 = 4.f * (l1(po, 1) - l1(po, 2)) + (l1(po, 4) - l1(po, 3)); }
-            else if constexpr (I == 3) { a0 = 2.f * (l1(pe, 3) - l1(pe, 1)) + (l1(pe, 4) - l1(pe, 2)); a1 = 2.f * (l1(po, 3) - l1(po, 1)) + (l1(po, 4) - l1(po, 2)); }
-            else if constexpr (I == 4) { a0 = (l1(pe, 4) - l1(pe, 2)) - 2.f * (l1(pe, 3) - l1(pe, 1)); a1 = (l1(po, 4) - l1(po, 2)) - 2.f * (l1(po, 3) - l1(po, 1)); }
-            else { a0 = 4.f * l1(pe, 1) + (-5.f * l1(pe, 3) + l1(pe, 5)); a1 = 4.f * l1(po, 1) + (-5.f * l1(po, 3) + l1(po, 5)); }
-            t0 = f32x2{a0, t4[0]}; t1 = f32x2{a1, t5[0]};
-        } else {
-            t0 = f32x2{c0[1], t4[0]}; t1 = f32x2{c1[1], t5[0]};
+        for (int c = 0; c < 4; ++c) {
+            const int col = 4 * s + 2 + c;
+            lds_cf4* p = xb[col & 3] + (col & ~3) * IT;
+#pragma unroll
+            for (int k = 0; k < NX; ++k)
+                r[c][k] = W4_NO_LDS ? f32x2{w4_fake(1.f + c), w4_fake(2.f + k)} : f32x2{p[(X0 + k * XS) * XR], p[(X0 + k * XS) * XR + 4 * IT]};
         }
-        c0 = t4; c1 = t5;
-        const f32x2 x0 = grow(4 * s), x1 = grow(4 * s + 1), x2 = grow(4 * s + 2), x3 = grow(4 * s + 3);
-        f32x2 v[6], z[6];
-        // V = (row) B: the same six combinations over the window columns
-        v[0] = k4 * t0 + (k5 * t2 + t4);
-        v[1] = (t3 + t4) - k4 * (t1 + t2);
-        v[2] = k4 * (t1 - t2) + (t4 - t3);
-        const f32x2 d42 = t4 - t2, d31 = t3 - t1;
-        v[3] = k2 * d31 + d42;
-        v[4] = d42 - k2 * d31;
-        v[5] = k4 * t1 + (k5 * t3 + t5);
-        // Z = (row) G^T
-        const f32x2 e = x0 + x2, o = x1 + x3, e4 = k4 * x2 + x0, o4 = k4 * x3 + x1;
-        z[0] = x0; z[1] = e + o; z[2] = e - o; z[3] = k2 * o4 + e4; z[4] = e4 - k2 * o4; z[5] = x3;
-        if constexpr (I == 1) bs += z[1][0] + z[1][1];     // point (1, 1) = sum of the 4x4 gradient tile
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][h], z[j][h], acc[j], 0, 0, 0);
     }
-}
+    // the tile's first two window columns (read alone)
+    static __device__ __forceinline__ void x_issue01(lds_cf4* xe, lds_cf4* xo, float (&r)[2][NX]) {
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            r[0][k] = W4_NO_LDS ? w4_fake(1.f + k) : xe[(X0 + k * XS) * XR];
+            r[1][k] = W4_NO_LDS ? w4_fake(2.f + k) : xo[(X0 + k * XS) * XR];
+        }
+    }
+    // row I of B^T over the window rows
+    template <class T>
+    static __device__ __forceinline__ T x_row(const T (&r)[NX]) {
+        if constexpr (I == 0) return 4.f * r[0] + (-5.f * r[1] + r[2]);
+        else if constexpr (I == 1) return (r[2] + r[3]) - 4.f * (r[0] + r[1]);
+        else if constexpr (I == 2) return 4.f * (r[0] - r[1]) + (r[3] - r[2]);
+        else if constexpr (I == 3) return 2.f * (r[2] - r[0]) + (r[3] - r[1]);
+        else if constexpr (I == 4) return (r[3] - r[1]) - 2.f * (r[2] - r[0]);
+        else return 4.f * r[0] + (-5.f * r[1] + r[2]);
+    }
+    static __device__ __forceinline__ void g_issue(lds_cf4* const (&gb)[4], int s, f32x2 (&r)[4][NG]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = 4 * s + c;
+            lds_cf4* p = gb[col & 3] + (col & ~3) * OT;
+#pragma unroll
+            for (int k = 0; k < NG; ++k)
+                r[c][k] = W4_NO_LDS ? f32x2{w4_fake(1.f + c), w4_fake(2.f + k)} : f32x2{p[(G0 + k) * GR], p[(G0 + k) * GR + 4 * OT]};
+        }
+    }
+    // row I of G over the tile rows
+    static __device__ __forceinline__ f32x2 g_row(const f32x2 (&r)[NG]) {
+        if constexpr (I == 0 || I == 5) return r[0];
+        else if constexpr (I == 1) return (r[0] + r[2]) + (r[1] + r[3]);
+        else if constexpr (I == 2) return (r[0] + r[2]) - (r[1] + r[3]);
+        else if constexpr (I == 3) return 2.f * (4.f * r[3] + r[1]) + (4.f * r[2] + r[0]);
+        else return (4.f * r[2] + r[0]) - 2.f * (4.f * r[3] + r[1]);
+    }
+    // V = (row) B over the six window columns t[0..5]
+    static __device__ __forceinline__ void v_cols(const f32x2 (&t)[6], f32x2 (&v)[6]) {
+        v[0] = 4.f * t[0] + (-5.f * t[2] + t[4]);
+        v[1] = (t[3] + t[4]) - 4.f * (t[1] + t[2]);
+        v[2] = 4.f * (t[1] - t[2]) + (t[4] - t[3]);
+        const f32x2 d42 = t[4] - t[2], d31 = t[3] - t[1];
+        v[3] = 2.f * d31 + d42;
+        v[4] = d42 - 2.f * d31;
+        v[5] = 4.f * t[1] + (-5.f * t[3] + t[5]);
+    }
+    // Z = (row) G^T over the four tile columns
+    static __device__ __forceinline__ void z_cols(const f32x2 (&x)[4], f32x2 (&z)[6]) {
+        const f32x2 e = x[0] + x[2], o = x[1] + x[3], e4 = 4.f * x[2] + x[0], o4 = 4.f * x[3] + x[1];
+        z[0] = x[0]; z[1] = e + o; z[2] = e - o; z[3] = 2.f * o4 + e4; z[4] = e4 - 2.f * o4; z[5] = x[3];
+    }
+};
 
 __global__ __launch_bounds__(384, 3) void wgrad_wino4_kernel(const W4Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -159,13 +175,9 @@ __global__ __launch_bounds__(384, 3) void wgrad_wino4_kernel(const W4Args a) {
     const int p0 = min(split * chunk, ntAll), p1 = min(p0 + chunk, ntAll);
 
     // ---- DMA roles.  16-byte pieces: lane -> (pixel lane>>3 of 8, channel quad lane&7); 4-byte tail piece of a halo row:
-    // lane -> (pixel 16 + lane>>5, channel lane&31).  Out-of-range channels are forced out of range with an OR mask.
-    const int xq = ci0 + (lane & 7) * 4, xt = ci0 + li, gq = co0 + (lane & 7) * 4;
-    const int xlc = ((lane >> 3) * xld + (xFromA ? xq : xq - a.Ca)) * 4;           // bytes from the piece's first pixel
-    const int xlt = (kh * xld + (xFromA ? xt : xt - a.Ca)) * 4;
-    const int glc = ((lane >> 3) * a.ldG + gq) * 4;
-    const int xbadq = xq < a.Ctot ? 0 : -1, xbadt = xt < a.Ctot ? 0 : -1, gbadq = gq < a.Co ? 0 : -1;
-
+    // lane -> (pixel 16 + lane>>5, channel lane&31).  Out-of-range channels are forced out of range with an OR mask.  The
+    // per-lane constants are recomputed per request from an opaque copy of the lane id: hoisted out of the K loop they would
+    // hold six of the 72 registers the loop has next to its accumulators.
     // coordinates of the next tile to request (wave-uniform; advanced by increments)
     int qg, qn, qy, qx;
     {
@@ -175,6 +187,14 @@ __global__ __launch_bounds__(384, 3) void wgrad_wino4_kernel(const W4Args a) {
         qy = t % a.tilesY; qn = t / a.tilesY;
     }
     auto request = [&](int buf) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int l8 = ln >> 3, l32 = ln >> 5;
+        const int xq = ci0 + (ln & 7) * 4, xt = ci0 + (ln & 31), gq = co0 + (ln & 7) * 4;
+        const int xlc = (l8 * xld + (xFromA ? xq : xq - a.Ca)) * 4;                // bytes from the piece's first pixel
+        const int xlt = (l32 * xld + (xFromA ? xt : xt - a.Ca)) * 4;
+        const int glc = (l8 * a.ldG + gq) * 4;
+        const int xbadq = xq < a.Ctot ? 0 : -1, xbadt = xt < a.Ctot ? 0 : -1, gbadq = gq < a.Co ? 0 : -1;
         const int oy0 = qy * GH, ox0 = qx * GW;
         const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
         const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g[qg]), 0, limG, 0x00020000);
@@ -182,15 +202,15 @@ __global__ __launch_bounds__(384, 3) void wgrad_wino4_kernel(const W4Args a) {
             const_cast<float*>(xFromA ? a.inA[qg] : a.inB[qg]), 0, limX, 0x00020000);
         char* xdst = smem + buf * BUF_BYTES;
         char* gdst = xdst + X_BYTES;
-        const int cx0 = (unsigned)(ix0 + (lane >> 3)) < (unsigned)a.W ? 0 : -1;          // column tests (per lane)
-        const int cx1 = (unsigned)(ix0 + 8 + (lane >> 3)) < (unsigned)a.W ? 0 : -1;
-        const int cxt = (unsigned)(ix0 + 16 + kh) < (unsigned)a.W ? 0 : -1;
-        const int cg0 = ox0 + (lane >> 3) < a.Wo ? 0 : -1, cg1 = ox0 + 8 + (lane >> 3) < a.Wo ? 0 : -1;
+        const int cx0 = (unsigned)(ix0 + l8) < (unsigned)a.W ? 0 : -1;                   // column tests (per lane)
+        const int cx1 = (unsigned)(ix0 + 8 + l8) < (unsigned)a.W ? 0 : -1;
+        const int cxt = (unsigned)(ix0 + 16 + l32) < (unsigned)a.W ? 0 : -1;
+        const int cg0 = ox0 + l8 < a.Wo ? 0 : -1, cg1 = ox0 + 8 + l8 < a.Wo ? 0 : -1;
         // halo rows: wave w moves rows w and w + 6 (waves 0-3)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int r = wave + 6 * k;
-            if (r < XH) {
+            if (r < XH && !W4_NO_DMA) {
                 const int iy = iy0 + r;
                 const int rbad = (unsigned)iy < (unsigned)a.H ? 0 : -1;
                 const int base = ((qn * a.H + iy) * a.W + ix0) * xld * 4;                 // bytes, < 2^31 for live lanes (host check)
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(384, 3) void wgrad_wino4_kernel(const W4Args a) {
         const int gr0 = wave < 4 ? wave : 2 * wave - 4;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (k == 0 || wave >= 4) {
+            if ((k == 0 || wave >= 4) && !W4_NO_DMA) {
                 const int r = gr0 + k;
                 const int oy = oy0 + r;
                 const int rbad = oy < a.Ho ? 0 : -1;
@@ -237,27 +257,109 @@ __global__ __launch_bounds__(384, 3) void wgrad_wino4_kernel(const W4Args a) {
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     float bs = 0.f;
 
+    // The K loop as an explicit software pipeline (the scheduling fences pin the order; the compiler only places the waits).
+    // Per pair iteration (two tile columns, 12 MFMAs): gradient reads -> V column pass (from the window rows transformed one
+    // iteration earlier) -> Z -> the NEXT iteration's input reads are issued -> 12 MFMAs (the LDS latency rides under them)
+    // -> row pass of what has arrived.  A K tile is two iterations; its ONE barrier sits in front of the second
+    // iteration's MFMAs: behind it the next tile has landed and nobody reads this tile's buffer any more (this wave's last
+    // reads of it were consumed by the Z transform just before), so the tile after the next is requested into it and the
+    // next tile's first input reads are issued from the other buffer.
     auto kloop = [&](auto TI) {
         constexpr int I = decltype(TI)::value;
-        if (p0 < p1) request(0);
+        using R = W4Row<I>;
+        if (p0 >= p1) return;
+        lds_cf4* xb[4]; lds_cf4* gb[4]; lds_cf4* xe; lds_cf4* xo;
+        auto bases_x = [&](int buf) {
+            xe = (lds_cf4*)(smem + buf * BUF_BYTES) + (4 * kh) * (XW * IT) + li;
+            xb[0] = xe; xb[1] = xe + IT; xb[2] = xe + 2 * IT; xb[3] = xe + 3 * IT; xo = xe + IT;
+            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xe), "+v"(xo));
+        };
+        auto bases_g = [&](int buf) {
+            lds_cf4* ge = (lds_cf4*)(smem + buf * BUF_BYTES + X_BYTES) + (4 * kh) * (GW * OT) + li;
+            gb[0] = ge; gb[1] = ge + OT; gb[2] = ge + 2 * OT; gb[3] = ge + 3 * OT;
+            asm volatile("" : "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3]));
+        };
+        f32x2 t[6], v[6], z[6];
+        f32x2 xr[4][R::NX], gr[4][R::NG];
+        float x01[2][R::NX];
+        auto fence = [] { __builtin_amdgcn_sched_barrier(0); };
+        // window rows of a tile's FIRST iteration out of what x_issue / x_issue01 fetched
+        auto rows_first = [&] {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[2 + c] = R::x_row(xr[c]);
+            t[0] = f32x2{R::x_row(x01[0]), t[4][0]};
+            t[1] = f32x2{R::x_row(x01[1]), t[5][0]};
+        };
+        // ... of its second iteration: columns 0 / 1 of the low half are the first iteration's columns 4 / 5 of the high half
+        auto rows_second = [&] {
+            const float c0 = t[4][1], c1 = t[5][1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) t[2 + c] = R::x_row(xr[c]);
+            t[0] = f32x2{c0, t[4][0]};
+            t[1] = f32x2{c1, t[5][0]};
+        };
+        auto zpass = [&] {
+            f32x2 x[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) x[c] = R::g_row(gr[c]);
+            R::z_cols(x, z);
+            if constexpr (I == 1) bs += z[1][0] + z[1][1];                // point (1, 1) = sum of the 4x4 gradient tile
+        };
+        auto mfmas = [&] {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if (W4_NO_MFMA) { asm volatile("" :: "v"(v[j][h]), "v"(z[j][h])); continue; }
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][h], z[j][h], acc[j], 0, 0, 0);
+                }
+        };
+
+        request(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the first tile has landed (this wave's pieces)
+        if (!W4_NO_BAR) __builtin_amdgcn_s_barrier();      // ... everybody's
+        fence();
+        if (p0 + 1 < p1) request(1);
+        bases_x(0);
+        R::x_issue(xb, 0, xr);
+        R::x_issue01(xe, xo, x01);
+        rows_first();
         int cur = 0;
         for (int pt = p0; pt < p1; ++pt, cur ^= 1) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's pieces of buffer `cur` have landed
-            __builtin_amdgcn_s_barrier();                  // ... everybody's; and everybody is done with the other buffer
-            __builtin_amdgcn_sched_barrier(0);
-            if (pt + 1 < p1) request(cur ^ 1);
-            lds_cf4* xe = (lds_cf4*)(smem + cur * BUF_BYTES) + (4 * kh) * (XW * IT) + li;
-            lds_cf4* ge = (lds_cf4*)(smem + cur * BUF_BYTES + X_BYTES) + (4 * kh) * (GW * OT) + li;
-            // one opaque base per column residue mod 4 (the compiler pairs the ds_reads of one base that are NEIGHBOURS in
-            // offset: on such a base those are exactly (column c, column c + 4), the register pair the packed transforms
-            // want) + two for the tile's first two columns, which are read alone
-            lds_cf4* xb[4] = {xe, xe + IT, xe + 2 * IT, xe + 3 * IT};
-            lds_cf4* gb[4] = {ge, ge + OT, ge + 2 * OT, ge + 3 * OT};
-            lds_cf4* xo = xe + IT;
-            asm volatile("" : "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3]), "+v"(xe), "+v"(xo));
-            asm volatile("" : "+v"(gb[0]), "+v"(gb[1]), "+v"(gb[2]), "+v"(gb[3]));
-            f32x2 c0, c1;
-            w4_tile<I>(xb, xe, xo, gb, acc, bs, c0, c1);
+            // ---- first iteration (tile columns 0, 1) ----
+            fence();
+            bases_g(cur);
+            R::g_issue(gb, 0, gr);
+            fence();
+            R::v_cols(t, v);
+            fence();
+            zpass();
+            fence();
+            R::x_issue(xb, 2, xr);                         // second iteration's window columns, same buffer
+            fence();
+            mfmas();
+            fence();
+            rows_second();
+            // ---- second iteration (tile columns 2, 3) ----
+            fence();
+            bases_g(cur);
+            R::g_issue(gb, 2, gr);
+            fence();
+            R::v_cols(t, v);
+            fence();
+            zpass();
+            fence();
+            __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's pieces of the next tile have landed
+            if (!W4_NO_BAR) __builtin_amdgcn_s_barrier();  // ... everybody's; and everybody is done with this tile's buffer
+            fence();
+            if (pt + 2 < p1) request(cur);
+            bases_x(cur ^ 1);
+            R::x_issue(xb, 0, xr);                         // (past the last tile: stale data, never used)
+            fence();
+            mfmas();
+            fence();
+            R::x_issue01(xe, xo, x01);                     // (the tile's first two columns: 8 more registers would spill above)
+            rows_first();
         }
     };
     switch (wave) {
@@ -378,7 +480,8 @@ Geo4 geo4_of(const refid_wgrad_desc* d) {
     g.tilesY = cdiv(d->ho, GH);
     g.ntiles = g.tilesX * g.tilesY * d->n;
     // two workgroups per CU; a multiple of 8 splits keeps the workgroups of one K range on one XCD (grid x is fastest)
-    int want = cdiv(512, g.ncoT * g.nciT);
+    static const int wgs = []() { const char* e = getenv("REFID_W4_WGS"); return e ? atoi(e) : 512; }();
+    int want = cdiv(wgs, g.ncoT * g.nciT);
     if (want >= 8) want = want / 8 * 8;
     if (want < 1) want = 1;
     if (want > g.ntiles) want = g.ntiles;
@@ -399,6 +502,11 @@ int refid_wgrad_wino4_launch(const refid_wgrad_desc* d, hipStream_t st) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino4_kernel, LDS4_BYTES, "wgrad_wino4")) return rc;
     const Geo4 g = geo4_of(d);
+    if (getenv("REFID_W4_OCC")) {
+        int nb = -1;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, wgrad_wino4_kernel, 384, LDS4_BYTES);
+        fprintf(stderr, "wgrad_wino4: occupancy %d workgroups per CU (%s), grid %d x %d x %d\n", nb, hipGetErrorString(e), g.nsplit, g.nciT, g.ncoT);
+    }
     REFID_CHECK(d->c_b == 0 || d->c_a % IT == 0, "wgrad (Winograd F(3x3,4x4)): c_a must be a multiple of %d for two sources", IT);
     REFID_CHECK(d->ld_g % 4 == 0 && d->ld_a % 4 == 0 && (d->c_b == 0 || d->ld_b % 4 == 0) && d->c_o % 4 == 0 &&
                     d->c_a % 4 == 0 && d->c_b % 4 == 0,

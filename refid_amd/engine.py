@@ -226,10 +226,10 @@ WGRAD_GROUP = max(1, min(24, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
 # product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
 # are transformed and split on the fly, ~19 VALU per MFMA.  Off.
 WGRAD_WINO6 = os.environ.get("REFID_WGRAD_WINO6", "0") == "1"
-# Round 5: 3x3 weight gradients on the Winograd F(3x3,4x4) tile (refid_wgrad_desc.algo = 5: 36 instead of 64 fp32 MFMAs per
-# 16 output pixels) wherever the F(2x2,3x3) tile (algo 1) was used and the output has at least WGRAD_F4_MIN_HW rows and
-# columns (below that a 4x4 tile grid is mostly zero padding and the F(2x2) tile's smaller transform error is free).
-# REFID_WGRAD_F4=0 is the A/B switch back to algo 1.
+# Round 5: 3x3 weight gradients on the Winograd 2x4-tile form (refid_wgrad_desc.algo = 5: F(3,2) x F(3,4), 24 instead of 32
+# fp32 MFMAs per 8 output pixels, packed transforms) wherever the 2x2-tile form (algo 1) was used and the output has at
+# least WGRAD_F4_MIN_HW rows and columns (below that a 4 x 16-pixel K tile is mostly zero padding and the 2x2 form's smaller
+# transform error is free).  REFID_WGRAD_F4=0 is the A/B switch back to algo 1.
 WGRAD_F4 = os.environ.get("REFID_WGRAD_F4", "1") != "0"
 WGRAD_F4_MIN_HW = int(os.environ.get("REFID_WGRAD_F4_MIN_HW", "16"))
 
@@ -646,7 +646,7 @@ class ConvOp:
             algo = 0          # the Winograd weight-gradient tile picks the source per 32-channel tile (base 24, 40, 48 ...)
         if algo == 1 and WGRAD_F4 and min(g.shape[1], g.shape[2]) >= WGRAD_F4_MIN_HW and g.shape[3] % 4 == 0 and \
                 a.shape[3] % 4 == 0 and (b is None or b.shape[3] % 4 == 0):
-            algo = 5          # Winograd F(3x3,4x4): 1.78x fewer fp32 MFMAs than algo 1
+            algo = 5          # Winograd over 2x4 tiles: 0.75x the fp32 MFMAs of algo 1, packed transforms
         if algo == 1 and WGRAD_WINO6 and not self.bf16:
             algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:

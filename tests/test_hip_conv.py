@@ -492,12 +492,12 @@ def test_winograd_dgrad(cfg):
     (2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 256, 256, 256), (1, 5, 3, 64, 0, 128),
     (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 32, 32), (1, 8, 32, 32, 0, 3),
 ])
-@pytest.mark.parametrize("algo", [1, 3, 4, 5])
+@pytest.mark.parametrize("algo", [1, 3, 4, 5, 6])
 def test_winograd_wgrad(cfg, algo):
-    """algo 1: fp32 MFMA, F(2x2,3x3); algo 5: fp32 MFMA, F(3x3,4x4) (wgrad_wino4.hip); experimental builds: algo 3 = six
-    exact-split bf16 products per fp32 product, algo 4 = the fp32 tile fed by LDS-DMA into two buffers."""
+    """algo 1: fp32 MFMA, 2x2 tiles; algo 5: fp32 MFMA, 2x4 tiles (wgrad_wino24.hip); experimental builds: algo 3 = six
+    exact-split bf16 products per fp32 product, algo 4 = the fp32 tile fed by LDS-DMA into two buffers, algo 6 = 4x4 tiles."""
     ops = _ops()
-    if algo in (3, 4):
+    if algo in (3, 4, 6):
         _need_experimental()
     if algo == 4 and cfg[5] % 4:
         pytest.skip("the LDS-DMA kernel moves 16-byte pieces")
@@ -526,9 +526,9 @@ def test_winograd_wgrad(cfg, algo):
 
 @pytest.mark.parametrize("cfg", [(2, 64, 64, 64, 0, 64), (1, 48, 80, 64, 64, 64), (1, 32, 32, 128, 128, 128), (4, 32, 32, 32, 0, 32)])
 def test_wgrad_f4_accuracy_class(cfg):
-    """Winograd F(3x3,4x4) weight gradient (algo 5) against the float64 gradient on O(1) activations (offset, like the
-    LeakyReLU outputs it reads) and small output gradients: its deviation is in the fp32 class -- below 2e-5 of the
-    tensor's largest entry and within 10x of the F(2x2,3x3) tile's (algo 1); the bias gradient is a plain sum."""
+    """Winograd weight gradient over 2x4 tiles (algo 5: F(3,2) x F(3,4)) against the float64 gradient on O(1) activations
+    (offset, like the LeakyReLU outputs it reads) and small output gradients: its deviation is in the fp32 class -- below 2e-5
+    of the tensor's largest entry and within 10x of the 2x2-tile form's (algo 1); the bias gradient is a plain sum."""
     ops = _ops()
     N, H, W, Ca, Cb, Co = cfg
     x = rnd(N, Ca + Cb, H, W, seed=1)
@@ -1007,12 +1007,12 @@ def test_bf16_weight_gradient_tile(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 33, 64, 64, 128)])
-@pytest.mark.parametrize("algo", [1, 3, 4, 5])
+@pytest.mark.parametrize("algo", [1, 3, 4, 5, 6])
 def test_winograd_wgrad_grouped_time_steps(cfg, algo):
     """refid_wgrad_desc.groups: the Winograd weight gradients of several time steps of one conv in ONE launch (the weights
     are shared over T) == the same calls one by one -- persistent-slab phases included."""
     ops = _ops()
-    if algo in (3, 4):
+    if algo in (3, 4, 6):
         _need_experimental()
     N, H, W, Ca, Cb, Co = cfg
     steps = []

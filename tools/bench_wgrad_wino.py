@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """fp32 Winograd weight gradient at the config-2 shapes, 8 grouped time steps per launch as in the train step: the F(2x2,3x3)
-tile (algo 1, "regs") against the F(3x3,4x4) tile (algo 5, "f4"; default) or, with OTHER=dma, the LDS-DMA double-buffered
-experiment (algo 4; libraries built with REFID_EXPERIMENTAL_TILES=1).  Not bit-equal: the largest relative difference is
+tile (algo 1, "regs") against the 2x4-tile form (algo 5, "f24"; default) or, with OTHER=f4 / OTHER=dma, the F(3x3,4x4) tile
+(algo 6) / the LDS-DMA double-buffered F(2x2) experiment (algo 4), both in libraries built with REFID_EXPERIMENTAL_TILES=1.  Not bit-equal: the largest relative difference is
 printed."""
 import os
 import subprocess
@@ -22,7 +22,8 @@ def run(tag, algo):
     from bench_kernels import timeit, B
     G = int(os.environ.get("GROUPS", 8))
     out = {}
-    for name, H, Ca, Cb, Co in SHAPES:
+    only = os.environ.get("ONLY_SHAPE")
+    for name, H, Ca, Cb, Co in (SHAPES if only is None else [SHAPES[int(only)]]):
         torch.manual_seed(1)
         Ci = Ca + Cb
         steps = []
@@ -37,11 +38,16 @@ def run(tag, algo):
         def go():
             return ops.conv2d_wgrad(g0, a0, dw, kh=3, kw=3, pad=1, in_b=b0, db=db, algo=algo, phase=1, more=steps[1:])
         go()
+        if "REPS" in os.environ:                               # counter passes (tools/probes/w4_pmc.sh): a few launches, no timing loop
+            for _ in range(int(os.environ["REPS"])):
+                go()
+            torch.cuda.synchronize()
+            continue
         t = timeit(go)
         dw.zero_(); db.zero_()
         slabs = go()
         ops.conv2d_wgrad(g0, a0, dw, kh=3, kw=3, pad=1, in_b=b0, db=db, algo=algo, phase=3, slabs=slabs)
-        fl = 2.0 * G * B * H * H * Co * Ci * (36 / 16 if algo == 5 else 16 / 4)
+        fl = 2.0 * G * B * H * H * Co * Ci * ({5: 24 / 8, 6: 36 / 16}.get(algo, 16 / 4))
         print(f"{tag} {name:26s} {t*1e6:8.1f} us  {fl/t/1e12:6.1f} TF/s issued", flush=True)
         out[name] = (dw.cpu(), db.cpu())
     torch.save(out, f"/tmp/wgrad_wino_{tag}.pt")
@@ -49,9 +55,9 @@ def run(tag, algo):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        run(sys.argv[1], {"regs": 1, "dma": 4, "f4": 5}[sys.argv[1]])
+        run(sys.argv[1], {"regs": 1, "dma": 4, "f24": 5, "f4": 6}[sys.argv[1]])
     else:
-        other = os.environ.get("OTHER", "f4")                 # "dma": the LDS-DMA experiment (experimental builds)
+        other = os.environ.get("OTHER", "f24")                # "f4" / "dma": experimental builds (F(3x3,4x4), LDS-DMA F(2x2))
         for tag in ("regs", other):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), tag])
         import torch

@@ -635,11 +635,11 @@ def main(argv=None, claim_stdout=False):
                                          "profiles/*_nooverlap_kernel_stats.csv")
 
     strong = None
-    if world > 1 and args.scaling == "weak" and not args.no_strong_leg and args.batch % world == 0 and not args.dry_run:
+    if world > 1 and args.scaling == "weak" and not args.no_strong_leg and args.batch % world == 0:
         # the same GLOBAL batch as the 1-GPU configuration, sharded over the ranks (B = batch/N per GPU)
         sdt = timed(args.batch // world, args.steps, args.warmup)
         strong = {"global_batch": args.batch, "per_gpu_batch": args.batch // world,
-                  "value": round(args.batch * args.T * args.steps / sdt, 3), "unit": "frames/s",
+                  "value": None if args.dry_run else round(args.batch * args.T * args.steps / sdt, 3), "unit": "frames/s",
                   "ms_per_step": round(sdt / args.steps * 1e3, 2)}
     if use_dist:
         torch.distributed.barrier()

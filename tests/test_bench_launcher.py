@@ -44,6 +44,20 @@ def test_strong_scaling_shards_the_global_batch():
     assert r.returncode != 0 and "not divisible" in r.stderr
 
 
+def test_eight_gloo_ranks_dry_run_weak_and_strong_legs():
+    """The driver's widest launch (`--gpus 8`: the reference's 8-GPU recipe, README.md:138, dist_util.py:11-30) on CPU: eight
+    gloo ranks come up through the self-launcher, every rank pins itself to its share of the cores, the weak line carries the
+    strong-scaling leg of the same global batch (B = 1 per rank: the reference's batch_size_per_gpu), one JSON line."""
+    r = _run(["--gpus", "8", "--dry-run", "--backend", "gloo", "--steps", "2", "--warmup", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 8 and out["config"]["parallelism"] == "dp8" and out["dry_run"] is True
+    assert out["scaling"] == "weak" and out["config"]["global_batch"] == 64
+    assert out["strong"]["global_batch"] == 8 and out["strong"]["per_gpu_batch"] == 1 and out["strong"]["value"] is None
+    ncores = int(out["rank0_cpu_affinity"].split()[0])                                 # "<n> cores (a-b)"
+    assert 1 <= ncores <= max(1, (os.cpu_count() or 8) // 8 + 1)                      # rank 0 kept its share, not every core
+
+
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "2", "--dry-run", "--backend", "gloo"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0

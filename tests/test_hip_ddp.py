@@ -187,3 +187,84 @@ def test_one_rank_rccl_group_runs_the_same_collectives():
         a, b = sd[k].double().cpu(), sd0[k].double()
         disp = (a - P[k].double()).abs().max().item()
         assert (a - b).abs().max().item() <= 0.02 * disp + 1e-9, k
+
+
+def _order_worker(rank, world, port, ret):
+    """1-rank RCCL group; logs the host-side order of GradSync calls and Engine.backward_late, and whether the early
+    phase's all-reduces were still un-waited (asynchronous) when the backward sweep's BPTT started."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      REFID_FORCE_GRADSYNC="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from refid_amd import dist as rdist, engine as reng
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    log = []
+    sync_call, late = rdist.GradSync.__call__, reng.Engine.backward_late
+
+    def sync_logged(self, phase):
+        ev = torch.cuda.Event(enable_timing=True); ev.record()
+        sync_call(self, phase)
+        log.append(("sync", phase, len(self.pending), ev))
+
+    def late_logged(self, state):
+        ev = torch.cuda.Event(enable_timing=True); ev.record()
+        log.append(("late", None, len(model.grad_sync.pending), ev))
+        return late(self, state)
+
+    rdist.GradSync.__call__ = sync_logged
+    reng.Engine.backward_late = late_logged
+    model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
+    assert model.dist_on and model.grad_sync is not None
+    x, ev_, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    model.update_learning_rate(1)
+    model.feed_data({"lq": x, "voxel": ev_, "gt": gt})
+    model.optimize_parameters(1)
+    torch.cuda.synchronize()
+    order = [(k, p, n) for k, p, n, _ in log]
+    gaps = [log[i][3].elapsed_time(log[i + 1][3]) for i in range(len(log) - 1)]
+    ret[rank] = (order, gaps, len(model.grad_sync.runs["early"]), len(model.grad_sync.runs["late"]))
+    dist.destroy_process_group()
+
+
+def test_early_all_reduce_is_enqueued_before_the_backward_sweep_bptt():
+    """GradSync (dist.py): the early phase's RCCL all-reduces are issued between the two halves of BPTT (base_model.py:62-72
+    wraps the net in DDP, whose reducer overlaps buckets with backward; here: two explicit phases) and nobody waits for
+    them before the late phase -- host order, asynchrony, and the order of the events recorded on the compute stream."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_order_worker, args=(1, port, ret), nprocs=1, join=True)
+    order, gaps, n_early, n_late = ret[0]
+    assert [o[:2] for o in order] == [("sync", "early"), ("late", None), ("sync", "late")], order
+    assert n_early >= 1 and n_late >= 1
+    assert order[0][2] == n_early                  # the early works are pending (async_op=True), not waited
+    assert order[1][2] == n_early                  # ... still un-waited when backward_late starts
+    assert order[2][2] == 0                        # the late call waits for all of them
+    assert all(g >= 0.0 for g in gaps)             # compute-stream events in the same order
+
+
+def test_forced_gradsync_bench_costs_under_one_percent():
+    """`REFID_FORCE_GRADSYNC=1 python bench.py --gpus 1`: the N > 1 path (RCCL all-reduce on its own stream, pinned-host
+    prefetch on another, the compute streams) on one GPU: rccl_ranks = 1, and the step is within 1 % of the plain step --
+    the side streams do not serialise the step."""
+    import json, subprocess, sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+    def run(force):
+        e = dict(env, REFID_FORCE_GRADSYNC="1" if force else "0")
+        r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-roofline"],
+                           capture_output=True, text=True, env=e, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+
+    best = None
+    for attempt in range(2):                       # (two attempts: the boxes' run-to-run noise is ~0.3 %)
+        a, b = run(True), run(False)
+        assert a["rccl_ranks"] == 1 and b["rccl_ranks"] == 0
+        ratio = a["ms_per_step"] / b["ms_per_step"]
+        best = ratio if best is None else min(best, ratio)
+        if best <= 1.01:
+            break
+    assert best <= 1.01, (a["ms_per_step"], b["ms_per_step"])

@@ -675,6 +675,9 @@ def main(argv=None, claim_stdout=False):
             out["h2d_ms_exposed"] = h2d["exposed_ms"]
         if pinned:
             out["rank0_cpu_affinity"] = f"{len(pinned)} cores ({pinned[0]}-{pinned[-1]})"
+        gs = getattr(model, "grad_sync", None)
+        if gs is not None and getattr(gs, "calls", 0):
+            out["gradsync_host_ms_per_step"] = {k: round(v / gs.calls * 1e3, 3) for k, v in gs.host_s.items()}
         if args.dry_run:
             out["dry_run"] = True
             out["backend"] = args.backend

@@ -522,6 +522,105 @@ __global__ __launch_bounds__(256) void wgrad_thin_reduce_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Thin-OUTPUT 3x3 weight gradient (c_o <= 4: `pred`, 32 -> 3, XXNet_final_attenfusion_arch.py:215; its gradient has one real
+// channel triple per pixel).  As a GEMM tile it fills 3 of 32 output-channel rows (the W3_32x32 plan ran at 0.07 of HBM,
+// 913 us per grouped launch); it is a STREAMING REDUCTION: per input pixel q and lane = input channel i,
+//     dW[o][i][ky][kx] += x[q][i] * g[q + (1 - ky, 1 - kx)][o]
+// -- one coalesced 128-byte read of x per pixel, the 3 x 3 window of gradient pixels (one float4 each, the same address
+// for the 32 lanes: a broadcast read) slides along the row, 9 NO multiply-adds per lane, nothing staged.  A workgroup =
+// 8 half-waves, each walking whole image rows of a contiguous row range (split); the eight partial sums are added in order
+// through LDS into the split's slab, laid out exactly like the MFMA tile's ([split][tap][CoP][CiP]), so phases, grouping
+// and the deterministic slab reduction are the plan's own.
+template <int NO>
+__global__ __launch_bounds__(256) void wgrad_thinout_kernel(const WgKArgs a) {
+    __shared__ float sred[8 * (NO * 9 * 32 + 4)];
+    const int hw = threadIdx.x >> 5, li = threadIdx.x & 31;
+    const int split = blockIdx.x;
+    const long long rows = (long long)a.groups * a.N * a.H;
+    const long long chunk = (rows + a.nsplit - 1) / a.nsplit;
+    const long long r0 = split * chunk, r1 = min(r0 + chunk, rows);
+    const bool iok = li < a.Ctot;
+    float acc[NO][9];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[o][t] = 0.f;
+    float bs[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) bs[o] = 0.f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (long long row = r0 + hw; row < r1; row += 8) {
+        const int grp = (int)(row / ((long long)a.N * a.H));
+        const int rem = (int)(row - (long long)grp * a.N * a.H);
+        const int y = rem % a.H;
+        const float* xp = a.inA[grp] + (long long)rem * a.W * a.ldA + li;
+        const float* gp = a.g[grp] + (long long)rem * a.W * a.ldG;              // gradient row y (same pixel grid: stride 1, pad 1)
+        const bool up = y > 0, dn = y + 1 < a.H;
+        // window rows: r = 0 -> gradient row y - 1 (taps ky = 2), 1 -> y, 2 -> y + 1 (ky = 0); columns slide
+        auto gload = [&](int r, int x) -> f32x4 {
+            const bool ok = (r == 1 || (r == 0 ? up : dn)) && x >= 0 && x < a.W;
+            const float* p = gp + ((long long)(r - 1) * a.W + (ok ? x : 0)) * a.ldG;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? p : gp);
+            return ok ? v : zero4;
+        };
+        f32x4 w0[3], w1[3], w2[3];                          // columns x - 1, x, x + 1
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { w0[r] = zero4; w1[r] = gload(r, 0); }
+        for (int x = 0; x < a.W; ++x) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) w2[r] = gload(r, x + 1);
+            const float xv = iok ? xp[(long long)x * a.ldA] : 0.f;
+#pragma unroll
+            for (int o = 0; o < NO; ++o) {
+                // tap (ky, kx) pairs with the gradient at (y + 1 - ky, x + 1 - kx) = window[2 - ky][2 - kx]
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    acc[o][ky * 3 + 0] = fmaf(xv, w2[2 - ky][o], acc[o][ky * 3 + 0]);
+                    acc[o][ky * 3 + 1] = fmaf(xv, w1[2 - ky][o], acc[o][ky * 3 + 1]);
+                    acc[o][ky * 3 + 2] = fmaf(xv, w0[2 - ky][o], acc[o][ky * 3 + 2]);
+                }
+                bs[o] += w1[1][o];                          // (every lane of the half-wave holds the same sum)
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { w0[r] = w1[r]; w1[r] = w2[r]; }
+        }
+    }
+    // the eight half-waves in order
+    float* mine = sred + hw * (NO * 9 * 32 + 4);
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) mine[(o * 9 + t) * 32 + li] = acc[o][t];
+    if (li == 0) {
+#pragma unroll
+        for (int o = 0; o < NO; ++o) mine[NO * 9 * 32 + o] = bs[o];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NO * 9 * 32 + NO; e += 256) {
+        const int src = e < NO * 9 * 32 ? e : NO * 9 * 32 + (e - NO * 9 * 32);
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += sred[k * (NO * 9 * 32 + 4) + src];
+        if (e < NO * 9 * 32) {
+            const int i = e & 31, t = (e >> 5) % 9, o = (e >> 5) / 9;
+            if (i < a.CiP) {
+                float* dst = a.slabs + (((long long)split * 9 + t) * a.CoP + o) * a.CiP + i;
+                *dst = a.accum ? *dst + s : s;
+            }
+        } else if (a.bslabs != nullptr) {
+            float* dst = a.bslabs + (long long)split * a.CoP + (e - NO * 9 * 32);
+            *dst = a.accum ? *dst + s : s;
+        }
+    }
+}
+
+const bool USE_THINOUT_WGRAD = !(getenv("REFID_THINOUT_WGRAD") && getenv("REFID_THINOUT_WGRAD")[0] == '0');
+bool thinout_ok(const refid_wgrad_desc* d) {
+    return USE_THINOUT_WGRAD && d->algo == 0 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->c_o <= 4 &&
+           d->c_b == 0 && d->c_a <= 32 && d->i_total - d->i_base <= 32 && d->ld_g % 4 == 0 && d->ho == d->h && d->wo == d->w;
+}
+
 bool thin_ok(const refid_wgrad_desc* d) {
     return USE_THIN_WGRAD && d->algo == 0 && d->kh == d->kw && d->kh * d->kw <= 32 && d->kh >= 3 && d->stride == 1 &&
            d->c_a == 4 && d->c_b == 0 && d->c_o <= 32 && d->i_base == 0 && d->i_total <= 4 && 2 * d->pad == d->kh - 1 &&
@@ -784,6 +883,18 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
         if (sn == 2) hipLaunchKernelGGL(wgrad_pw_kernel<2>, grid, dim3(256), 0, st, w);
         else hipLaunchKernelGGL(wgrad_pw_kernel<1>, grid, dim3(256), 0, st, w);
         REFID_LAUNCH_CHECK("wgrad_pw");
+        rc = 0;
+    } else if (d->phase != 3 && p.id == P_W3_32x32 && thinout_ok(d)) {
+        for (int k = 0; k < ngrp; ++k)
+            REFID_CHECK((uintptr_t)a.g[k] % 16 == 0, "wgrad (thin output): the gradient tensor must be 16-byte aligned (group %d)", k);
+        dim3 grid(g.nsplit);
+        switch (d->o_real) {
+            case 1: hipLaunchKernelGGL(wgrad_thinout_kernel<1>, grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(wgrad_thinout_kernel<2>, grid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL(wgrad_thinout_kernel<3>, grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL(wgrad_thinout_kernel<4>, grid, dim3(256), 0, st, a); break;
+        }
+        REFID_LAUNCH_CHECK("wgrad_thinout");
         rc = 0;
     } else if (d->phase != 3 && d->algo == 2) {
         rc = refid_wgrad_bf16_launch(a, g.nciT, g.ncoT, st);

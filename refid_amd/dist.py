@@ -15,6 +15,7 @@ either way, so four large slices are used rather than many
 Averaging (1/world) is folded into the fused clip+AdamW kernel (grad_scale).
 """
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -113,8 +114,11 @@ class GradSync:
         self.group = group
         self.runs = bucket_slices(offsets, flat_grad.numel())
         self.pending = []
+        self.host_s = {"early": 0.0, "late": 0.0}      # host time spent inside the calls (enqueue only: nothing here may block)
+        self.calls = 0
 
     def __call__(self, phase):
+        t0 = time.perf_counter()
         for a, b in self.runs[phase]:
             self.pending.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group,
                                                 async_op=True))
@@ -122,3 +126,5 @@ class GradSync:
             for w in self.pending:
                 w.wait()
             self.pending = []
+            self.calls += 1
+        self.host_s[phase] += time.perf_counter() - t0

@@ -149,8 +149,20 @@ EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
 # stream, joined by one cross-stream dependency per level and step.  The ramp-up / tail of one chain's launches and the small
 # grids of the deep levels overlap the other chains (B=1: 124 -> 112 ms/step; B=8: < 1 %).  BPTT stays on one stream + the
 # weight-gradient side stream: the same wavefront over BPTT measured SLOWER (B=1 120 ms, B=8 544 ms: the weight-gradient
-# stream then has to wait for every chain).  REFID_PIPELINE=0: one chain.
-PIPELINE = os.environ.get("REFID_PIPELINE", "1") != "0"
+# stream then has to wait for every chain).  REFID_PIPELINE=0: one chain; 1: always; default "auto": only while the batch
+# leaves the chip room (B H W <= PIPELINE_MAX_PIX: B <= 4 at 256 x 256).  Every stream beyond the device's four hardware
+# queues shares a queue with another one: with the three chain streams next to the weight-gradient stream, the input
+# prefetch stream and RCCL's stream, a B=8 step lost 2 % -- and 4.5 % (18 ms) with a process group up -- to copies and
+# barrier packets queued in front of an unrelated stream's kernels (round 5: tools/diag_gradsync.py, DESIGN.md section 5;
+# REFID_FORCE_GRADSYNC=1: 429.7 vs 428.6 ms plain once the chains are off, 462 vs 442 with them), while the chains
+# themselves bought < 1 % at B=8 (B=1: 120.3 -> 112.5 ms, B=4: 248.3 -> 245.8).
+_PIPE_ENV = os.environ.get("REFID_PIPELINE", "auto")
+PIPELINE = "auto" if _PIPE_ENV == "auto" else _PIPE_ENV != "0"
+PIPELINE_MAX_PIX = int(os.environ.get("REFID_PIPELINE_MAX_PIX", str(4 * 256 * 256)))
+
+
+def use_pipeline(b, h, w):
+    return PIPELINE if isinstance(PIPELINE, bool) else b * h * w <= PIPELINE_MAX_PIX
 PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
 # The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
 # 199-203,211) and their BPTT counterparts (g_di + g_hd, g_b0 + g_skip) leave with the PRODUCING tile as a second output
@@ -1134,7 +1146,8 @@ class Engine:
             self.pred.fwd(head, out=q_pred[..., :self.out_chn])            # pred(head) + bias
 
         main = torch.cuda.current_stream()
-        lvs = [main, LV_STREAMS[0].get(dev), LV_STREAMS[1].get(dev)] if PIPELINE else [main, main, main]
+        pipe = use_pipeline(B, H, W)
+        lvs = [main, LV_STREAMS[0].get(dev), LV_STREAMS[1].get(dev)] if pipe else [main, main, main]
         for s_ in lvs[1:]:
             if s_ is not main:
                 s_.wait_stream(main)                   # image branch, event head: everything issued so far
@@ -1177,7 +1190,7 @@ class Engine:
         hf = [None, None, None]
         hd = [None, None, None]
         steps_f = []
-        dstream = DEC_STREAM.get(dev) if PIPELINE else None
+        dstream = DEC_STREAM.get(dev) if pipe else None
         if dstream is not None:
             dstream.wait_stream(main)                  # xb, head ...: everything issued so far
 

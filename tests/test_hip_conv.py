@@ -194,7 +194,10 @@ def test_conv_transpose_fwd_and_dgrad(cfg):
     (1, 16, 32, 32, 32, 32, 3, 1, 1),         # narrow-output tile
     (1, 16, 32, 32, 0, 64, 3, 1, 1),          # narrow-input tile
     (2, 8, 32, 32, 0, 32, 3, 1, 1),           # both narrow
-    (1, 8, 32, 32, 0, 3, 3, 1, 1),            # pred: 3 real output rows (g padded to 4)
+    (1, 8, 32, 32, 0, 3, 3, 1, 1),            # pred: 3 real output rows (g padded to 4) -- thin-output streaming kernel
+    (2, 9, 17, 32, 0, 3, 3, 1, 1),            #   ... ragged rows / columns, two samples
+    (1, 5, 3, 16, 0, 1, 3, 1, 1),             #   ... one output channel, 16 input channels
+    (3, 12, 20, 32, 0, 4, 3, 1, 1),           #   ... four real output channels
     (1, 16, 24, 28, 0, 32, 5, 1, 2),
     (2, 8, 16, 128, 128, 128, 1, 1, 0),
     (1, 16, 16, 32, 0, 64, 1, 1, 0),
@@ -230,6 +233,38 @@ def test_conv_wgrad(cfg):
     scale = max(1.0, float(w.grad.abs().max()))
     np.testing.assert_allclose(dw.double().cpu().numpy() / 2, w.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
     np.testing.assert_allclose(db.double().cpu().numpy() / 2, b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 24, 32, 3), (1, 9, 40, 32, 4)])
+def test_thin_output_wgrad_phases_and_groups(cfg):
+    """The streaming form of the thin-output 3x3 weight gradient (`pred`, arch:215) writes the plan's own slabs: persistent
+    phases (overwrite / add / reduce) and grouped time steps give the one-shot gradients' sum; REFID_THINOUT_WGRAD=0 (the
+    MFMA tile it replaces) is compared in a subprocess-free way through torch."""
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    w = rnd(Co, Ci, 3, 3, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    steps = []
+    for t in range(3):
+        x = rnd(N, Ci, H, W, seed=10 + t)
+        g = rnd(N, Co, H, W, seed=20 + t)
+        F.conv2d(x, w, b, 1, 1).backward(g)
+        gd = nhwc(g)
+        if Co % 4:
+            buf = torch.zeros(*gd.shape[:3], 4, device="cuda"); buf[..., :Co] = gd; gd = buf
+        steps.append((gd, nhwc(x), None))
+    kw = dict(kh=3, kw=3, stride=1, pad=1)
+    for grouping in ([[0], [1], [2]], [[0, 1, 2]], [[0], [1, 2]]):
+        dw = torch.zeros(Co, Ci, 3, 3, device="cuda"); db = torch.zeros(Co, device="cuda")
+        sl, first = None, True
+        for grp in grouping:
+            (g0, a0, _), more = steps[grp[0]], [steps[i] for i in grp[1:]]
+            sl = ops.conv2d_wgrad(g0, a0, dw, db=db, phase=1 if first else 2, slabs=sl, more=more, **kw)
+            first = False
+        ops.conv2d_wgrad(steps[0][0], steps[0][1], dw, db=db, phase=3, slabs=sl, **kw)
+        scale = max(1.0, float(w.grad.abs().max()))
+        np.testing.assert_allclose(dw.double().cpu().numpy(), w.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+        np.testing.assert_allclose(db.double().cpu().numpy(), b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
 
 
 def test_conv_transpose_wgrad():

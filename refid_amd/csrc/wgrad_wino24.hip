@@ -55,14 +55,15 @@ namespace {
 
 __device__ __forceinline__ float w24_fake(float seed) { asm volatile("" : "+v"(seed)); return seed; }
 
-constexpr int OT = 64, IT = 32;                // channel tile (o x i); the gradient tile is staged as two 32-channel halves
+constexpr int IT = 32;                         // input-channel tile; output-channel tile = 32 NS (NS = 2; 1 for c_o <= 32): the
+                                               // gradient tile is staged as NS 32-channel halves
 constexpr int TC = 4;                          // Winograd tile columns per K tile (tile rows: 2 = the MFMA K halves)
 constexpr int GH = 4, GW = 4 * TC;             // output-gradient pixels of a K tile
 constexpr int XH = GH + 2, XW = GW + 2;        // input halo
 constexpr int X_BYTES = XH * XW * IT * 4;      // 13,824
 constexpr int GS_BYTES = GH * GW * 32 * 4;     // 8,192 per 32-channel half
-constexpr int BUF_BYTES = X_BYTES + 2 * GS_BYTES;      // 30,208
-constexpr int LDS24_BYTES = 2 * BUF_BYTES;     // 60,416: two workgroups per CU
+constexpr int buf_bytes(int ns) { return X_BYTES + ns * GS_BYTES; }     // 30,208 (NS = 2) / 22,016
+constexpr int lds24_bytes(int ns) { return 2 * buf_bytes(ns); }         // 60,416: two workgroups per CU / 44,032: three
 constexpr int NXI = 24;
 typedef __attribute__((address_space(3))) void* lds_ptr24;
 typedef __attribute__((address_space(3))) const float lds_cf24;     // typed LDS pointers: 32-bit, ds_read instructions
@@ -156,7 +157,9 @@ struct W24Row {
     }
 };
 
-__global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
+template <int NS>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(const W24Args a) {
+    constexpr int OT = 32 * NS, BUF_BYTES = buf_bytes(NS);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -210,7 +213,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
         char* xdst = smem + buf * BUF_BYTES;
         char* gdst = xdst + X_BYTES;
         const bool fast = fullch && ix0 >= 0 && ix0 + XW <= a.W && ox0 + GW <= a.Wo && xld * 8 * 4 < 0x100000 && a.ldG * 8 * 4 < 0x100000;
-        const int q0 = wave < 2 ? wave : 3 * wave - 4, nq = wave < 2 ? 1 : 3;     // gradient (half, row) pairs of this wave
+        // gradient (half, row) pairs q = 4 half + row of this wave: NS = 2: wave 0 q = 0, wave 1 q = 1, wave 2 q = 2..4, wave 3
+        // q = 5..7 (with the halo rows: 8 / 8 / 9 / 9 DMA instructions); NS = 1: waves 2 / 3 two rows each (6 / 6 / 7 / 7)
+        const int q0 = NS == 2 ? (wave < 2 ? wave : 3 * wave - 4) : 2 * (wave - 2), nq = NS == 2 ? (wave < 2 ? 1 : 3) : (wave < 2 ? 0 : 2);
         if (fast) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
         } else {
             const int l8 = lane >> 3, l32 = lane >> 5;
             const int xbadq = xq < a.Ctot ? 0 : -1, xbadt = xt < a.Ctot ? 0 : -1;
-            const int gbad0 = gq < a.Co ? 0 : -1, gbad1 = gq + 32 < a.Co ? 0 : -1;
+            const int gbad0 = gq < a.Co ? 0 : -1, gbad1 = gq + 32 < a.Co ? 0 : -1;         // (NS = 1: no second half)
             const int cx0 = (unsigned)(ix0 + l8) < (unsigned)a.W ? 0 : -1;               // column tests (per lane)
             const int cx1 = (unsigned)(ix0 + 8 + l8) < (unsigned)a.W ? 0 : -1;
             const int cxt = (unsigned)(ix0 + 16 + l32) < (unsigned)a.W ? 0 : -1;
@@ -256,7 +261,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
                                                              (base + 16 * xld * 4 + xlt) | xbadt | rbad | cxt, 0, 0, 0);
                 }
             }
-            // gradient (half, row) pairs q = 4 half + row: wave 0 moves q = 0, wave 1 q = 1, wave 2 q = 2..4, wave 3 q = 5..7
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k < nq && !W24_NO_DMA) {
@@ -294,19 +298,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
         }
     };
 
-    f32x16 acc[6][2];                                      // [j][o half]
+    f32x16 acc[6][NS];                                     // [j][o half]
 #pragma unroll
     for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int sm = 0; sm < 2; ++sm)
+        for (int sm = 0; sm < NS; ++sm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][sm][r] = 0.f;
-    float bs[2] = {0.f, 0.f};
+    float bs[NS];
+#pragma unroll
+    for (int sm = 0; sm < NS; ++sm) bs[sm] = 0.f;
 
     // The LDS bases point into buffer 0 and never change: buffer 1 is 118 x 256 bytes further, an immediate of the same
     // ds_read2st64 (the largest unit offset is 218 of 255), so the K loop is written for a PAIR of tiles (buffer 0, buffer 1)
     // and carries no address arithmetic at all.
-    static_assert(BUF_BYTES % 256 == 0 && (BUF_BYTES + X_BYTES + GS_BYTES + 4 * GW * 32 * 4) / 256 < 256, "ds_read2st64 offset range");
+    static_assert(BUF_BYTES % 256 == 0 && (BUF_BYTES + X_BYTES + (NS - 1) * GS_BYTES + 4 * GW * 32 * 4) / 256 < 256, "ds_read2st64 offset range");
     lds_cf24* xe = (lds_cf24*)smem + (2 * kh) * (XW * IT) + li;
     lds_cf24* ge = (lds_cf24*)(smem + X_BYTES) + (2 * kh) * (GW * 32) + li;
     lds_cf24* xb[4] = {xe, xe + IT, xe + 2 * IT, xe + 3 * IT};
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
                 f32x2 v[6];
                 R::v_cols(t, v);
 #pragma unroll
-                for (int sm = 0; sm < 2; ++sm) {
+                for (int sm = 0; sm < NS; ++sm) {
                     f32x2 x[4], z[6];
                     R::g_rows(gbb, s, sm, x);
                     R::z_cols(x, z);
@@ -388,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
     for (int j = 0; j < 6; ++j) {
         float* sl = a.slabs + ((long long)(split * NXI + wave * 6 + j) * a.CoP) * a.CiP;
 #pragma unroll
-        for (int sm = 0; sm < 2; ++sm) {
+        for (int sm = 0; sm < NS; ++sm) {
             const int co = co0 + sm * 32 + li;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
@@ -403,9 +409,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_wino24_kernel(const W24Args a) {
         }
     }
     if (a.bslabs != nullptr && blockIdx.y == 0 && wave == 1) {
-        // wave 1 holds the tile sums of the 64 output channels: the two tile rows (kh) by one shuffle -- fixed order
+        // wave 1 holds the tile sums of the output channels: the two tile rows (kh) by one shuffle -- fixed order
 #pragma unroll
-        for (int sm = 0; sm < 2; ++sm) {
+        for (int sm = 0; sm < NS; ++sm) {
             const float tot = bs[sm] + __shfl_xor(bs[sm], 32, 64);
             if (kh == 0) {
                 float* dst = a.bslabs + (long long)split * a.CoP + co0 + sm * 32 + li;
@@ -483,17 +489,21 @@ __global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs
 
 struct Geo24 { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
 
+int ns_of(const refid_wgrad_desc* d) { return d->c_o <= 32 ? 1 : 2; }      // 32-channel output tile for the thin layers
+
 Geo24 geo24_of(const refid_wgrad_desc* d) {
     Geo24 g;
+    const int OT = 32 * ns_of(d);
     g.ncoT = cdiv(d->c_o, OT);
     const int ci_geo = (d->phase != 0) ? d->i_total - d->i_base : d->c_a + d->c_b;     // stable across steps
     g.nciT = cdiv(ci_geo > d->c_a + d->c_b ? ci_geo : d->c_a + d->c_b, IT);
     g.tilesX = cdiv(d->wo, GW);
     g.tilesY = cdiv(d->ho, GH);
     g.ntiles = g.tilesX * g.tilesY * d->n;
-    // two workgroups per CU; a multiple of 8 splits keeps the workgroups of one K range on one XCD (grid x is fastest)
+    // two (NS = 1: three) workgroups per CU; a multiple of 8 splits keeps the workgroups of one K range on one XCD (grid x
+    // is fastest)
     static const int wgs = []() { const char* e = getenv("REFID_W24_WGS"); return e ? atoi(e) : 512; }();
-    int want = cdiv(wgs, g.ncoT * g.nciT);
+    int want = cdiv(ns_of(d) == 1 ? wgs * 3 / 2 : wgs, g.ncoT * g.nciT);
     if (want >= 8) want = want / 8 * 8;
     if (want < 1) want = 1;
     if (want > g.ntiles) want = g.ntiles;
@@ -511,8 +521,9 @@ size_t refid_wgrad_wino24_workspace_bytes(const refid_wgrad_desc* d) {
 }
 
 int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0};
-    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino24_kernel, LDS24_BYTES, "wgrad_wino24")) return rc;
+    static std::atomic<unsigned long long> attr_done{0}, attr_done1{0};
+    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino24_kernel<2>, lds24_bytes(2), "wgrad_wino24")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done1, &wgrad_wino24_kernel<1>, lds24_bytes(1), "wgrad_wino24<1>")) return rc;
     const Geo24 g = geo24_of(d);
     REFID_CHECK(d->c_b == 0 || d->c_a % IT == 0, "wgrad (Winograd 2x4 tiles): c_a must be a multiple of %d for two sources", IT);
     REFID_CHECK(d->ld_g % 4 == 0 && d->ld_a % 4 == 0 && (d->c_b == 0 || d->ld_b % 4 == 0) && d->c_o % 4 == 0 &&
@@ -547,7 +558,10 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     a.CoP = g.CoP; a.CiP = g.CiP;
     a.accum = (d->phase == 2);
     if (d->phase != 3) {
-        hipLaunchKernelGGL(wgrad_wino24_kernel, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), LDS24_BYTES, st, a);
+        if (ns_of(d) == 1)
+            hipLaunchKernelGGL(wgrad_wino24_kernel<1>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds24_bytes(1), st, a);
+        else
+            hipLaunchKernelGGL(wgrad_wino24_kernel<2>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds24_bytes(2), st, a);
         REFID_LAUNCH_CHECK("wgrad_wino24");
     }
     if (d->phase == 1 || d->phase == 2) return 0;          // reduction deferred (phase 3)

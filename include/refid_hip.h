@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 6
+#define REFID_ABI_VERSION 7     /* 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);

@@ -72,7 +72,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 6          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 7          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 

@@ -2,6 +2,7 @@
 # Cross-compile everything tools/profile_round.sh runs on the GPU box (CPU container, before `gpurun`):
 #   tools/probes/bin/librefid_w6abl*.so   conv_wino6.hip with one piece removed   (tools/probes/wino6_ablate.py)
 #   tools/probes/bin/librefid_wwabl*.so   wgrad_wino.hip with one piece removed   (tools/probes/wgrad_wino_ablate.py)
+#   tools/probes/bin/librefid_w24abl*.so  wgrad_wino24.hip with one piece removed (tools/probes/w24_ablate.py)
 #   tools/probes/bin/{wino6_loop,mfma_lds_feed,mfma_valu_overlap}                 stand-alone hardware probes
 # The variant libraries link the CURRENT objects of the product build, so they must be rebuilt whenever csrc/ changes
 # (round 3's r03_wino6_ablation.txt was a Python traceback for exactly that reason); the ablation scripts refuse to run
@@ -11,6 +12,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
 python tools/probes/wino6_ablate.py --build
 python tools/probes/wgrad_wino_ablate.py --build          # (builds with REFID_EXPERIMENTAL_TILES=1: its algo 4 lives there)
+python -m refid_amd.build > /dev/null                      # product objects again: the 2x4 weight-gradient variants link them
+python tools/probes/w24_ablate.py --build
 python -m refid_amd.build > /dev/null                      # back to the product library
 mkdir -p tools/probes/bin
 for p in wino6_loop mfma_lds_feed mfma_valu_overlap; do

@@ -15,6 +15,7 @@ PY
 bash $R/tools/prof_step.sh ${tag}_bench_n1 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 bash $R/tools/prof_step.sh ${tag}_bench_n1_nooverlap --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
 bash $R/tools/prof_step.sh ${tag}_b1 --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
+for b in 1 2 4; do python $R/bench.py --batch $b --steps 8 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $R/gpurun_out/${tag}_b${b}_bench_untraced.json; done
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 bash $R/tools/prof_step.sh ${tag}_bf16_nooverlap --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null
 cd /tmp
 PASSES="FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES,SQ_BUSY_CU_CYCLES,GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE,SQ_INSTS_VALU,SQ_INSTS_LDS"
@@ -40,6 +41,8 @@ python tools/roofline_report.py --stats gpurun_out/${tag}_bench_n1_nooverlap_ker
   --out gpurun_out/${tag}_roofline_per_kernel.csv --summary gpurun_out/${tag}_pmc_summary.txt > gpurun_out/${tag}_roofline_report.txt 2>&1
 python tools/bench_wino6.py > gpurun_out/${tag}_wino6_tiles_bench.txt 2>&1
 python tools/probes/wino6_ablate.py > gpurun_out/${tag}_wino6_ablation.txt 2>&1
+python tools/probes/w24_ablate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_wgrad_w24_ablation.txt
+python tools/bench_wgrad_wino.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_wgrad_tiles_bench.txt
 tools/probes/bin/wino6_loop > gpurun_out/${tag}_wino6_loop_probe.txt 2>&1
 python tools/grad_error_report.py > gpurun_out/${tag}_grad_error_report.txt 2>&1
 for d in fp32 bf16x3 bf16; do python bench.py --dtype $d --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_$d.json; done
@@ -47,6 +50,8 @@ for d in fp32 bf16x3 bf16; do python bench.py --dtype $d --steps 5 --warmup 2 2>
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_single_stream_untraced.json
 python tools/busy_report.py --stats gpurun_out/${tag}_bench_n1_nooverlap_kernel_stats.csv --stat-steps 4 \
   --single gpurun_out/${tag}_bench_n1_single_stream_untraced.json --default gpurun_out/${tag}_bench_n1_fp32.json > gpurun_out/${tag}_gpu_busy.txt 2>&1
+# the driver's command line
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_driver_style.json
 # inference lines (BASELINE configs[3] / configs[4])
 python bench.py --mode infer --config 4 --steps 10 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${tag}_infer_config4.json
 python bench.py --mode infer --config 5 --steps 3 --warmup 1 2>/dev/null | tail -1 > gpurun_out/${tag}_infer_config5.json

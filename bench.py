@@ -658,7 +658,10 @@ def main(argv=None, claim_stdout=False):
                                    "transform-domain products (more than 32 output channels) and conv_down (4x4 stride 2) fwd/dgrad: "
                                    "every fp32 operand split EXACTLY into three bf16 numbers, six bf16 MFMAs per product, fp32 "
                                    "accumulation (same distance from float64 as the fp32 MFMA tiles: tests/test_hip_conv.py::"
-                                   "test_wino6_*, test_split_tile_conv_down_*; REFID_WINO6=0 / REFID_DOWN_SPLIT=0 turn them off)",
+                                   "test_wino6_*, test_split_tile_conv_down_*; REFID_WINO6=0 / REFID_DOWN_SPLIT=0 turn them off); 3x3 "
+                                   "weight gradients: fp32 MFMA in the Winograd domain over 2x4 tiles of the output gradient (F(3,2) x "
+                                   "F(3,4), transforms and accumulation fp32; 3e-6 .. 6e-6 of a tensor's scale from the float64 gradient, "
+                                   "test_wgrad_f4_accuracy_class; REFID_WGRAD_F4=0: 2x2 tiles)",
                            "bf16x3": "fp32 tensors and accumulation; 3x3 / 4x4 forward and input-gradient products as three bf16 MFMAs "
                                      "(2^-16 per product); weight gradients fp32",
                            "bf16": "bf16 MFMA operands (forward, input and weight gradients), fp32 tensors / accumulation / "

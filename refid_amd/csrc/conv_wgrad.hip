@@ -634,6 +634,7 @@ int thin_nsplit(const refid_wgrad_desc* d) {
 struct RedArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
+    int nsplitW;               // slabs behind `slabs` (nsplit, or the folded count); bslabs always has nsplit rows
 };
 
 // Slab reduction, deterministic.  `perGroup` = LPE (a power of two <= 8) adjacent lanes share ONE float4 element (4
@@ -661,11 +662,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
         for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (live) {
             int k = sub;
-            for (; k + 3 * lpe < a.nsplit; k += 4 * lpe) {
+            for (; k + 3 * lpe < a.nsplitW; k += 4 * lpe) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc[u] += p[(long long)(k + u * lpe) * slabStride4];
             }
-            for (; k < a.nsplit; k += lpe) acc[0] += p[(long long)k * slabStride4];
+            for (; k < a.nsplitW; k += lpe) acc[0] += p[(long long)k * slabStride4];
         }
         f32x4 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         for (int o = 1; o < lpe; o <<= 1) {
@@ -787,7 +788,8 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     if (!p.ok) return 0;
     const Geo g = geo_of(d, p);
-    return ((size_t)g.nsplit * p.ntaps * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP) * sizeof(float);
+    const size_t slab = (size_t)p.ntaps * g.CoP * g.CiP;
+    return ((size_t)g.nsplit * slab + (size_t)g.nsplit * g.CoP + (size_t)refid_slab_fold_count((long long)slab, g.nsplit) * slab) * sizeof(float);
 }
 
 extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
@@ -916,6 +918,17 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     // channel-padded operands (e.g. 26 -> 28 image channels, 3 -> 4 output channels): only the
     // real rows / columns of the parameter-layout gradient exist
     r.nsplit = g.nsplit; r.ntaps = p.ntaps; r.Co = d->o_real;
+    r.nsplitW = g.nsplit;
+    {   // streaming first stage: S partial slabs (wgrad_wino24.hip::refid_launch_slab_fold; the element-wise stage below read
+        // 100 MB of slabs at 0.09 of HBM)
+        const long long slab = (long long)p.ntaps * g.CoP * g.CiP;
+        if (const int S = refid_slab_fold_count(slab, g.nsplit)) {
+            float* part = d->slabs + (size_t)g.nsplit * slab + (size_t)g.nsplit * g.CoP;
+            if (int rc2 = refid_launch_slab_fold(a.slabs, part, slab, g.nsplit, S, st)) return rc2;
+            r.slabs = part;
+            r.nsplitW = S;
+        }
+    }
     r.Ci = (d->phase == 0 && a.Ctot < d->i_total - d->i_base) ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP;
     r.iBase = d->i_base; r.iTotal = d->i_total;
@@ -923,7 +936,7 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     const int nb = (int)((total4 + 255) / 256);
     // lanes per element: only where one thread per float4 would leave the chip idle (small weight tensors)
     int lpe = 1;
-    while (lpe < 8 && (long long)lpe * 2 * total4 <= 65536 && lpe * 2 <= g.nsplit) lpe *= 2;
+    while (lpe < 8 && (long long)lpe * 2 * total4 <= 65536 && lpe * 2 <= r.nsplitW) lpe *= 2;
     r.perGroup = lpe;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total4 * lpe + 255) / 256)), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_reduce");

@@ -32,6 +32,13 @@
 // i.e. on ONE XCD, so a tile is fetched from HBM once and re-read from that XCD's L2.
 // Split-K slabs [split][36][o][i] persist over the T recurrent steps exactly like wgrad_wino.hip's (phase 1 / 2 / 3); the
 // bias gradient is the transform point (1, 1) of G dY G^T (rows {1,1,1,1}: the tile sum), summed by wave 1 as it goes by.
+//
+// STATUS (round 5): correct (tests/test_hip_conv.py with REFID_EXPERIMENTAL_TILES=1) and NO FASTER than the 2x2-tile form it was
+// meant to replace -- 53-57 TF/s issued with scalar transforms, 57-61 packed (0.38 of the fp32 pipe; 2x2 tiles: 0.70 at 64/36 the
+// MFMAs), 48-52 in this file's final form (the explicit software pipeline below, which spills a few registers at 168).  With
+// nothing but its transforms and MFMAs (no DMA, no LDS reads, no barrier) it reaches 0.44: at ~7 vector instructions per MFMA
+// the transforms of a 6x6 window cost more than the MFMAs they save (profiles/r05_wgrad_f4x4_ablation.txt, r05_wgrad_f4x4_pmc.txt).
+// The product kernel is csrc/wgrad_wino24.hip (2x4 tiles: one F(3,2) direction keeps a 64x32 channel tile and a +-1 row pass).
 #include "../common.h"
 #include <cstdlib>
 #include <type_traits>

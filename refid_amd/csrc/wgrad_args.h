@@ -21,3 +21,7 @@ struct WgKArgs {
 // wgrad_bf16.hip: 3x3 / stride-1 partial products with bf16 MFMA operands; geometry = the fp32 W3 plan
 // (64 x 64 channel tile, 2 x 32 pixel tiles), grid (nsplit, nciT, ncoT)
 int refid_wgrad_bf16_launch(const WgKArgs& a, int nciT, int ncoT, hipStream_t st);
+
+// wgrad_wino24.hip: streaming first stage of a split-K slab reduction (S partial slabs out of nsplit; 0 = nothing to fold)
+int refid_slab_fold_count(long long slabFloats, int nsplit);
+int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats, int nsplit, int S, hipStream_t st);

@@ -424,65 +424,94 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
 struct W24rArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
+    int nsplitW;                           // slabs behind `slabs` (= nsplit, or the folded count); bslabs always has nsplit rows
 };
 
-// slab reduction + inverse transform dg = Ay^T dU Ax, accumulated into OIHW (9 contiguous floats).  Deterministic:
-// `perGroup` = LPE (power of two <= 16) adjacent lanes share one (co, ci) element, lane `sub` adds slabs sub, sub + LPE, ...
-// in order, a fixed xor-shuffle tree combines them, lane 0 owns the gradient element (no atomics).
+// First stage of the slab reduction.  Reading the slabs per (co, ci) element touches 64-256 contiguous bytes of each of 24 planes
+// of every slab per wave instruction -- 0.5-0.9 TB/s, 113-360 us per weight (100 MB each).  Here a workgroup owns 1024
+// consecutive floats of the slab image (4 KB contiguous per slab) and adds the slabs s, s + S, s + 2S, ... in order into partial
+// slab s: plain streaming at ~6 TB/s.  The second stage (below) then reads S <= 16 slabs instead of nsplit.  Deterministic:
+// fixed partition, fixed order.
+__global__ __launch_bounds__(256) void wgrad_wino24_fold_kernel(const float* __restrict__ slabs, float* __restrict__ part,
+                                                                long long slabFloats, int nsplit, int S) {
+    const long long off = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int s = blockIdx.y;
+    if (off >= slabFloats) return;
+    const f32x4* p = reinterpret_cast<const f32x4*>(slabs + off);
+    const long long st4 = slabFloats / 4;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    int k = s;
+    for (; k + S < nsplit; k += 2 * S) { a0 += p[k * st4]; a1 += p[(k + S) * st4]; }
+    if (k < nsplit) a0 += p[k * st4];
+    *reinterpret_cast<f32x4*>(part + (long long)s * slabFloats + off) = a0 + a1;
+}
+
+// slab reduction + inverse transform dg = Ay^T dU Ax, accumulated into OIHW (9 contiguous floats).  Deterministic (no atomics).
+// A workgroup owns EB = 256 / LPE consecutive (co, ci) elements (ci fastest); thread (sub = t / EB, e = t % EB) adds the slabs
+// sub, sub + LPE, ... of its element in order -- a 16-lane group reads 64 contiguous bytes of one slab plane (the first form of
+// this kernel put the LPE partial sums of ONE element on adjacent lanes: 16-byte pieces of 16 slabs per instruction, 0.19 of HBM)
+// -- the LPE partial sums meet in LDS and are added in index order by the element's first thread, which applies the transform.
 //   Ay^T = [ 1 1/2  1/2 0 ]      Ax^T = [ 1/4 -1/6 -1/6 1/24  1/24 0 ]
 //          [ 0 1/2 -1/2 0 ]             [ 0   -1/6  1/6 1/12 -1/12 0 ]
 //          [ 0 1/2  1/2 1 ]             [ 0   -1/6 -1/6 1/6   1/6  1 ]
 __global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs a) {
+    __shared__ float part[256 * (NXI + 1)];
     const long long plane = (long long)a.CoP * a.CiP;
     const long long slabStride = NXI * plane;
-    const int lpe = a.perGroup;
-    const long long gid = blockIdx.x * 256ll + threadIdx.x;
-    const long long e = gid / lpe;                                 // (co, ci), ci fastest
-    const int sub = (int)(gid % lpe);
+    const int lpe = a.perGroup, eb = 256 / lpe;
+    const int el = threadIdx.x % eb, sub = threadIdx.x / eb;
+    const long long e = (long long)blockIdx.x * eb + el;           // (co, ci), ci fastest
+    const bool live = e < (long long)a.Co * a.Ci;
+    const int ci = live ? (int)(e % a.Ci) : 0, co = live ? (int)(e / a.Ci) : 0;
     {
-        const bool live = e < (long long)a.Co * a.Ci;
-        const int ci = live ? (int)(e % a.Ci) : 0, co = live ? (int)(e / a.Ci) : 0;
         const float* p = a.slabs + (long long)co * a.CiP + ci;
         float u[NXI];
 #pragma unroll
         for (int x = 0; x < NXI; ++x) u[x] = 0.f;
         if (live) {
-            for (int k = sub; k < a.nsplit; k += lpe) {
+            for (int k = sub; k < a.nsplitW; k += lpe) {
 #pragma unroll
                 for (int x = 0; x < NXI; ++x) u[x] += p[k * slabStride + x * plane];
             }
         }
-        for (int o = 1; o < lpe; o <<= 1) {
+        if (lpe > 1) {
 #pragma unroll
-            for (int x = 0; x < NXI; ++x) u[x] += __shfl_xor(u[x], o, 64);
-        }
-        // t[p][j] = sum_i Ay^T[p][i] u[i][j] ;  dg[p][q] = sum_j t[p][j] Ax^T[q][j]
-        constexpr float c4 = 0.25f, c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
-        float dg[9];
+            for (int x = 0; x < NXI; ++x) part[threadIdx.x * (NXI + 1) + x] = u[x];
+            __syncthreads();
+            if (sub == 0) {
+                for (int s2 = 1; s2 < lpe; ++s2) {
 #pragma unroll
-        for (int pp = 0; pp < 3; ++pp) {
-            float t[6];
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float m = 0.5f * (u[6 + j] + u[12 + j]), d = 0.5f * (u[6 + j] - u[12 + j]);
-                t[j] = pp == 0 ? u[j] + m : (pp == 1 ? d : m + u[18 + j]);
+                    for (int x = 0; x < NXI; ++x) u[x] += part[(s2 * eb + el) * (NXI + 1) + x];
+                }
             }
-            const float s12 = t[1] + t[2], d21 = t[2] - t[1], s34 = t[3] + t[4], d34 = t[3] - t[4];
-            dg[pp * 3 + 0] = c4 * t[0] - c6 * s12 + c24 * s34;
-            dg[pp * 3 + 1] = c6 * d21 + c12 * d34;
-            dg[pp * 3 + 2] = c6 * (s34 - s12) + t[5];
         }
         if (live && sub == 0) {
+            // t[p][j] = sum_i Ay^T[p][i] u[i][j] ;  dg[p][q] = sum_j t[p][j] Ax^T[q][j]
+            constexpr float c4 = 0.25f, c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
+            float dg[9];
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp) {
+                float t[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float m = 0.5f * (u[6 + j] + u[12 + j]), d = 0.5f * (u[6 + j] - u[12 + j]);
+                    t[j] = pp == 0 ? u[j] + m : (pp == 1 ? d : m + u[18 + j]);
+                }
+                const float s12 = t[1] + t[2], d21 = t[2] - t[1], s34 = t[3] + t[4], d34 = t[3] - t[4];
+                dg[pp * 3 + 0] = c4 * t[0] - c6 * s12 + c24 * s34;
+                dg[pp * 3 + 1] = c6 * d21 + c12 * d34;
+                dg[pp * 3 + 2] = c6 * (s34 - s12) + t[5];
+            }
             float* dst = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * 9;
 #pragma unroll
             for (int k = 0; k < 9; ++k) dst[k] += dg[k];
         }
     }
     if (a.db != nullptr && blockIdx.x == 0) {
-        for (int co = threadIdx.x; co < a.Co; co += 256) {
+        for (int c2 = threadIdx.x; c2 < a.Co; c2 += 256) {
             float s = 0.f;
-            for (int k = 0; k < a.nsplit; ++k) s += a.bslabs[(long long)k * a.CoP + co];
-            a.db[co] += s;
+            for (int k = 0; k < a.nsplit; ++k) s += a.bslabs[(long long)k * a.CoP + c2];
+            a.db[c2] += s;
         }
     }
 }
@@ -515,9 +544,32 @@ Geo24 geo24_of(const refid_wgrad_desc* d) {
 
 }  // namespace
 
+// Generic first stage for every split-K slab family ([split][...]: slabFloats floats per split): S partial slabs -- as few as
+// keep the streaming stage at >= 2048 workgroups of 4 KB pieces (64 x 64 weights: 16 partial slabs out of 256; 512 x 256
+// weights: 1 out of 8); 0 = one slab only, nothing to fold.
+int refid_slab_fold_count(long long slabFloats, int nsplit) {
+    if (nsplit < 2) return 0;
+    const long long pieces = (slabFloats / 4 + 255) / 256;
+    int S = (int)((2048 + pieces - 1) / pieces);
+    if (S > 16) S = 16;
+    if (S >= nsplit) S = nsplit / 2;
+    return S < 1 ? 1 : S;
+}
+int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats, int nsplit, int S, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_wino24_fold_kernel, dim3((unsigned)((slabFloats / 4 + 255) / 256), S), dim3(256), 0, st, slabs, part,
+                       slabFloats, nsplit, S);
+    REFID_LAUNCH_CHECK("wgrad_slab_fold");
+    return 0;
+}
+
+namespace {
+int fold_count(const Geo24& g) { return refid_slab_fold_count((long long)NXI * g.CoP * g.CiP, g.nsplit); }
+}  // namespace
+
 size_t refid_wgrad_wino24_workspace_bytes(const refid_wgrad_desc* d) {
     const Geo24 g = geo24_of(d);
-    return ((size_t)g.nsplit * NXI * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP) * sizeof(float);
+    const size_t fold = (size_t)fold_count(g) * NXI * g.CoP * g.CiP;
+    return ((size_t)g.nsplit * NXI * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP + fold) * sizeof(float);
 }
 
 int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
@@ -568,13 +620,22 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     W24rArgs r;
     r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
     r.nsplit = g.nsplit; r.Co = d->o_real;
+    int nred = g.nsplit;                   // slabs the element-wise stage reads
+    if (const int S = fold_count(g)) {
+        const long long slabFloats = (long long)NXI * g.CoP * g.CiP;
+        float* part = d->slabs + (size_t)g.nsplit * NXI * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP;      // (behind the bias slabs)
+        if (int rc = refid_launch_slab_fold(a.slabs, part, slabFloats, g.nsplit, S, st)) return rc;
+        r.slabs = part;
+        nred = S;
+    }
     r.Ci = (d->phase == 0 && a.Ctot < d->i_total - d->i_base) ? a.Ctot : d->i_total - d->i_base;
     r.CoP = g.CoP; r.CiP = g.CiP; r.iBase = d->i_base; r.iTotal = d->i_total;
     const long long total = (long long)r.Co * r.Ci;
-    int lpe = 1;                           // lanes per element (small weight tensors only)
-    while (lpe < 16 && (long long)lpe * 2 * total <= 65536 && lpe * 2 <= g.nsplit) lpe *= 2;
+    int lpe = 1;                           // threads per element (small weight tensors only)
+    while (lpe < 16 && (long long)lpe * 2 * total <= 65536 && lpe * 2 <= nred) lpe *= 2;
     r.perGroup = lpe;
-    hipLaunchKernelGGL(wgrad_wino24_reduce_kernel, dim3((int)((total * lpe + 255) / 256)), dim3(256), 0, st, r);
+    r.nsplitW = nred;
+    hipLaunchKernelGGL(wgrad_wino24_reduce_kernel, dim3((int)((total + 256 / lpe - 1) / (256 / lpe))), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_wino24_reduce");
     return 0;
 }

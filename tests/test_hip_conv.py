@@ -583,6 +583,38 @@ def test_wgrad_f4_accuracy_class(cfg):
     assert err[5] < 2e-5 and err[5] < 10 * max(err[1], 1e-6), err
 
 
+def test_convop_sub_batched_input_gradient_keeps_the_gelu_mask(monkeypatch):
+    """engine.ConvOp.dgrad issues a batch whose tensors reach 2 GiB in sub-batches: the GELU' mask (conv5's input gradient,
+    fusion_modules.py:327-329 backward) must ride in every sub-call -- sub-batched == whole batch, bit for bit; and a conv whose
+    input-gradient tile cannot apply GELU' refuses the request instead of applying the leaky-step mask."""
+    from collections import OrderedDict
+    from refid_amd import engine
+    from refid_amd.engine import ConvOp, ParamArena
+    from refid_amd._lib import RefidHipError
+    co, ci, N, H, W = 128, 128, 4, 8, 16
+    A = ParamArena(OrderedDict([("c.weight", (co, ci, 1, 1)), ("c.bias", (co,)), ("d.weight", (64, 64, 3, 3)), ("d.bias", (64,))]),
+                   torch.device("cuda"))
+    A.p("c.weight").copy_(rnd(co, ci, 1, 1, seed=1, scale=0.1).float())
+    A.p("d.weight").copy_(rnd(64, 64, 3, 3, seed=2, scale=0.1).float())
+    op = ConvOp(A, "c")
+    op.repack()
+    g = nhwc(rnd(N, co, H, W, seed=3))
+    c4 = nhwc(rnd(N, ci, H, W, seed=4))
+    whole = op.dgrad(g, mask=c4, gelu_mask=True)
+    from refid_amd import ops
+    plain = op.dgrad(g)
+    want = ops.gelu_bwd(plain, c4)
+    assert float((whole - want).abs().max()) <= 1e-6 * float(want.abs().max())
+    monkeypatch.setattr(engine, "_LIM4", g[0].numel() * 2 - 1)              # two samples no longer fit "2 GiB"
+    monkeypatch.setattr(engine, "_batch_step", lambda n, *t: 1)
+    parts = op.dgrad(g, mask=c4, gelu_mask=True)
+    assert torch.equal(parts, whole)
+    op3 = ConvOp(A, "d")
+    op3.repack()
+    with pytest.raises(RefidHipError, match="gelu_mask"):
+        op3.dgrad(nhwc(rnd(1, 64, 8, 16, seed=5)), mask=nhwc(rnd(1, 64, 8, 16, seed=6)), gelu_mask=True)
+
+
 @pytest.mark.parametrize("ca,cb,group", [(48, 48, 1), (48, 48, 3), (40, 24, 1), (64, 64, 3)])
 def test_convop_two_source_weight_gradient_any_split(ca, cb, group):
     """engine.ConvOp: a two-source 3x3 conv whose first source is not a multiple of 32 channels (the Winograd

@@ -276,6 +276,19 @@ def test_schedulers_match_reference_sequences(golden_dir):
         train.scheduler_lr("CosineAnnealingLR", {}, 1, 2e-4, 2e-4)     # the reference rejects this spelling too
 
 
+def test_forward_wavefront_streams_only_for_small_batches(monkeypatch):
+    """engine.use_pipeline: the three forward-wavefront streams exist only while the batch leaves the chip room (the device has
+    four hardware queues: DESIGN.md section 5); REFID_PIPELINE=0 / 1 force it."""
+    from refid_amd import engine
+    monkeypatch.setattr(engine, "PIPELINE", "auto")
+    assert engine.use_pipeline(1, 256, 256) and engine.use_pipeline(4, 256, 256) and engine.use_pipeline(1, 512, 512)
+    assert not engine.use_pipeline(8, 256, 256) and not engine.use_pipeline(2, 512, 512)
+    monkeypatch.setattr(engine, "PIPELINE", False)
+    assert not engine.use_pipeline(1, 64, 64)
+    monkeypatch.setattr(engine, "PIPELINE", True)
+    assert engine.use_pipeline(8, 256, 256)
+
+
 def test_split_tile_grid_policy_follows_the_split_k_policy():
     """engine._fills_gpu: conv_down goes to the split tile only when its smallest grid gives each of the 256 CUs a
     workgroup -- by the real batch under the 'auto' split-K policy, as if 8 samples otherwise (batch invariance)."""

@@ -787,7 +787,8 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (thin_ok(d)) return (size_t)thin_nsplit(d) * 4 * (WT_MAXG * 1024 + 32) * sizeof(float);
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     if (!p.ok) return 0;
-    const Geo g = geo_of(d, p);
+    Geo g = geo_of(d, p);
+    if (refid_wgrad_pws_ok(d)) refid_wgrad_pws_geo(d, &g.ncoT, &g.nciT, &g.nsplit, &g.CoP, &g.CiP);
     const size_t slab = (size_t)p.ntaps * g.CoP * g.CiP;
     return ((size_t)g.nsplit * slab + (size_t)g.nsplit * g.CoP + (size_t)refid_slab_fold_count((long long)slab, g.nsplit) * slab) * sizeof(float);
 }
@@ -811,7 +812,8 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     REFID_CHECK(d->algo == 0 || ((d->algo >= 1 && d->algo <= 6) && d->kh == 3 && d->kw == 3 && d->stride == 1),
                 "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
     REFID_CHECK(d->groups <= REFID_WGRAD_MAX_GROUPS, "wgrad: at most %d grouped time steps", REFID_WGRAD_MAX_GROUPS);
-    REFID_CHECK(d->groups <= 1 || (d->phase != 3 && !thin_ok(d) && (d->algo != 0 || p.id != P_PW)),
+    const bool pws = refid_wgrad_pws_ok(d);               // streaming 1x1 form (wgrad_pws.hip): its own slab geometry
+    REFID_CHECK(d->groups <= 1 || (d->phase != 3 && !thin_ok(d) && (d->algo != 0 || p.id != P_PW || pws)),
                 "wgrad: grouped time steps are not implemented by the thin-input and 1x1 register tiles (and mean nothing in phase 3)");
     REFID_CHECK(d->algo != 2 || (p.id == P_W3 && d->pad == 1),
                 "wgrad: algo 2 (bf16 operands) needs more than 32 output and input channels and pad 1");
@@ -844,7 +846,8 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
         REFID_LAUNCH_CHECK("wgrad_thin_reduce");
         return 0;
     }
-    const Geo g = geo_of(d, p);
+    Geo g = geo_of(d, p);
+    if (pws) refid_wgrad_pws_geo(d, &g.ncoT, &g.nciT, &g.nsplit, &g.CoP, &g.CiP);
     WgKArgs a;
     const int ngrp = d->groups > 1 ? d->groups : 1;
     for (int k = 0; k < REFID_WGRAD_MAX_GROUPS; ++k) {
@@ -866,7 +869,9 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     a.accum = (d->phase == 2);
     REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
     int rc = (d->phase == 3) ? 0 : 1;
-    if (d->phase != 3 && p.id == P_PW) {
+    if (d->phase != 3 && pws) {
+        rc = refid_wgrad_pws_launch(d, a, g.nciT, g.ncoT, st);
+    } else if (d->phase != 3 && p.id == P_PW) {
         const long long npix = (long long)d->n * d->h * d->w;
         REFID_CHECK(d->c_b == 0 || d->c_a % 32 == 0, "wgrad: pointwise tile needs c_a %% 32 == 0 for two sources");
         REFID_CHECK(npix * d->ld_g * 4 < 0x7fffffffLL && npix * d->ld_a * 4 < 0x7fffffffLL &&

@@ -25,3 +25,8 @@ int refid_wgrad_bf16_launch(const WgKArgs& a, int nciT, int ncoT, hipStream_t st
 // wgrad_wino24.hip: streaming first stage of a split-K slab reduction (S partial slabs out of nsplit; 0 = nothing to fold)
 int refid_slab_fold_count(long long slabFloats, int nsplit);
 int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats, int nsplit, int S, hipStream_t st);
+
+// wgrad_pws.hip: streaming 1x1 weight gradient (LDS-DMA ring, fp32 MFMA); geometry of its slabs [split][CoP][CiP]
+bool refid_wgrad_pws_ok(const refid_wgrad_desc* d);
+void refid_wgrad_pws_geo(const refid_wgrad_desc* d, int* ncoT, int* nciT, int* nsplit, int* CoP, int* CiP);
+int refid_wgrad_pws_launch(const refid_wgrad_desc* d, const WgKArgs& a, int nciT, int ncoT, hipStream_t st);

@@ -242,6 +242,9 @@ WGRAD_WINO6 = os.environ.get("REFID_WGRAD_WINO6", "0") == "1"
 # fp32 MFMAs per 8 output pixels, packed transforms) wherever the 2x2-tile form (algo 1) was used and the output has at
 # least WGRAD_F4_MIN_HW rows and columns (below that a 4 x 16-pixel K tile is mostly zero padding and the 2x2 form's smaller
 # transform error is free).  REFID_WGRAD_F4=0 is the A/B switch back to algo 1.
+# 1x1 weight gradients on the streaming form (csrc/wgrad_pws.hip: LDS-DMA ring, every tensor read once at 128 x 128 channels),
+# and grouped over the time steps like the 3x3 ones (the older 1x1 tiles cannot group).  REFID_PWS_WGRAD=0: the older tiles.
+PWS_WGRAD = os.environ.get("REFID_PWS_WGRAD", "1") != "0"
 WGRAD_F4 = os.environ.get("REFID_WGRAD_F4", "1") != "0"
 WGRAD_F4_MIN_HW = int(os.environ.get("REFID_WGRAD_F4_MIN_HW", "16"))
 
@@ -663,7 +666,8 @@ class ConvOp:
             algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
-        if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down"):
+        pws = PWS_WGRAD and self.kind == "conv" and self.k == 1 and algo == 0 and self._pws_ok(a, b)
+        if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down" or pws):
             # same source split, algorithm and bias mode as the waiting calls (the first recurrent step has no second source yet)?
             if self.w_pend and ((self.w_pend[0][2] is None) != (b is None) or self.w_algo != algo or self.w_bias != bias):
                 self._launch_group()
@@ -678,6 +682,17 @@ class ConvOp:
                                       slabs=self.wslab)
         self.w_calls += 1
         self.w_last = (g, a, b, algo)
+
+    def _pws_ok(self, a, b):
+        """Mirror of refid_wgrad_pws_ok (csrc/wgrad_pws.hip): does this 1x1 weight gradient take the streaming form?  (Only it
+        can take several time steps per launch.)"""
+        ca, cb = a.shape[3], (b.shape[3] if b is not None else 0)
+        if self.co < 64 or self.co % 32 or ca % 32 or cb % 32 or self.ci % 32:
+            return False
+        wi = 4 if self.ci >= 128 else (2 if self.ci >= 64 else 1)
+        while cb and wi > 1 and ca % (32 * wi):
+            wi //= 2
+        return not (self.co >= 128 and wi == 1 and cb and ca % 64)
 
     def _slab_layout(self, algo):
         """The partial-sum slabs persist over the calls of one backward pass, and their layout belongs to the algorithm

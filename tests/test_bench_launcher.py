@@ -122,8 +122,10 @@ def test_inference_bench_modes():
 def test_stdout_is_one_json_line_even_with_rccl_up():
     """RCCL prints a banner on the C-level stdout when its first communicator comes up (flushed at exit, i.e. after the JSON line
     when stdout is a pipe): bench.py keeps file descriptor 1 for the JSON line alone."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()         # (a fixed port may sit in TIME_WAIT)
     r = _run(["--steps", "1", "--warmup", "1", "--batch", "1", "--T", "3", "--size", "64", "--no-cpu-baseline", "--no-roofline"],
-             {"REFID_FORCE_GRADSYNC": "1"})
+             {"REFID_FORCE_GRADSYNC": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-1000:]

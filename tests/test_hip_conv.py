@@ -267,6 +267,48 @@ def test_thin_output_wgrad_phases_and_groups(cfg):
         np.testing.assert_allclose(db.double().cpu().numpy(), b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co
+    (2, 16, 24, 64, 0, 64), (1, 9, 13, 128, 0, 64), (2, 8, 16, 64, 0, 128), (1, 16, 16, 128, 0, 128), (1, 7, 5, 64, 64, 64),
+    (1, 8, 8, 256, 256, 256), (1, 12, 20, 32, 0, 64), (3, 5, 7, 128, 128, 128), (1, 4, 4, 96, 0, 96)])
+def test_pointwise_streaming_wgrad(cfg):
+    """csrc/wgrad_pws.hip: the streaming 1x1 weight gradient (LDS-DMA ring, every (OW, WI) instantiation, two sources, ragged
+    pixel counts, the first recurrent step's missing second source) against torch; persistent phases and grouped time steps
+    give the one-shot gradients' sum."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    Ci = Ca + Cb
+    w = rnd(Co, Ci, 1, 1, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    steps = []
+    for t in range(3):
+        x = rnd(N, Ci, H, W, seed=10 + t)
+        g = rnd(N, Co, H, W, seed=20 + t)
+        F.conv2d(x, w, b).backward(g)
+        steps.append((nhwc(g), nhwc(x[:, :Ca]), nhwc(x[:, Ca:]) if Cb else None))
+    kw = dict(kh=1, kw=1, stride=1, pad=0, i_total=Ci)
+    scale = max(1.0, float(w.grad.abs().max()))
+    for grouping in ([[0], [1], [2]], [[0, 1, 2]], [[0], [1, 2]]):
+        dw = torch.zeros(Co, Ci, 1, 1, device="cuda"); db = torch.zeros(Co, device="cuda")
+        sl, first = None, True
+        for grp in grouping:
+            (g0, a0, b0), more = steps[grp[0]], [steps[i] for i in grp[1:]]
+            sl = ops.conv2d_wgrad(g0, a0, dw, in_b=b0, db=db, phase=1 if first else 2, slabs=sl, more=more, **kw)
+            first = False
+        ops.conv2d_wgrad(steps[0][0], steps[0][1], dw, in_b=steps[0][2], db=db, phase=3, slabs=sl, **kw)
+        np.testing.assert_allclose(dw.double().cpu().numpy(), w.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+        np.testing.assert_allclose(db.double().cpu().numpy(), b.grad.numpy(), rtol=RTOL, atol=ATOL * scale)
+    if Cb:      # first recurrent step: the second source does not exist yet, the slab geometry already covers it
+        dw1 = torch.zeros(Co, Ci, 1, 1, device="cuda")
+        s1 = ops.conv2d_wgrad(steps[0][0], steps[0][1], dw1, phase=1, **kw)
+        ops.conv2d_wgrad(steps[0][0], steps[0][1], dw1, phase=3, slabs=s1, **kw)
+        x0 = rnd(N, Ci, H, W, seed=10)
+        g0 = rnd(N, Co, H, W, seed=20)
+        ref = torch.einsum("nohw,nihw->oi", g0, x0[:, :Ca])
+        assert float((dw1[:, :Ca, 0, 0].double().cpu() - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        assert float(dw1[:, Ca:].abs().max()) == 0.0
+
+
 def test_conv_transpose_wgrad():
     ops = _ops()
     N, H, W, Ci, Co = 1, 8, 16, 128, 64

@@ -253,7 +253,8 @@ def test_forced_gradsync_bench_costs_under_one_percent():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
 
     def run(force):
-        e = dict(env, REFID_FORCE_GRADSYNC="1" if force else "0")
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()     # (a fixed port may sit in TIME_WAIT)
+        e = dict(env, REFID_FORCE_GRADSYNC="1" if force else "0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         r = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-roofline"],
                            capture_output=True, text=True, env=e, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]

@@ -39,7 +39,7 @@ def algo_key(k):
     if k.startswith("conv_split_kernel"): return "conv_split_kernel<6>"
     m = re.match(r"wgrad_kernel<WCfg<(\d+), (\d+), (\d+)", k)
     if m: return f"wgrad_kernel<{m.group(1)}x{m.group(2)}s{m.group(3)}>"
-    if k.startswith("wgrad_pw_kernel"): return "wgrad_kernel<1x1s1>"
+    if k.startswith("wgrad_pw_kernel") or k.startswith("wgrad_pws_kernel"): return "wgrad_kernel<1x1s1>"
     m = re.match(r"conv_igemm_kernel<(Cfg<[^>]*>)", k)
     if m: return f"conv_igemm_kernel<{m.group(1)}>"
     return None

@@ -248,7 +248,9 @@ def test_forced_gradsync_bench_costs_under_one_percent():
     """`REFID_FORCE_GRADSYNC=1 python bench.py --gpus 1`: the N > 1 path (RCCL all-reduce on its own stream, pinned-host
     prefetch on another, the compute streams) on one GPU: rccl_ranks = 1, and the step is within 1 % of the plain step --
     the side streams do not serialise the step."""
-    import json, subprocess, sys
+    import gc, json, subprocess, sys
+    gc.collect()
+    torch.cuda.empty_cache()        # the B=8 step needs ~150 GiB: whatever earlier tests left in this process's caching allocator must go
     bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
 

@@ -201,7 +201,9 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
     # pipe: price the kernel against the MFMA roof with the FLOPs it actually issues, and keep
     # the SURVEY 8(d) direct-convolution figure beside it.
     executed = fl * (16.0 / 36.0) if "wino" in name else fl
-    if "wino24" in name:
+    if "wino24_down" in name:
+        executed = fl * (12.0 / 16.0)                            # conv_down through its parity phases: 4 x 3 MFMA-units per pixel x 16 taps
+    elif "wino24" in name:
         executed = fl * (12.0 / 36.0)                            # Winograd over 2x4 tiles: 24 MFMA-units per 8 pixels x 9 taps
     peak = FP32_MFMA_PEAK_TFLOPS
     ach = executed / sec / 1e12

@@ -219,6 +219,10 @@ typedef struct refid_wgrad_desc {
                                                    transforms (wgrad_wino24.hip; slabs [split][24][o][i]; pitches / channel
                                                    counts multiples of 4 floats, 16-byte aligned tensors, c_a % 32 == 0 for two
                                                    sources); deviation from the float64 gradient 3e-6 .. 6e-6 of scale;
+                                                   7 = conv_down (4x4 stride 2 pad 1, even input size): algo 5's kernel on the four
+                                                   parity phases of the input (a stride-2 conv is four 2x2-tap stride-1 convs on
+                                                   them): 12 instead of 16 fp32 MFMA-units per output pixel; slabs
+                                                   [split][phase][24][o][i];
                                                    6 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured no faster
                                                    than algo 1): Winograd F(3x3,4x4), 36 MFMAs per 16 pixels, six-wave
                                                    workgroups (experimental/wgrad_wino4.hip)                          */

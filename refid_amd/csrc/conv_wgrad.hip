@@ -781,6 +781,7 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
     if (d->algo == 5) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
+    if (d->algo == 7) return (d->kh == 4 && d->kw == 4 && d->stride == 2) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
 #ifdef REFID_EXPERIMENTAL_TILES
     if (d->algo == 6) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino4_workspace_bytes(d) : 0;
 #endif
@@ -809,8 +810,9 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
                 d->wo, eh, ew);
     REFID_CHECK(d->i_total > d->i_base && d->i_base >= 0 && d->o_real > 0 && d->o_real <= d->c_o,
                 "wgrad: i_base/i_total/o_real inconsistent");
-    REFID_CHECK(d->algo == 0 || ((d->algo >= 1 && d->algo <= 6) && d->kh == 3 && d->kw == 3 && d->stride == 1),
-                "wgrad: algo %d needs a 3x3 stride-1 conv", d->algo);
+    REFID_CHECK(d->algo == 0 || ((d->algo >= 1 && d->algo <= 6) && d->kh == 3 && d->kw == 3 && d->stride == 1) ||
+                    (d->algo == 7 && d->kh == 4 && d->kw == 4 && d->stride == 2 && d->pad == 1),
+                "wgrad: algo %d needs a 3x3 stride-1 conv (algo 7: a 4x4 stride-2 pad-1 conv)", d->algo);
     REFID_CHECK(d->groups <= REFID_WGRAD_MAX_GROUPS, "wgrad: at most %d grouped time steps", REFID_WGRAD_MAX_GROUPS);
     const bool pws = refid_wgrad_pws_ok(d);               // streaming 1x1 form (wgrad_pws.hip): its own slab geometry
     REFID_CHECK(d->groups <= 1 || (d->phase != 3 && !thin_ok(d) && (d->algo != 0 || p.id != P_PW || pws)),
@@ -818,7 +820,7 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     REFID_CHECK(d->algo != 2 || (p.id == P_W3 && d->pad == 1),
                 "wgrad: algo 2 (bf16 operands) needs more than 32 output and input channels and pad 1");
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return refid_wgrad_wino_launch(d, st);
-    if (d->algo == 5) return refid_wgrad_wino24_launch(d, st);
+    if (d->algo == 5 || d->algo == 7) return refid_wgrad_wino24_launch(d, st);
 #ifdef REFID_EXPERIMENTAL_TILES
     if (d->algo == 6) return refid_wgrad_wino4_launch(d, st);
 #else

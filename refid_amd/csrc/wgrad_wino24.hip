@@ -91,6 +91,8 @@ struct W24Args {
     int tilesX, tilesY, ntiles, nsplit;
     int CoP, CiP;
     int accum;
+    // DOWN form (conv_down, 4x4 stride 2 pad 1): H, W above are the PHASE image's size (= Ho, Wo), pad = 1
+    int Hin, Win, ncoT;
 };
 
 // The transforms of one wave (F(3,2) row I), PACKED over two consecutive tile columns (steps s, s+1): a ds_read2st64 of
@@ -157,21 +159,30 @@ struct W24Row {
     }
 };
 
-template <int NS>
+// DOWN = true: the weight gradient of conv_down (4x4, stride 2, pad 1; recurrent_sub_modules.py:12-14).  A stride-2 conv is four
+// stride-1 convs with 2x2 taps on the input's PARITY PHASES  P_pq[Y][X] = in[2Y + p][2X + q]:  tap ky reads phase p = (ky - 1) & 1
+// at row offset (ky - 1 - p) / 2, i.e. offsets {0, +1} for p = 0 and {-1, 0} for p = 1.  So per phase the wanted 2x2 taps are a
+// sub-block of the 3x3 correlation this kernel computes on (P_pq, dY) with pad 1 -- ky = 2u + p - 1 for u = 0..2 where that
+// lies in 0..3 --: 4 phases x 3 = 12 fp32 MFMA-units per output pixel instead of the direct form's 16.  The only differences:
+// the phase (grid z) selects the slab block, and the DMA gathers every other pixel of every other row (per-lane offsets, so it
+// costs nothing); the reduction scatters the 2x2 sub-blocks into the 4x4 gradient.
+template <int NS, bool DOWN>
 __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(const W24Args a) {
-    constexpr int OT = 32 * NS, BUF_BYTES = buf_bytes(NS);
+    constexpr int OT = 32 * NS, BUF_BYTES = buf_bytes(NS), XPS = DOWN ? 2 : 1;     // XPS: input pixels per phase pixel
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kh = lane >> 5;
-    const int co0 = blockIdx.z * OT, ci0 = blockIdx.y * IT;
+    const int phase = DOWN ? blockIdx.z / a.ncoT : 0, php = phase >> 1, phq = phase & 1;
+    const int co0 = (DOWN ? blockIdx.z % a.ncoT : blockIdx.z) * OT, ci0 = blockIdx.y * IT;
     const int split = blockIdx.x;
+    const int Hin = DOWN ? a.Hin : a.H, Win = DOWN ? a.Win : a.W;
 
     // the input-channel tile lies in one source (host: c_a % 32 == 0 for two sources), so the descriptor is workgroup-uniform;
     // a tile beyond the sources (first recurrent step: no second source yet) keeps a valid descriptor, all lanes out of range
     const bool xFromA = ci0 < a.Ca || ci0 >= a.Ctot;
     const int xld = xFromA ? a.ldA : a.ldB;
-    const long long gpixAll = (long long)a.N * a.Ho * a.Wo, xpixAll = (long long)a.N * a.H * a.W;
+    const long long gpixAll = (long long)a.N * a.Ho * a.Wo, xpixAll = (long long)a.N * Hin * Win;
     const int limG = (int)min(gpixAll * a.ldG * 4, 0x7fffffffLL), limX = (int)min(xpixAll * xld * 4, 0x7fffffffLL);
     const int ntAll = a.ntiles * a.groups;
     const int chunk = (ntAll + a.nsplit - 1) / a.nsplit;
@@ -192,18 +203,21 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
     // an out-of-image ROW is a scalar select of an out-of-range base: one v_add per DMA instruction.  Otherwise out-of-range
     // columns / channels are forced out of range with OR masks.
     const int xq = ci0 + (lane & 7) * 4, xt = ci0 + (lane & 31), gq = co0 + (lane & 7) * 4;
-    const int xlc = ((lane >> 3) * xld + (xFromA ? xq : xq - a.Ca)) * 4;            // bytes from the piece's first pixel
-    const int xlt = ((lane >> 5) * xld + (xFromA ? xt : xt - a.Ca)) * 4;
+    const int xlc = ((lane >> 3) * XPS * xld + (xFromA ? xq : xq - a.Ca)) * 4;      // bytes from the piece's first pixel
+    const int xlt = ((lane >> 5) * XPS * xld + (xFromA ? xt : xt - a.Ca)) * 4;
     const int glc = ((lane >> 3) * a.ldG + gq) * 4;
     const bool fullch = ci0 + IT <= a.Ctot && co0 + OT <= a.Co;                     // workgroup-uniform
     constexpr int OOB = 0x7ff00000;                        // base of a dead row: + any lane constant (< 1 MB) stays out of range
     // Scalar state of the walk: the current time step's tensors (reloaded from the argument block only when the walk crosses
     // into the next step -- an s_load per request would put a full scalar-memory latency in front of every tile), the byte
     // offset of the next tile's first halo / gradient pixel (advanced by one tile width; recomputed at the end of a tile row)
-    const int xRowB = a.W * xld * 4, gRowB = a.Wo * a.ldG * 4;      // bytes per image row
+    const int xRowB = XPS * Win * xld * 4, gRowB = a.Wo * a.ldG * 4;      // bytes per (phase) image row
+    auto x_origin = [&](int n, int ty, int tx) {           // byte offset of phase pixel (ty GH - pad, tx GW - pad) of sample n
+        return ((n * Hin + XPS * (ty * GH - a.pad) + php) * Win + XPS * (tx * GW - a.pad) + phq) * xld * 4;
+    };
     const float* gPtr = a.g[qg];
     const float* xPtr = xFromA ? a.inA[qg] : a.inB[qg];
-    int xTile = ((qn * a.H + qy * GH - a.pad) * a.W + qx * GW - a.pad) * xld * 4;
+    int xTile = x_origin(qn, qy, qx);
     int gTile = ((qn * a.Ho + qy * GH) * a.Wo + qx * GW) * a.ldG * 4;
     auto request = [&](int buf) {
         const int oy0 = qy * GH, ox0 = qx * GW;
@@ -212,7 +226,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xPtr), 0, limX, 0x00020000);
         char* xdst = smem + buf * BUF_BYTES;
         char* gdst = xdst + X_BYTES;
-        const bool fast = fullch && ix0 >= 0 && ix0 + XW <= a.W && ox0 + GW <= a.Wo && xld * 8 * 4 < 0x100000 && a.ldG * 8 * 4 < 0x100000;
+        const bool fast = fullch && ix0 >= 0 && ix0 + XW <= a.W && ox0 + GW <= a.Wo && xld * 8 * XPS * 4 < 0x100000 && a.ldG * 8 * 4 < 0x100000;
         // gradient (half, row) pairs q = 4 half + row of this wave: NS = 2: wave 0 q = 0, wave 1 q = 1, wave 2 q = 2..4, wave 3
         // q = 5..7 (with the halo rows: 8 / 8 / 9 / 9 DMA instructions); NS = 1: waves 2 / 3 two rows each (6 / 6 / 7 / 7)
         const int q0 = NS == 2 ? (wave < 2 ? wave : 3 * wave - 4) : 2 * (wave - 2), nq = NS == 2 ? (wave < 2 ? 1 : 3) : (wave < 2 ? 0 : 2);
@@ -224,8 +238,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
                     const int base = (unsigned)(iy0 + r) < (unsigned)a.H ? xTile + r * xRowB : OOB;
                     char* dst = xdst + r * (XW * IT * 4);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)dst, 16, base + xlc, 0, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)(dst + 1024), 16, base + 8 * xld * 4 + xlc, 0, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)(dst + 2048), 4, base + 16 * xld * 4 + xlt, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)(dst + 1024), 16, base + 8 * XPS * xld * 4 + xlc, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)(dst + 2048), 4, base + 16 * XPS * xld * 4 + xlt, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -256,9 +270,9 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
                     char* dst = xdst + r * (XW * IT * 4);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)dst, 16, (base + xlc) | xbadq | rbad | cx0, 0, 0, 0);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)(dst + 1024), 16,
-                                                             (base + 8 * xld * 4 + xlc) | xbadq | rbad | cx1, 0, 0, 0);
+                                                             (base + 8 * XPS * xld * 4 + xlc) | xbadq | rbad | cx1, 0, 0, 0);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr24)(dst + 2048), 4,
-                                                             (base + 16 * xld * 4 + xlt) | xbadt | rbad | cxt, 0, 0, 0);
+                                                             (base + 16 * XPS * xld * 4 + xlt) | xbadt | rbad | cxt, 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
         // advance
         qx += 1;
         if (qx != a.tilesX) {
-            xTile += GW * xld * 4;
+            xTile += GW * XPS * xld * 4;
             gTile += GW * a.ldG * 4;
         } else {
             qx = 0;
@@ -293,7 +307,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
                     xPtr = xFromA ? a.inA[qg] : a.inB[qg];
                 }
             }
-            xTile = ((qn * a.H + qy * GH - a.pad) * a.W - a.pad) * xld * 4;
+            xTile = x_origin(qn, qy, 0);
             gTile = (qn * a.Ho + qy * GH) * a.Wo * a.ldG * 4;
         }
     };
@@ -392,7 +406,8 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
     // ---- slab: [split][xi][co][ci]; D[ci][co]: lane li = output channel, register quad = 4 ci ------
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-        float* sl = a.slabs + ((long long)(split * NXI + wave * 6 + j) * a.CoP) * a.CiP;
+        // slab image of one split: [phase (DOWN: 4)][xi][co][ci]
+        float* sl = a.slabs + ((long long)((split * (DOWN ? 4 : 1) + phase) * NXI + wave * 6 + j) * a.CoP) * a.CiP;
 #pragma unroll
         for (int sm = 0; sm < NS; ++sm) {
             const int co = co0 + sm * 32 + li;
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
             }
         }
     }
-    if (a.bslabs != nullptr && blockIdx.y == 0 && wave == 1) {
+    if (a.bslabs != nullptr && blockIdx.y == 0 && phase == 0 && wave == 1) {
         // wave 1 holds the tile sums of the output channels: the two tile rows (kh) by one shuffle -- fixed order
 #pragma unroll
         for (int sm = 0; sm < NS; ++sm) {
@@ -516,9 +531,60 @@ __global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs
     }
 }
 
+// DOWN form: per (co, ci) the four phases' 24 planes -> four 3x3 blocks -> the 2x2 sub-block of each that exists in the 4x4
+// gradient (ky = 2u + p - 1, kx = 2v + q - 1), accumulated into OIHW (16 contiguous floats).  Reads the (folded) slab image
+// [split][phase][xi][co][ci]; one thread per element, slabs in order (deterministic).
+__global__ __launch_bounds__(256) void wgrad_wino24_reduce_down_kernel(const W24rArgs a) {
+    const long long plane = (long long)a.CoP * a.CiP;
+    const long long slabStride = 4 * NXI * plane;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long e = gid >> 2;                              // (co, ci), ci fastest; four threads = the four phases: every tap
+    const int ph = (int)(gid & 3);                             // of the 4x4 gradient belongs to exactly one of them
+    const bool live = e < (long long)a.Co * a.Ci;
+    const int ci = live ? (int)(e % a.Ci) : 0, co = live ? (int)(e / a.Ci) : 0;
+    if (live) {
+        const float* p = a.slabs + (long long)co * a.CiP + ci + ph * NXI * plane;
+        float u[NXI];
+#pragma unroll
+        for (int x = 0; x < NXI; ++x) u[x] = 0.f;
+        for (int k = 0; k < a.nsplitW; ++k) {
+#pragma unroll
+            for (int x = 0; x < NXI; ++x) u[x] += p[k * slabStride + x * plane];
+        }
+        constexpr float c4 = 0.25f, c6 = 1.f / 6.f, c12 = 1.f / 12.f, c24 = 1.f / 24.f;
+        float* dst = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * 16;
+#pragma unroll
+        for (int pp = 0; pp < 3; ++pp) {
+            const int ky = 2 * pp + (ph >> 1) - 1;
+            float t[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float m = 0.5f * (u[6 + j] + u[12 + j]), d = 0.5f * (u[6 + j] - u[12 + j]);
+                t[j] = pp == 0 ? u[j] + m : (pp == 1 ? d : m + u[18 + j]);
+            }
+            const float s12 = t[1] + t[2], d21 = t[2] - t[1], s34 = t[3] + t[4], d34 = t[3] - t[4];
+            const float r3[3] = {c4 * t[0] - c6 * s12 + c24 * s34, c6 * d21 + c12 * d34, c6 * (s34 - s12) + t[5]};
+            if (ky < 0 || ky > 3) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int kx = 2 * q + (ph & 1) - 1;
+                if (kx >= 0 && kx <= 3) dst[ky * 4 + kx] += r3[q];
+            }
+        }
+    }
+    if (a.db != nullptr && blockIdx.x == 0) {
+        for (int c2 = threadIdx.x; c2 < a.Co; c2 += 256) {
+            float sacc = 0.f;
+            for (int k = 0; k < a.nsplit; ++k) sacc += a.bslabs[(long long)k * a.CoP + c2];
+            a.db[c2] += sacc;
+        }
+    }
+}
+
 struct Geo24 { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
 
 int ns_of(const refid_wgrad_desc* d) { return d->c_o <= 32 ? 1 : 2; }      // 32-channel output tile for the thin layers
+bool is_down(const refid_wgrad_desc* d) { return d->kh == 4; }              // algo 7: conv_down through its parity phases
 
 Geo24 geo24_of(const refid_wgrad_desc* d) {
     Geo24 g;
@@ -532,7 +598,7 @@ Geo24 geo24_of(const refid_wgrad_desc* d) {
     // two (NS = 1: three) workgroups per CU; a multiple of 8 splits keeps the workgroups of one K range on one XCD (grid x
     // is fastest)
     static const int wgs = []() { const char* e = getenv("REFID_W24_WGS"); return e ? atoi(e) : 512; }();
-    int want = cdiv(ns_of(d) == 1 ? wgs * 3 / 2 : wgs, g.ncoT * g.nciT);
+    int want = cdiv(ns_of(d) == 1 ? wgs * 3 / 2 : wgs, g.ncoT * g.nciT * (is_down(d) ? 4 : 1));
     if (want >= 8) want = want / 8 * 8;
     if (want < 1) want = 1;
     if (want > g.ntiles) want = g.ntiles;
@@ -563,20 +629,27 @@ int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats
 }
 
 namespace {
-int fold_count(const Geo24& g) { return refid_slab_fold_count((long long)NXI * g.CoP * g.CiP, g.nsplit); }
+long long slab_floats(const refid_wgrad_desc* d, const Geo24& g) { return (long long)(is_down(d) ? 4 : 1) * NXI * g.CoP * g.CiP; }
 }  // namespace
 
 size_t refid_wgrad_wino24_workspace_bytes(const refid_wgrad_desc* d) {
     const Geo24 g = geo24_of(d);
-    const size_t fold = (size_t)fold_count(g) * NXI * g.CoP * g.CiP;
-    return ((size_t)g.nsplit * NXI * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP + fold) * sizeof(float);
+    const long long slab = slab_floats(d, g);
+    return ((size_t)g.nsplit * slab + (size_t)g.nsplit * g.CoP + (size_t)refid_slab_fold_count(slab, g.nsplit) * slab) * sizeof(float);
 }
 
 int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
-    static std::atomic<unsigned long long> attr_done{0}, attr_done1{0};
-    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino24_kernel<2>, lds24_bytes(2), "wgrad_wino24")) return rc;
-    if (int rc = refid_lds_attr_once(attr_done1, &wgrad_wino24_kernel<1>, lds24_bytes(1), "wgrad_wino24<1>")) return rc;
+    static std::atomic<unsigned long long> attr_done{0}, attr_done1{0}, attr_done2{0}, attr_done3{0};
+    if (int rc = refid_lds_attr_once(attr_done, &wgrad_wino24_kernel<2, false>, lds24_bytes(2), "wgrad_wino24")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done1, &wgrad_wino24_kernel<1, false>, lds24_bytes(1), "wgrad_wino24<1>")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done2, &wgrad_wino24_kernel<2, true>, lds24_bytes(2), "wgrad_wino24<down>")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done3, &wgrad_wino24_kernel<1, true>, lds24_bytes(1), "wgrad_wino24<1, down>")) return rc;
     const Geo24 g = geo24_of(d);
+    const bool down = is_down(d);
+    const long long slab = slab_floats(d, g);
+    if (down)
+        REFID_CHECK(d->kw == 4 && d->stride == 2 && d->pad == 1 && d->h % 2 == 0 && d->w % 2 == 0 && d->ho == d->h / 2 && d->wo == d->w / 2,
+                    "wgrad (algo 7): a 4x4 stride-2 pad-1 conv over an even-sized input");
     REFID_CHECK(d->c_b == 0 || d->c_a % IT == 0, "wgrad (Winograd 2x4 tiles): c_a must be a multiple of %d for two sources", IT);
     REFID_CHECK(d->ld_g % 4 == 0 && d->ld_a % 4 == 0 && (d->c_b == 0 || d->ld_b % 4 == 0) && d->c_o % 4 == 0 &&
                     d->c_a % 4 == 0 && d->c_b % 4 == 0,
@@ -604,16 +677,23 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     a.ldA = d->ld_a; a.ldB = d->ld_b;
     a.Ca = d->c_a; a.Ctot = d->c_a + d->c_b;
     a.slabs = d->slabs;
-    a.bslabs = d->db ? d->slabs + (size_t)g.nsplit * NXI * g.CoP * g.CiP : nullptr;
+    a.bslabs = d->db ? d->slabs + (size_t)g.nsplit * slab : nullptr;
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo; a.pad = d->pad;
+    a.Hin = d->h; a.Win = d->w; a.ncoT = g.ncoT;
+    if (down) { a.H = d->ho; a.W = d->wo; a.pad = 1; }      // the phase image
     a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
     a.CoP = g.CoP; a.CiP = g.CiP;
     a.accum = (d->phase == 2);
     if (d->phase != 3) {
-        if (ns_of(d) == 1)
-            hipLaunchKernelGGL(wgrad_wino24_kernel<1>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds24_bytes(1), st, a);
+        if (down) {
+            if (ns_of(d) == 1)
+                hipLaunchKernelGGL((wgrad_wino24_kernel<1, true>), dim3(g.nsplit, g.nciT, 4 * g.ncoT), dim3(256), lds24_bytes(1), st, a);
+            else
+                hipLaunchKernelGGL((wgrad_wino24_kernel<2, true>), dim3(g.nsplit, g.nciT, 4 * g.ncoT), dim3(256), lds24_bytes(2), st, a);
+        } else if (ns_of(d) == 1)
+            hipLaunchKernelGGL((wgrad_wino24_kernel<1, false>), dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds24_bytes(1), st, a);
         else
-            hipLaunchKernelGGL(wgrad_wino24_kernel<2>, dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds24_bytes(2), st, a);
+            hipLaunchKernelGGL((wgrad_wino24_kernel<2, false>), dim3(g.nsplit, g.nciT, g.ncoT), dim3(256), lds24_bytes(2), st, a);
         REFID_LAUNCH_CHECK("wgrad_wino24");
     }
     if (d->phase == 1 || d->phase == 2) return 0;          // reduction deferred (phase 3)
@@ -621,9 +701,9 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     r.slabs = a.slabs; r.bslabs = a.bslabs; r.dw = d->dw; r.db = d->db;
     r.nsplit = g.nsplit; r.Co = d->o_real;
     int nred = g.nsplit;                   // slabs the element-wise stage reads
-    if (const int S = fold_count(g)) {
-        const long long slabFloats = (long long)NXI * g.CoP * g.CiP;
-        float* part = d->slabs + (size_t)g.nsplit * NXI * g.CoP * g.CiP + (size_t)g.nsplit * g.CoP;      // (behind the bias slabs)
+    if (const int S = refid_slab_fold_count(slab, g.nsplit)) {
+        const long long slabFloats = slab;
+        float* part = d->slabs + (size_t)g.nsplit * slab + (size_t)g.nsplit * g.CoP;      // (behind the bias slabs)
         if (int rc = refid_launch_slab_fold(a.slabs, part, slabFloats, g.nsplit, S, st)) return rc;
         r.slabs = part;
         nred = S;
@@ -635,6 +715,11 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     while (lpe < 16 && (long long)lpe * 2 * total <= 65536 && lpe * 2 <= nred) lpe *= 2;
     r.perGroup = lpe;
     r.nsplitW = nred;
+    if (down) {
+        hipLaunchKernelGGL(wgrad_wino24_reduce_down_kernel, dim3((int)((total * 4 + 255) / 256)), dim3(256), 0, st, r);
+        REFID_LAUNCH_CHECK("wgrad_wino24_reduce_down");
+        return 0;
+    }
     hipLaunchKernelGGL(wgrad_wino24_reduce_kernel, dim3((int)((total + 256 / lpe - 1) / (256 / lpe))), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_wino24_reduce");
     return 0;

@@ -247,6 +247,9 @@ WGRAD_WINO6 = os.environ.get("REFID_WGRAD_WINO6", "0") == "1"
 PWS_WGRAD = os.environ.get("REFID_PWS_WGRAD", "1") != "0"
 WGRAD_F4 = os.environ.get("REFID_WGRAD_F4", "1") != "0"
 WGRAD_F4_MIN_HW = int(os.environ.get("REFID_WGRAD_F4_MIN_HW", "16"))
+# conv_down's weight gradient (4x4 stride 2) on the same kernel through the input's four parity phases (algo 7: 12 instead of
+# 16 fp32 MFMA-units per output pixel).  REFID_WGRAD_DOWN_F4=0: the direct tile.
+WGRAD_DOWN_F4 = os.environ.get("REFID_WGRAD_DOWN_F4", "1") != "0"
 
 
 def flush_wgrads(device):
@@ -662,6 +665,10 @@ class ConvOp:
         if algo == 1 and WGRAD_F4 and min(g.shape[1], g.shape[2]) >= WGRAD_F4_MIN_HW and g.shape[3] % 4 == 0 and \
                 a.shape[3] % 4 == 0 and (b is None or b.shape[3] % 4 == 0):
             algo = 5          # Winograd over 2x4 tiles: 0.75x the fp32 MFMAs of algo 1, packed transforms
+        if self.kind == "down" and WGRAD_DOWN_F4 and USE_WINOGRAD and self.co >= 32 and self.ci >= 32 and a.shape[3] % 32 == 0 and \
+                (b is None or b.shape[3] % 32 == 0) and a.shape[1] % 2 == 0 and a.shape[2] % 2 == 0 and \
+                min(g.shape[1], g.shape[2]) >= WGRAD_F4_MIN_HW and g.shape[3] % 4 == 0:
+            algo = 7          # the 2x4-tile Winograd kernel on the four parity phases of the input
         if algo == 1 and WGRAD_WINO6 and not self.bf16:
             algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:

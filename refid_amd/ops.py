@@ -338,7 +338,7 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     ngrp = max(1, d.groups)
     flops = 2.0 * ngrp * d.n * d.ho * d.wo * d.o_real * min(d.c_a + d.c_b, d.i_total) * kh * kw
     nbytes = 4.0 * ngrp * (d.n * d.h * d.w * (d.c_a + d.c_b) + d.n * d.ho * d.wo * d.c_o)
-    PROFILE.append((("wgrad_wino_kernel" if algo == 1 else "wgrad_wino24_kernel" if algo == 5 else "wgrad_wino4_kernel" if algo == 6 else "wgrad_wino6_kernel" if algo == 3 else "wgrad_wino_dma_kernel" if algo == 4 else ("wgrad_bf16_kernel" if algo == 2 else
+    PROFILE.append((("wgrad_wino_kernel" if algo == 1 else "wgrad_wino24_kernel" if algo == 5 else "wgrad_wino24_down_kernel" if algo == 7 else "wgrad_wino4_kernel" if algo == 6 else "wgrad_wino6_kernel" if algo == 3 else "wgrad_wino_dma_kernel" if algo == 4 else ("wgrad_bf16_kernel" if algo == 2 else
                                                            f"wgrad_kernel<{kh}x{kw}s{stride}>")), flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None)), nbytes))
     return slabs

@@ -309,6 +309,44 @@ def test_pointwise_streaming_wgrad(cfg):
         assert float(dw1[:, Ca:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Ca, Cb, Co
+    (2, 32, 64, 64, 0, 64), (1, 40, 24, 32, 0, 64), (1, 16, 32, 64, 64, 128), (2, 12, 20, 32, 0, 32), (1, 64, 64, 128, 0, 128)])
+def test_conv_down_wgrad_through_parity_phases(cfg):
+    """refid_wgrad_desc.algo 7: the weight gradient of conv_down (4x4, stride 2, pad 1: recurrent_sub_modules.py:12-14) on the
+    2x4-tile Winograd kernel through the four parity phases of the input, against torch; persistent phases and grouped time
+    steps give the one-shot gradients' sum; and its distance from the float64 gradient stays in the fp32 class."""
+    ops = _ops()
+    N, H, W, Ca, Cb, Co = cfg
+    Ci = Ca + Cb
+    w = rnd(Co, Ci, 4, 4, seed=2).requires_grad_(True)
+    b = rnd(Co, seed=3).requires_grad_(True)
+    steps = []
+    for t in range(3):
+        x = rnd(N, Ci, H, W, seed=10 + t)
+        x = torch.where(x > -0.3, x, 0.1 * x) + 0.2
+        g = rnd(N, Co, H // 2, W // 2, seed=20 + t, scale=1e-2)
+        F.conv2d(x, w, b, 2, 1).backward(g)
+        steps.append((nhwc(g), nhwc(x[:, :Ca]), nhwc(x[:, Ca:]) if Cb else None))
+    kw = dict(kh=4, kw=4, stride=2, pad=1, i_total=Ci, algo=7)
+    for grouping in ([[0], [1], [2]], [[0, 1, 2]], [[0], [1, 2]]):
+        dw = torch.zeros(Co, Ci, 4, 4, device="cuda"); db = torch.zeros(Co, device="cuda")
+        sl, first = None, True
+        for grp in grouping:
+            (g0, a0, b0), more = steps[grp[0]], [steps[i] for i in grp[1:]]
+            sl = ops.conv2d_wgrad(g0, a0, dw, in_b=b0, db=db, phase=1 if first else 2, slabs=sl, more=more, **kw)
+            first = False
+        ops.conv2d_wgrad(steps[0][0], steps[0][1], dw, in_b=steps[0][2], db=db, phase=3, slabs=sl, **kw)
+        err = float((dw.double().cpu() - w.grad).abs().max() / w.grad.abs().max())
+        assert err < 2e-5, (grouping, err)
+        assert float((db.double().cpu() - b.grad).abs().max() / b.grad.abs().max()) < 1e-5
+    # the direct tile on the same operands: the two forms agree to the fp32 class
+    dw0 = torch.zeros(Co, Ci, 4, 4, device="cuda")
+    for (g0, a0, b0) in steps:
+        ops.conv2d_wgrad(g0, a0, dw0, kh=4, kw=4, stride=2, pad=1, in_b=b0, i_total=Ci)
+    assert float((dw0 - dw).abs().max() / dw0.abs().max()) < 3e-5
+
+
 def test_conv_transpose_wgrad():
     ops = _ops()
     N, H, W, Ci, Co = 1, 8, 16, 128, 64

@@ -32,6 +32,7 @@ def algo_key(k):
     if k.startswith("conv_wino6_kernel"): return k if "<" in k else "conv_wino6_kernel<2>"
     if k.startswith("conv_wino_kernel"): return k
     if k.startswith("wgrad_wino_kernel"): return "wgrad_wino_kernel"
+    if k.startswith("wgrad_wino24_kernel") and "true" in k: return "wgrad_wino24_down_kernel"
     if k.startswith("wgrad_wino24_kernel"): return "wgrad_wino24_kernel"
     if k.startswith("conv_pw_kernel"):
         m = re.match(r"conv_pw_kernel<(\d+), (\d+)", k)
@@ -81,6 +82,7 @@ def main():
             alg_bytes = al["bytes"] / al["launches"]
             mult, peak, bound = 1.0, FP32, "mfma-fp32"
             if "wino6" in k: mult, peak, bound = 16.0 / 36.0 * 6.0, BF16, "mfma-bf16"
+            elif "wino24" in k and "true" in k: mult = 12.0 / 16.0
             elif "wino24" in k: mult = 12.0 / 36.0
             elif "wino" in k: mult = 16.0 / 36.0
             elif "split" in k: mult, peak, bound = 6.0 * 10.0 / 9.0 if "3, 2, 0>" in k else 6.0, BF16, "mfma-bf16"

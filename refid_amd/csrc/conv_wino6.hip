@@ -383,9 +383,22 @@ Wino6Plan wino6_plan(ConvKArgs& a, int split_mode, int tile_hint = 0) {
     // (tile_hint 4, an experiment switch: the 32-channel form for every layer -- three instead of two workgroups per CU,
     //  twice the V transforms / splits per product)
     p.nt = (a.Cout > 32 && tile_hint != 4) ? 2 : 1;
-    const int bn = 32 * p.nt;
     a.tilesX = cdiv(a.Wo, TW);
     a.tilesY = cdiv(a.Ho, TH);
+    // Small grids (round 5): where the 64-channel form would launch at most two workgroups per CU's worth (<= 512) and K is
+    // short (< 9 chunks = up to 128 input channels), the 32-channel form doubles the workgroups (three per CU) and mostly makes
+    // the split-K finishing launch unnecessary: B=1 103.2 -> 98.4 ms, B=2 143.0 -> 139.8, neutral at B=8 (410.1 vs 409.5; without
+    // the K limit its bottleneck convs -- 256 channels at 32 x 32 -- took the slower form: 413 ms).  REFID_WINO_TILE=1 keeps the
+    // 64-channel form.  Decided like split-K: by the total grid under policy 2, by the per-sample geometry (as if 8 samples)
+    // under policy 1.
+    if (p.nt == 2 && tile_hint == 0 && split_mode) {
+        const int ncot2 = cdiv(a.Cout, 64);
+        const int nwg2 = (split_mode == 2) ? round_up(a.tilesX * a.tilesY * a.N, 8) * ncot2 : a.tilesX * a.tilesY * ncot2 * 8;
+        static const int small_wg = []() { const char* e = getenv("REFID_WINO6_SMALL"); return e ? atoi(e) : 512; }();
+        static const int small_k = []() { const char* e = getenv("REFID_WINO6_SMALL_K"); return e ? atoi(e) : 9; }();
+        if (nwg2 <= small_wg && cdiv(a.Ctot, KC) < small_k) p.nt = 1;
+    }
+    const int bn = 32 * p.nt;
     a.nchunks = cdiv(a.Ctot, KC);
     a.ncot = cdiv(a.Cout, bn);
     p.grid = dim3(round_up(a.tilesX * a.tilesY * a.N, 8) * a.ncot);
@@ -421,7 +434,7 @@ bool refid_wino6_eligible(const ConvKArgs& a) {
 
 size_t refid_wino6_workspace_bytes(const ConvKArgs& ka, int split_mode) {
     size_t need = 0;
-    for (int hint = 0; hint <= 4; hint += 4) {             // either tile form may be asked for (wino_tile = 4): the larger need
+    for (int hint : {0, 1, 4}) {                           // any tile form may be asked for (wino_tile): the largest need
         ConvKArgs a = ka;
         const Wino6Plan p = wino6_plan(a, split_mode, hint);
         if (p.ks > 1) need = std::max(need, (size_t)p.ks * a.N * a.Ho * a.Wo * round_up(a.Cout, 4) * sizeof(float));

@@ -137,7 +137,16 @@ def _pad4(c):
 USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
 USE_POINTWISE = os.environ.get("REFID_POINTWISE", "1") != "0"     # register-operand tile for 1x1 convs
 # weight-gradient kernels on a side HIP stream (REFID_OVERLAP_WGRAD=0: everything on one stream)
-OVERLAP_WGRAD = os.environ.get("REFID_OVERLAP_WGRAD", "1") != "0"
+# 1: always; default "auto": only while the forward-wavefront streams are NOT in use (large batches) -- with them, the side
+# stream is the fifth or sixth stream on four hardware queues and cost a B=1 step 5 % (round 5: 103.5 vs 108.9 ms), while at
+# B=8 it no longer buys anything either way (434-436 ms).
+_OVL_ENV = os.environ.get("REFID_OVERLAP_WGRAD", "auto")
+OVERLAP_WGRAD = "auto" if _OVL_ENV == "auto" else _OVL_ENV != "0"
+_AUTO_OVERLAP = True                      # what "auto" means right now (Engine.backward_early decides per step)
+
+
+def overlap_wgrad():
+    return OVERLAP_WGRAD if isinstance(OVERLAP_WGRAD, bool) else _AUTO_OVERLAP
 # EGACA forward as 6 launches (LayerNorm prologues, squeeze-excite + scale inside conv3, GELU second output) instead of
 # 12; REFID_EGACA_FUSED=0: one kernel per reference op
 EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
@@ -633,7 +642,7 @@ class ConvOp:
 
         Weight gradients are off BPTT's critical path (only input gradients feed the next step), so they are
         issued on a side stream: their kernels fill the tails/gaps of the dependent dgrad chain."""
-        side = WGRAD_STREAM.get(g.device) if OVERLAP_WGRAD else None
+        side = WGRAD_STREAM.get(g.device) if overlap_wgrad() else None
         if side is None:
             return self._wgrad(g, a, b, bias, i_base)
         for t in (g, a, b):
@@ -725,7 +734,7 @@ class ConvOp:
 
     def finish_wgrad(self):
         """Reduce the accumulated slabs into the parameter gradient (once per step, after BPTT)."""
-        side = WGRAD_STREAM.get(self.w.device) if OVERLAP_WGRAD else None
+        side = WGRAD_STREAM.get(self.w.device) if overlap_wgrad() else None
         if side is not None:
             flush_wgrads(self.w.device)                    # this op's launches may still be deferred
         if self.w_calls == 0 and not self.w_pend:
@@ -1319,6 +1328,8 @@ class Engine:
         self.fold_scratch.zero_()             # folded-weight gradients of THIS backward only (see ConvOp.__init__)
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
+        global _AUTO_OVERLAP
+        _AUTO_OVERLAP = not use_pipeline(B, H, W)          # the side stream only where the wavefront streams are not in use
         self._set_wgrad_groups(T)
         dev = gout.device
         gout = gout.contiguous()

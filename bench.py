@@ -663,7 +663,8 @@ def main(argv=None, claim_stdout=False):
                                    "test_wino6_*, test_split_tile_conv_down_*; REFID_WINO6=0 / REFID_DOWN_SPLIT=0 turn them off); 3x3 "
                                    "weight gradients: fp32 MFMA in the Winograd domain over 2x4 tiles of the output gradient (F(3,2) x "
                                    "F(3,4), transforms and accumulation fp32; 3e-6 .. 6e-6 of a tensor's scale from the float64 gradient, "
-                                   "test_wgrad_f4_accuracy_class; REFID_WGRAD_F4=0: 2x2 tiles)",
+                                   "test_wgrad_f4_accuracy_class; REFID_WGRAD_F4=0: 2x2 tiles); conv_down's weight gradient: the same kernel on the "
+                                   "input's four parity phases (REFID_WGRAD_DOWN_F4=0: direct fp32 tile)",
                            "bf16x3": "fp32 tensors and accumulation; 3x3 / 4x4 forward and input-gradient products as three bf16 MFMAs "
                                      "(2^-16 per product); weight gradients fp32",
                            "bf16": "bf16 MFMA operands (forward, input and weight gradients), fp32 tensors / accumulation / "

@@ -355,15 +355,40 @@ class TwoImageEventRecurrentRestorationModel:
         self.save_network(self.net_g, "net_g", current_iter)
         self.save_training_state(epoch, current_iter)
 
-    def save_training_state(self, epoch, current_iter):
-        """base_model.py:283-306: {opt['path']['training_states']}/{iter}.state with one optimizer / scheduler entry
-        (the fused AdamW's state lives in two flat arenas: they are stored as such)."""
+    def save_training_state(self, epoch, current_iter, reference_layout=None):
+        """base_model.py:283-306: {opt['path']['training_states']}/{iter}.state with one optimizer / scheduler entry.
+        Default: the fused AdamW's state as it lives here, two flat arenas.  reference_layout=True (or
+        opt['path']['state_layout'] == 'reference'): the layout the REFERENCE writes -- `torch.optim.AdamW.state_dict()`
+        (per-parameter `step` / `exp_avg` / `exp_avg_sq` keyed by the parameter's index in named_parameters order, one
+        param group) and a torch scheduler-style dict -- so basicsr's own `resume_training` (base_model.py:308-323:
+        `optimizer.load_state_dict` / `scheduler.load_state_dict`) can continue a run started here.  `resume_training`
+        below reads both."""
         if self.rank != 0 or current_iter == -1:
             return None
-        state = {"epoch": epoch, "iter": current_iter,
-                 "optimizers": [{"type": "refid_amd.fused_adamw", "step": self.step_count,
-                                 "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()}],
-                 "schedulers": [{"type": self.sched_type, "last_epoch": self.sched_epoch, "lr": self.cur_lr}]}
+        if reference_layout is None:
+            reference_layout = self.opt.get("path", {}).get("state_layout") == "reference"
+        if reference_layout:
+            arena = self.net_g.engine.arena
+            m, v = self.exp_avg.cpu(), self.exp_avg_sq.cpu()
+            st = {}
+            for i, (k, (off, n)) in enumerate(arena.offsets.items()):
+                st[i] = {"step": torch.tensor(float(self.step_count)),
+                         "exp_avg": m[off:off + n].view(arena.shapes[k]).clone(),
+                         "exp_avg_sq": v[off:off + n].view(arena.shapes[k]).clone()}
+            group = {"lr": self.cur_lr, "betas": tuple(self.betas), "eps": self.adam_eps, "weight_decay": self.weight_decay,
+                     "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                     "fused": None, "initial_lr": self.base_lr, "params": list(range(len(st)))}
+            sched = {"last_epoch": self.sched_epoch, "_step_count": self.sched_epoch + 1, "base_lrs": [self.base_lr],
+                     "_last_lr": [self.cur_lr], "_get_lr_called_within_step": False}
+            sched.update({k: v for k, v in self.sched_cfg.items() if isinstance(v, (int, float, list, tuple))})
+            state = {"epoch": epoch, "iter": current_iter,
+                     "optimizers": [{"state": st if self.step_count else {}, "param_groups": [group]}],
+                     "schedulers": [sched]}
+        else:
+            state = {"epoch": epoch, "iter": current_iter,
+                     "optimizers": [{"type": "refid_amd.fused_adamw", "step": self.step_count,
+                                     "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()}],
+                     "schedulers": [{"type": self.sched_type, "last_epoch": self.sched_epoch, "lr": self.cur_lr}]}
         save_path = os.path.join(self.opt["path"]["training_states"], f"{current_iter}.state")
         torch.save(state, save_path)
         return save_path

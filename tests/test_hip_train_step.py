@@ -141,6 +141,28 @@ def test_save_and_resume_training_state(tmp_path):
     assert d.step_count == 4
     for (k, vb), vd in zip(b.net_g.state_dict().items(), d.net_g.state_dict().values()):
         assert torch.equal(vb, vd), k                       # no atomics on the path: the same bits
+    # ... and written by save_training_state itself in the reference's layout: torch's own AdamW loads it (what basicsr's
+    # resume_training does, base_model.py:316-320), and it resumes here to the same bits
+    b2 = TwoImageEventRecurrentRestorationModel(o2)
+    b2.resume_training(torch.load(os.path.join(tmp_path, "2.state")))
+    ref_dir = os.path.join(tmp_path, "ref_layout")
+    os.makedirs(ref_dir)
+    b2.opt["path"]["training_states"] = ref_dir
+    b2.save_training_state(0, 2, reference_layout=True)
+    written = torch.load(os.path.join(ref_dir, "2.state"))
+    plist = [torch.nn.Parameter(torch.zeros(arena.shapes[k])) for k in arena.offsets]
+    topt = torch.optim.AdamW(plist, lr=1e-4)
+    topt.load_state_dict(written["optimizers"][0])                       # torch accepts it
+    assert topt.state_dict()["param_groups"][0]["betas"] == tuple(opt["train"]["optim_g"]["betas"])
+    assert torch.equal(topt.state[plist[3]]["exp_avg"], st[3]["exp_avg"]) and float(topt.state[plist[3]]["step"]) == 2.0
+    e = TwoImageEventRecurrentRestorationModel(o2)
+    e.resume_training(written)
+    e.feed_data({"lq": x, "voxel": ev, "gt": gt})
+    for it in (3, 4):
+        e.update_learning_rate(it)
+        e.optimize_parameters(it)
+    for (k, vb), ve in zip(b.net_g.state_dict().items(), e.net_g.state_dict().values()):
+        assert torch.equal(vb, ve), k
     # a real torch `.state` is SPARSE when some parameter never received a gradient (atten_fuse.se_2 is unused in forward,
     # fusion_modules.py:261 vs :312-315): entries missing -> zero moments; here the se_2 entries are dropped, whose moments
     # are exactly zero anyway (zero gradient), so the resumed run must stay on the same bits

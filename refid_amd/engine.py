@@ -241,8 +241,12 @@ PW6 = os.environ.get("REFID_PW6", "0") == "1"
 WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
 # (round 4: the ABI takes up to 24 steps per launch.  All T steps of a sweep in ONE launch write the partial-sum slabs once
 #  instead of read-modify-writing them per group -- measured: B=8 460.5 vs 458.3 ms, B=1 109.3 vs 106.0 ms at 24 vs 8 steps: the
-#  later start of the weight-gradient kernels costs more overlap than the slab passes save.  8 stays.)
-WGRAD_GROUP = max(1, min(24, int(os.environ.get("REFID_WGRAD_GROUP", "8"))))
+#  later start of the weight-gradient kernels costs more overlap than the slab passes save.  8 stays -- for large batches.
+#  Round 5: small batches run their weight gradients on the MAIN stream (overlap_wgrad()), where a launch is a link of the
+#  dependent chain: there 24 steps per launch win (B=1: 99.6 -> 98.0 ms on a fast host, 107.8 -> 96.0 on a slow one).)
+_WG_ENV = os.environ.get("REFID_WGRAD_GROUP")
+WGRAD_GROUP = max(1, min(24, int(_WG_ENV))) if _WG_ENV else 8
+WGRAD_GROUP_SMALL = max(1, min(24, int(_WG_ENV))) if _WG_ENV else 24
 # Experiment (REFID_EXPERIMENTAL_TILES builds only): Winograd weight gradient with six exact-split bf16 products per fp32
 # product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
 # are transformed and split on the fly, ~19 VALU per MFMA.  Off.
@@ -893,10 +897,10 @@ class Engine:
         img_ops = {id(o) for e in self.img for o in e.values()} | {id(self.head_img), id(self.head_ev)}
         self.recurrent_ops = [o for o in self.all_ops if id(o) not in img_ops]
 
-    def _set_wgrad_groups(self, T):
+    def _set_wgrad_groups(self, T, small=False):
         """Group size of the deferred weight-gradient launches: min(WGRAD_GROUP, T) on the recurrent convs (a group
-        never outlives a sweep), 1 elsewhere."""
-        n = max(1, min(WGRAD_GROUP, T))
+        never outlives a sweep; small batches: WGRAD_GROUP_SMALL), 1 elsewhere."""
+        n = max(1, min(WGRAD_GROUP_SMALL if small else WGRAD_GROUP, T))
         for o in self.recurrent_ops:
             o.w_group = n
 
@@ -1329,8 +1333,9 @@ class Engine:
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
         global _AUTO_OVERLAP
-        _AUTO_OVERLAP = not use_pipeline(B, H, W)          # the side stream only where the wavefront streams are not in use
-        self._set_wgrad_groups(T)
+        small = use_pipeline(B, H, W)
+        _AUTO_OVERLAP = not small                          # the side stream only where the wavefront streams are not in use
+        self._set_wgrad_groups(T, small)
         dev = gout.device
         gout = gout.contiguous()
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]

@@ -613,9 +613,8 @@ def main(argv=None, claim_stdout=False):
         # one extra, instrumented step (every rank runs it: the step contains collectives; only rank 0
         # records): HIP events around every conv-tile / wgrad launch on the launch stream; the dominant
         # kernel = the kernel with the largest accumulated time
-        # The timed steps run the weight-gradient kernels on a side stream, concurrently with the dgrad chain;
-        # for a per-kernel duration that means something against the roofline the instrumented step runs
-        # every kernel alone on one stream (same as REFID_OVERLAP_WGRAD=0).
+        # For a per-kernel duration that means something against the roofline the instrumented step runs every kernel
+        # alone on one stream (no forward wavefront; the weight gradients are on the main stream by default anyway).
         from refid_amd import engine as _engine
         overlap, _engine.OVERLAP_WGRAD = _engine.OVERLAP_WGRAD, False
         pipeline, _engine.PIPELINE = _engine.PIPELINE, False
@@ -632,9 +631,8 @@ def main(argv=None, claim_stdout=False):
         if rank == 0:
             prof, ops.PROFILE = ops.PROFILE, None
             roof = roofline_from_profile(prof, dt / args.steps, args.dtype,
-                                         "per-kernel timing from one extra single-stream step (kernels run alone; the timed "
-                                         "steps overlap wgrad kernels on a side stream); rocprof counterpart: "
-                                         "profiles/*_nooverlap_kernel_stats.csv")
+                                         "per-kernel timing from one extra single-stream step (kernels run alone, HIP events on the "
+                                         "launch stream); rocprof counterpart: profiles/*_nooverlap_kernel_stats.csv")
 
     strong = None
     if world > 1 and args.scaling == "weak" and not args.no_strong_leg and args.batch % world == 0:

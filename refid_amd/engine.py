@@ -137,16 +137,18 @@ def _pad4(c):
 USE_WINOGRAD = os.environ.get("REFID_WINOGRAD", "1") != "0"
 USE_POINTWISE = os.environ.get("REFID_POINTWISE", "1") != "0"     # register-operand tile for 1x1 convs
 # weight-gradient kernels on a side HIP stream (REFID_OVERLAP_WGRAD=0: everything on one stream)
-# 1: always; default "auto": only while the forward-wavefront streams are NOT in use (large batches) -- with them, the side
-# stream is the fifth or sixth stream on four hardware queues and cost a B=1 step 5 % (round 5: 103.5 vs 108.9 ms), while at
-# B=8 it no longer buys anything either way (434-436 ms).
-_OVL_ENV = os.environ.get("REFID_OVERLAP_WGRAD", "auto")
-OVERLAP_WGRAD = "auto" if _OVL_ENV == "auto" else _OVL_ENV != "0"
-_AUTO_OVERLAP = True                      # what "auto" means right now (Engine.backward_early decides per step)
+# Default since the end of round 5: OFF -- the weight gradients run on the main stream, in 8-step (large batches) or 24-step
+# (small batches) groups.  The side stream dates from rounds 1-2, when the dependent input-gradient chain left the chip idle
+# between its kernels; with today's kernels a B=8 step is 100 % busy on one stream, and the second compute stream only
+# costs: B=8 412.0-413.8 ms with it vs 406.1-406.9 without (three alternating runs on one box), B=1 108.9 vs 103.5 (there it
+# is also the sixth stream on four hardware queues).  REFID_OVERLAP_WGRAD=1 turns it back on (tests/test_hip_streams.py keeps
+# its write-after-read hazard check alive).
+_OVL_ENV = os.environ.get("REFID_OVERLAP_WGRAD", "0")
+OVERLAP_WGRAD = _OVL_ENV not in ("0", "auto")
 
 
 def overlap_wgrad():
-    return OVERLAP_WGRAD if isinstance(OVERLAP_WGRAD, bool) else _AUTO_OVERLAP
+    return bool(OVERLAP_WGRAD)
 # EGACA forward as 6 launches (LayerNorm prologues, squeeze-excite + scale inside conv3, GELU second output) instead of
 # 12; REFID_EGACA_FUSED=0: one kernel per reference op
 EGACA_FUSED = os.environ.get("REFID_EGACA_FUSED", "1") != "0"
@@ -1332,10 +1334,7 @@ class Engine:
         self.fold_scratch.zero_()             # folded-weight gradients of THIS backward only (see ConvOp.__init__)
         self.ctx = None
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
-        global _AUTO_OVERLAP
-        small = use_pipeline(B, H, W)
-        _AUTO_OVERLAP = not small                          # the side stream only where the wavefront streams are not in use
-        self._set_wgrad_groups(T, small)
+        self._set_wgrad_groups(T, use_pipeline(B, H, W))
         dev = gout.device
         gout = gout.contiguous()
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]

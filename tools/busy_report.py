@@ -36,7 +36,7 @@ def main():
           f"{launches // a.stat_steps} launches")
     print(f"single-stream step, untraced (REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0): {s['ms_per_step']:.1f} ms "
           f"-> GPU busy {100 * k_ms / s['ms_per_step']:.1f} %, gaps {s['ms_per_step'] - k_ms:.1f} ms")
-    print(f"default step, untraced (weight gradients on a side stream, forward wavefront): {d['ms_per_step']:.1f} ms "
+    print(f"default step, untraced (the shipped stream layout): {d['ms_per_step']:.1f} ms "
           f"= {100 * d['ms_per_step'] / k_ms:.1f} % of the serial kernel time")
 
 

@@ -165,8 +165,11 @@ __device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap,
     return 0.f;
 }
 
-__device__ __forceinline__ void pack_elem(const PackArgs& p, long long e) {
-    long long r = e;
+// (IDX: the element index type -- unsigned where the packing has < 2^31 elements: a 64-bit division by a run-time value costs
+//  ~4x a 32-bit one, and the index decode is most of this kernel's instructions)
+template <class IDX>
+__device__ __forceinline__ void pack_elem(const PackArgs& p, IDX e) {
+    IDX r = e;
     const int kk = r % p.KC; r /= p.KC;
     const int row = r % p.rowsPad; r /= p.rowsPad;
     const int tap = r % p.ntaps; r /= p.ntaps;
@@ -181,19 +184,20 @@ __device__ __forceinline__ void pack_elem(const PackArgs& p, long long e) {
 
 __global__ __launch_bounds__(256) void pack_kernel(const PackArgs p) {
     const long long total = (long long)p.ncls * p.nchunks * p.ntaps * p.rowsPad * p.KC;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_elem(p, e);
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_elem<long long>(p, e);
 }
 
 // split-bf16 planes for conv_split.hip (8-channel sub-chunks, `planes` bf16 numbers per weight):
 //   mode 0 (3x3 s1):        [chunk8][plane][tap 0..9][rowsPad][8]            the tenth tap is zero (tap pairs fill K = 16)
 //   mode 1 (4x4 s2 forward): [chunk8][sy][sx][plane][tap (ty,tx)][rowsPad][8]  = W[row][k][2ty+sy][2tx+sx]  (2x2 input blocks)
 //   mode 2 (its dgrad):      [class][chunk8][plane][tap (ta,tb)][rowsPad][8]   (REFID_ROLE_DOWN_DGRAD's classes / taps)
-__device__ __forceinline__ void pack_split_elem(const PackArgs& p, int planes, int mode, long long e) {
+template <class IDX>
+__device__ __forceinline__ void pack_split_elem(const PackArgs& p, int planes, int mode, IDX e) {
     const int ntp = mode == 0 ? p.ntaps + 1 : 4;
     const int nsub = mode == 1 ? 4 : 1;
     __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
     {
-        long long r = e;
+        IDX r = e;
         const int k8 = r % 8; r /= 8;
         const int row = r % p.rowsPad; r /= p.rowsPad;
         const int tap = r % ntp; r /= ntp;
@@ -218,15 +222,16 @@ __device__ __forceinline__ void pack_split_elem(const PackArgs& p, int planes, i
 
 __global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes, int mode) {
     const long long total = (long long)p.ncls * p.nchunks * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? p.ntaps + 1 : 4) * p.rowsPad * 8;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_split_elem(p, planes, mode, e);
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_split_elem<long long>(p, planes, mode, e);
 }
 
 // 1x1 (conv_pw.hip, six products): [chunk16][plane][rowsPad][16]; the 16 channels of a row are stored as the two MFMA K
 // halves of the pointwise tile's lanes: slot 8h + t = channel 4h + t (t < 4) or 8 + 4h + (t - 4)
-__device__ __forceinline__ void pack_pw6_elem(const PackArgs& p, int planes, long long e) {
+template <class IDX>
+__device__ __forceinline__ void pack_pw6_elem(const PackArgs& p, int planes, IDX e) {
     __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
     {
-        long long r = e;
+        IDX r = e;
         const int slot = r % 16; r /= 16;
         const int row = r % p.rowsPad; r /= p.rowsPad;
         const int plane = r % planes;
@@ -245,33 +250,58 @@ __device__ __forceinline__ void pack_pw6_elem(const PackArgs& p, int planes, lon
 
 __global__ __launch_bounds__(256) void pack_pw6_kernel(const PackArgs p, int planes) {
     const long long total = (long long)((p.K + 15) / 16) * planes * p.rowsPad * 16;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_pw6_elem(p, planes, e);
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_pw6_elem<long long>(p, planes, e);
 }
 
-// Winograd-domain weights U = G g G^T as three bf16 planes for conv_wino6.hip: [chunk16][xi][plane][rowsPad][16]
-__device__ __forceinline__ void pack_wino6_elem(const PackArgs& p, long long e) {
-    __bf16* dst = reinterpret_cast<__bf16*>(p.dst);
-    {
-        long long r = e;
-        const int k16 = r % 16; r /= 16;
-        const int row = r % p.rowsPad; r /= p.rowsPad;
-        const int plane = r % 3; r /= 3;
-        const int xi = r % 16;
-        const int chunk = r / 16;
-        const int k = chunk * 16 + k16;
-        float v = 0.f;
-        if (row < p.rows && k < p.K) v = pack_fetch(p, 0, xi, row, k);
+// Winograd-domain weights U = G g G^T as three bf16 planes for conv_wino6.hip: [chunk16][xi][plane][rowsPad][16].
+// One thread per WEIGHT (chunk, row, k16): nine loads, the 16 transform points once, 48 two-byte stores -- a wave's 64 threads
+// (4 rows x 16 k) write 128 contiguous bytes per (xi, plane).  (The first form had one thread per OUTPUT element: 48 x the
+// loads and transforms and five 64-bit divisions each -- 0.05 of HBM for the model's 238 MB of these planes.)
+__device__ __forceinline__ void pack_wino6_weight(const PackArgs& p, unsigned f) {
+    const unsigned k16 = f & 15, r = f >> 4;
+    const unsigned row = r % (unsigned)p.rowsPad, chunk = r / (unsigned)p.rowsPad;
+    const int k = chunk * 16 + k16;
+    float u[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) u[t] = 0.f;
+    if ((int)row < p.rows && k < p.K) {
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+        const bool fwd = p.role == REFID_ROLE_WINO_FWD;
+        const float* g = fwd ? p.w + ((long long)row * p.I + k) * 9 : p.w + ((long long)k * p.I + row) * 9;
+        float gv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gv[t] = fwd ? g[t] : g[8 - t];              // dgrad: flipped taps
+        const float sc = p.oscale ? p.oscale[fwd ? row : k] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;                                               // (pack_fetch's order of additions)
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) acc += G[i][aa] * G[j][bb] * gv[aa * 3 + bb];
+                u[i * 4 + j] = acc * sc;
+            }
+    }
+    const long long plane = (long long)p.rowsPad * 16;
+    __bf16* dst = reinterpret_cast<__bf16*>(p.dst) + ((long long)chunk * 48 * p.rowsPad + row) * 16 + k16;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        const float v = u[xi];
         const __bf16 h = (__bf16)v;
         const float r1 = v - (float)h;
         const __bf16 m = (__bf16)r1;
         const __bf16 l = (__bf16)(r1 - (float)m);
-        dst[e] = plane == 0 ? h : (plane == 1 ? m : l);
+        dst[(xi * 3 + 0) * plane] = h;
+        dst[(xi * 3 + 1) * plane] = m;
+        dst[(xi * 3 + 2) * plane] = l;
     }
 }
 
 __global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
-    const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
-    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_wino6_elem(p, e);
+    const unsigned total = (unsigned)p.nchunks * p.rowsPad * 16;                  // weights (padding included)
+    for (unsigned f = blockIdx.x * 256u + threadIdx.x; f < total; f += gridDim.x * 256u) pack_wino6_weight(p, f);
 }
 
 // ---- all packings of a model in ONE launch (refid_pack_batch): the table lives in device memory, a workgroup finds its
@@ -294,13 +324,26 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __rest
     const PackArgs p = en.p;
     const int kind = en.kind, planes = en.planes, mode = en.mode;
     const long long total = en.total, stride = (long long)en.nblk * 256;
-    for (long long e = (long long)(blockIdx.x - en.blk0) * 256 + threadIdx.x; e < total; e += stride) {
-        switch (kind) {
-            case 0: pack_elem(p, e); break;
-            case 1: pack_split_elem(p, planes, mode, e); break;
-            case 2: pack_pw6_elem(p, planes, e); break;
-            case 3: pack_wino6_elem(p, e); break;
-            default: p.dst[e] = p.w[e] * p.oscale[e]; break;
+    const long long e0 = (long long)(blockIdx.x - en.blk0) * 256 + threadIdx.x;
+    if (kind == 3) {                                         // (total = weights, < 2^31: refid_pack_entry_fill)
+        for (unsigned f = (unsigned)e0; f < (unsigned)total; f += (unsigned)stride) pack_wino6_weight(p, f);
+    } else if (total < 0x7fffffffLL) {
+        for (unsigned e = (unsigned)e0; e < (unsigned)total; e += (unsigned)stride) {
+            switch (kind) {
+                case 0: pack_elem<unsigned>(p, e); break;
+                case 1: pack_split_elem<unsigned>(p, planes, mode, e); break;
+                case 2: pack_pw6_elem<unsigned>(p, planes, e); break;
+                default: p.dst[e] = p.w[e] * p.oscale[e]; break;
+            }
+        }
+    } else {
+        for (long long e = e0; e < total; e += stride) {
+            switch (kind) {
+                case 0: pack_elem<long long>(p, e); break;
+                case 1: pack_split_elem<long long>(p, planes, mode, e); break;
+                case 2: pack_pw6_elem<long long>(p, planes, e); break;
+                default: p.dst[e] = p.w[e] * p.oscale[e]; break;
+            }
         }
     }
 }
@@ -409,7 +452,8 @@ extern "C" int refid_pack_conv_weights_wino6(const float* w, const float* oscale
     REFID_CHECK(role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD, "pack_wino6: Winograd roles only");
     REFID_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_wino6: bad geometry");
     p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
-    const long long total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+    const long long total = (long long)p.nchunks * p.rowsPad * 16;                 // one thread per weight
+    REFID_CHECK(total * 48 < 0x7fffffffLL, "pack_wino6: packing of %lld elements exceeds the 32-bit index range", total * 48);
     hipLaunchKernelGGL(pack_wino6_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
     REFID_LAUNCH_CHECK("pack_conv_weights_wino6");
     return 0;
@@ -464,7 +508,8 @@ extern "C" int refid_pack_entry_fill(void* entry_host, int kind, const float* w,
         REFID_FILL_CHECK((role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD) && kh == 3 && kw == 3, "pack_entry_fill: Winograd roles, 3x3");
         REFID_FILL_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
         p.bf16 = 1;
-        en.total = (long long)p.nchunks * 16 * 3 * p.rowsPad * 16;
+        en.total = (long long)p.nchunks * p.rowsPad * 16;    // WEIGHTS (one thread each writes its 48 plane entries)
+        REFID_FILL_CHECK(en.total * 48 < 0x7fffffffLL, "pack_entry_fill: Winograd x six packing exceeds the 32-bit index range");
     } else {
         REFID_FILL_CHECK(false, "pack_entry_fill: unknown kind %d", kind);
     }

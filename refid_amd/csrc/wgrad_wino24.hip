@@ -43,6 +43,7 @@
 // Timing experiments only (tools/probes/w24_ablate.py builds the variants; results are wrong for n != 0):
 //   1: no DMA requests (stale tiles: no global traffic, no LDS writes)   2: no MFMAs (operands kept alive)
 //   3: no LDS reads (operands from opaque registers)   4: no barrier   5: 1 + 4   6: 1 + 3 + 4 (transforms + MFMAs alone)
+//   7: every request fetches the workgroup's FIRST tile again (same instructions, same LDS writes, cache hits instead of HBM)
 #ifndef REFID_W24_ABLATE
 #define REFID_W24_ABLATE 0
 #endif
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 3) void wgrad_wino24_kernel(cons
             }
         }
         // advance
+        if (REFID_W24_ABLATE == 7) return;
         qx += 1;
         if (qx != a.tilesX) {
             xTile += GW * XPS * xld * 4;

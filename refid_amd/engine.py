@@ -117,6 +117,7 @@ class ParamArena:
         self.total = off
         self.flat_p = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(off, dtype=torch.float32, device=device)
+        self.pack_epoch = 0                   # bumped by every batched repack: stamps ConvOp's lazily packed fallback layouts
 
     def p(self, k):
         o, n = self.offsets[k]
@@ -175,6 +176,8 @@ PIPELINE_MAX_PIX = int(os.environ.get("REFID_PIPELINE_MAX_PIX", str(4 * 256 * 25
 def use_pipeline(b, h, w):
     return PIPELINE if isinstance(PIPELINE, bool) else b * h * w <= PIPELINE_MAX_PIX
 PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
+# fp32 Winograd packings of convs that run on their Winograd x six planes: packed on demand instead of every step (ConvOp)
+LAZY_FALLBACK_PACKS = os.environ.get("REFID_LAZY_PACKS", "1") != "0"
 # The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
 # 199-203,211) and their BPTT counterparts (g_di + g_hd, g_b0 + g_skip) leave with the PRODUCING tile as a second output
 # (refid_conv_desc.out2 = out + add2) instead of a separate add kernel each.  0: one add kernel per sum.
@@ -450,6 +453,14 @@ class ConvOp:
         self.b_eff = self.b
         if self.scale is not None and self.has_bias:
             self.b_eff = torch.empty_like(self.b)
+        # A conv with Winograd x six planes runs on them wherever its shapes allow (fwd / dgrad below): its fp32 Winograd
+        # packing (wp / wd, algo 1) is a FALLBACK layout (two sources whose first is not a multiple of 16 channels, input-
+        # gradient row ranges below 32 rows) -- 159 MB of the model's 463 MB of packed weights that the batched repack of
+        # every optimiser step does not write; whoever needs one packs it on demand (_fallback_wp / _fallback_wd), stamped
+        # with the arena's pack epoch.  The one-by-one repack() writes everything.
+        self.wp_lazy = LAZY_FALLBACK_PACKS and self.wp6 is not None and self.f_algo == 1
+        self.wd_lazy = LAZY_FALLBACK_PACKS and self.wd6 is not None and self.d_algo == 1
+        self._wp_epoch = self._wd_epoch = -1
         # weight-gradient partial sums of the T recurrent steps accumulate in a private slab buffer
         # and are reduced into the parameter gradient once per step (finish_wgrad)
         self.wslab = None
@@ -465,8 +476,9 @@ class ConvOp:
     def plan_repack(self, plan):
         """The same packings as repack(), as entries of an ops.PackPlan (one launch for the whole model)."""
         k = self.k
-        plan.add_pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, self.wp, oscale=self.scale, bf16=self.bf16)
-        if self.wd is not None:
+        if not self.wp_lazy:
+            plan.add_pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, self.wp, oscale=self.scale, bf16=self.bf16)
+        if self.wd is not None and not self.wd_lazy:
             plan.add_pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, self.wd, oscale=self.scale, bf16=self.bf16)
         if self.wpp6 is not None:
             plan.add_split(self.w, ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, 3, self.wpp6, oscale=self.scale)
@@ -484,12 +496,34 @@ class ConvOp:
         if self.scale is not None and self.has_bias:
             plan.add_mul_vec(self.b, self.scale, self.b_eff)
 
+    def _fallback_wp(self):
+        """The fp32 Winograd forward packing, written now if the batched repack left it out (wp_lazy)."""
+        if self.wp_lazy and self._wp_epoch != self.arena.pack_epoch:
+            ops.pack_conv_weights(self.w, self.f_role, self.f_bn, self.f_kc, self.k, self.k, self.co, self.ci, out=self.wp,
+                                  oscale=self.scale)
+            self._wp_epoch = self.arena.pack_epoch
+        return self.wp
+
+    def _fallback_wd(self):
+        if self.wd_lazy and self._wd_epoch != self.arena.pack_epoch:
+            ops.pack_conv_weights(self.w, self.d_role, self.d_bn, self.d_kc, self.k, self.k, self.co, self.ci, out=self.wd,
+                                  oscale=self.scale)
+            self._wd_epoch = self.arena.pack_epoch
+        return self.wd
+
+    def pack_fallbacks(self):
+        """Bring the lazily packed layouts up to date (tests that read wp / wd directly)."""
+        self._fallback_wp()
+        if self.wd is not None:
+            self._fallback_wd()
+
     def repack(self):
         k = self.k
         pack = ops.pack_conv_weights_bf16 if self.bf16 else ops.pack_conv_weights
         pack(self.w, self.f_role, self.f_bn, self.f_kc, k, k, self.co, self.ci, out=self.wp, oscale=self.scale)
         if self.wd is not None:
             pack(self.w, self.d_role, self.d_bn, self.d_kc, k, k, self.co, self.ci, out=self.wd, oscale=self.scale)
+        self._wp_epoch = self._wd_epoch = self.arena.pack_epoch
         if self.wpp6 is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, planes=3, out=self.wpp6, oscale=self.scale)
         if self.wdp6 is not None:
@@ -557,7 +591,7 @@ class ConvOp:
             return out if plus is None else (out, ops.add(out, plus, out=o2))
         if self.f_algo == 3:                                      # (the pointwise tile has no second output)
             two = {}
-        ops.conv2d(a, self.wp, out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
+        ops.conv2d(a, self._fallback_wp(), out, kh=kh, kw=kw, stride=st, pad=self.pad, mode=md, cout=self.f_rows,
                    cout_pad=self.f_pad, in_b=b, bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post,
                    algo=self.f_algo, pw=pw, **two)
         if plus is not None and not two:
@@ -633,7 +667,7 @@ class ConvOp:
             two, fused_two = {}, False
             if gelu_mask:
                 two = dict(mask_mode=1)
-        ops.conv2d(g, self.wd, out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
+        ops.conv2d(g, self._fallback_wd(), out, kh=kh, kw=kw, stride=st, pad=pad, mode=md, cout=cnt, cout_pad=self.d_pad,
                    co_base=base, res=res, mask=mask, slope_mask=slope_mask, algo=self.d_algo, **two)
         if plus is not None and not fused_two:
             ops.add(out, plus, out=o2)
@@ -933,6 +967,7 @@ class Engine:
                     o.plan_repack(plan)
                 self._pack_plan = plan.build()
             self._pack_plan.run()
+            self.arena.pack_epoch += 1                     # the lazily packed fallback layouts are stale now
         else:
             for o in self.all_ops:
                 o.repack()

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "tools", "probes", "bin")
 VARIANTS = {0: "product tile (algo 5)", 1: "no DMA requests (stale tiles)", 2: "no MFMAs", 3: "no LDS reads", 4: "no barrier",
-            5: "no DMA, no barrier", 6: "no DMA, no LDS reads, no barrier (transforms + MFMAs alone)"}
+            5: "no DMA, no barrier", 6: "no DMA, no LDS reads, no barrier (transforms + MFMAs alone)",
+            7: "every request re-fetches the first tile (cache hits)"}
 if os.environ.get("W24_ONLY"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["W24_ONLY"].split(",")}
 

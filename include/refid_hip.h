@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 7     /* 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions); 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -232,6 +232,12 @@ typedef struct refid_wgrad_desc {
                                                    1 = partial products, OVERWRITE slabs (first step),
                                                    2 = partial products, ADD into slabs (later steps),
                                                    3 = reduction of the slabs into dw/db only (after BPTT);
+                                                   4 = as 3, but only the streaming first stage runs now: the element-wise
+                                                   stage is QUEUED and refid_wgrad_finish_flush issues every queued stage as
+                                                   one launch per kernel family (a step's ~130 small reductions are
+                                                   independent of each other; the caller must not touch `slabs`, dw or db
+                                                   between the call and the flush; two queued calls on the same dw block
+                                                   flush the queue in between);
                                                    the slab geometry depends on (c_o, i_total), not on c_a/c_b */
     int groups;                                 /* phases 0-2 (not the thin / 1x1 register tiles): 2..REFID_WGRAD_MAX_GROUPS = this launch also adds the
                                                    partial products of groups-1 MORE time steps of the same convolution
@@ -245,6 +251,10 @@ typedef struct refid_wgrad_desc {
 
 size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d);
 int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream);
+/* Issues the element-wise reduction stages queued by phase-4 calls (of this host thread) on `stream`: one launch per kernel
+ * family and 40 jobs (autograd's accumulation of the T steps' weight gradients, twoImage_event_recurrent_model.py:303; the
+ * reference has no counterpart -- its 2T per-step gradients are added by autograd one by one).  No queued job: no launch. */
+int refid_wgrad_finish_flush(void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight packing: reference layouts (Conv2d OIHW, ConvTranspose2d IOHW) -> the tile's

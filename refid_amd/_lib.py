@@ -72,7 +72,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 7          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 8          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 
@@ -99,6 +99,7 @@ def lib():
     L.refid_wgrad_workspace_bytes.argtypes = [C.POINTER(WgradDesc)]
     L.refid_wgrad_workspace_bytes.restype = C.c_size_t
     L.refid_conv2d_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]
+    L.refid_wgrad_finish_flush.argtypes = [C.c_void_p]
     L.refid_packed_weight_floats.argtypes = [C.c_int] * 7
     L.refid_packed_weight_floats.restype = C.c_size_t
     L.refid_packed_weight_split_bytes.restype = C.c_size_t

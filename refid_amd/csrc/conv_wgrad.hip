@@ -16,6 +16,8 @@
 // second kernel reduces the slabs and ACCUMULATES into the parameter-layout gradient,
 // because weights are shared over the T recurrent steps.
 #include "common.h"
+#include <vector>
+#include <cstring>
 #include "wgrad_args.h"
 #include <cstdlib>
 
@@ -652,12 +654,12 @@ struct RedArgs {
 // consecutive input channels): lane `sub` adds slabs sub, sub + LPE, ... in order, a fixed xor-shuffle tree combines the
 // LPE partial sums and lane 0 adds the total into the parameter-layout gradient (which it owns: no atomics).  LPE > 1
 // only for small weight tensors, where one thread per element would leave the chip idle.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
+__device__ __forceinline__ void wgrad_reduce_body(const RedArgs& a, const int blk) {
     const int Ci4 = a.CiP / 4;
     const long long total4 = (long long)a.ntaps * a.CoP * Ci4;
     const long long slabStride4 = total4;
     const int lpe = a.perGroup;
-    const long long gid = blockIdx.x * 256ll + threadIdx.x;
+    const long long gid = blk * 256ll + threadIdx.x;
     const long long e = gid / lpe;
     const int sub = (int)(gid % lpe);
     {
@@ -694,13 +696,47 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) {
         }
     }
     const int s0 = 0, s1 = a.nsplit;
-    if (a.db != nullptr && blockIdx.x == 0) {
+    if (a.db != nullptr && blk == 0) {
         for (int co = threadIdx.x; co < a.Co; co += 256) {
             float s = 0.f;
             for (int k = s0; k < s1; ++k) s += a.bslabs[(long long)k * a.CoP + co];
             a.db[co] += s;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const RedArgs a) { wgrad_reduce_body(a, blockIdx.x); }
+
+// every queued reduction in ONE launch (phase 4 + refid_wgrad_finish_flush): a workgroup finds its job by its block range
+struct RedBatch { RedArgs job[REFID_FINISH_BATCH]; int blk0[REFID_FINISH_BATCH + 1]; int n; };
+static_assert(sizeof(RedBatch) <= 4096, "kernel-argument block");
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const RedBatch b) {
+    int j = 0;
+    for (int k = 1; k < b.n; ++k) j = (int)blockIdx.x >= b.blk0[k] ? k : j;       // (workgroup-uniform)
+    wgrad_reduce_body(b.job[j], (int)blockIdx.x - b.blk0[j]);
+}
+
+struct RedQueued { RedArgs r; int nblocks; };
+thread_local std::vector<RedQueued> red_queue;
+thread_local bool defer_now = false;
+
+int red_flush(hipStream_t st) {
+    size_t at = 0;
+    while (at < red_queue.size()) {
+        RedBatch b;
+        memset(&b, 0, sizeof(b));
+        int n = 0, blk = 0;
+        for (; n < REFID_FINISH_BATCH && at < red_queue.size(); ++n, ++at) {
+            b.job[n] = red_queue[at].r;
+            b.blk0[n] = blk;
+            blk += red_queue[at].nblocks;
+        }
+        b.blk0[n] = blk; b.n = n;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blk), dim3(256), 0, st, b);
+        if (hipGetLastError() != hipSuccess) { red_queue.clear(); refid_set_error("wgrad_reduce_batch: launch failed"); return 1; }
+    }
+    red_queue.clear();
+    return 0;
 }
 
 // <KH,KW,S, TPW, SM,SN, WR,WC,WT, TH,TW>
@@ -805,9 +841,32 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     return ((size_t)g.nsplit * slab + (size_t)g.nsplit * g.CoP + (size_t)refid_slab_fold_count((long long)slab, g.nsplit) * slab) * sizeof(float);
 }
 
+bool refid_finish_defer_now() { return defer_now; }
+
+static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st);
+
 extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     REFID_CHECK(d != nullptr, "wgrad: null descriptor");
+    if (d->phase != 4) return conv2d_wgrad_impl(d, st);
+    // phase 4 = phase 3 with the element-wise stage queued for refid_wgrad_finish_flush (the families that have no batched
+    // form -- algo 1's tile, the thin-input tile -- run theirs at once)
+    refid_wgrad_desc dd = *d;
+    dd.phase = 3;
+    defer_now = true;
+    const int rc = conv2d_wgrad_impl(&dd, st);
+    defer_now = false;
+    return rc;
+}
+
+extern "C" int refid_wgrad_finish_flush(void* stream) {
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc = red_flush(st);
+    const int rc2 = refid_wino24_finish_flush(st);
+    return rc ? rc : rc2;
+}
+
+static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     REFID_CHECK(p.ok, "wgrad: unsupported geometry k=%dx%d stride=%d", d->kh, d->kw, d->stride);
     REFID_CHECK(d->g && d->in_a && d->dw && d->slabs, "wgrad: null tensor pointer");
@@ -956,7 +1015,15 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
     int lpe = 1;
     while (lpe < 8 && (long long)lpe * 2 * total4 <= 65536 && lpe * 2 <= r.nsplitW) lpe *= 2;
     r.perGroup = lpe;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((total4 * lpe + 255) / 256)), dim3(256), 0, st, r);
+    const int nblocks = (int)((total4 * lpe + 255) / 256);
+    if (defer_now) {
+        // two queued jobs must not add into the same gradient block (they would run concurrently): flush first
+        for (const RedQueued& q : red_queue)
+            if (q.r.dw == r.dw && q.r.iBase == r.iBase) { if (int rc2 = red_flush(st)) return rc2; break; }
+        red_queue.push_back({r, nblocks});
+        return 0;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblocks), dim3(256), 0, st, r);
     REFID_LAUNCH_CHECK("wgrad_reduce");
     return 0;
 }

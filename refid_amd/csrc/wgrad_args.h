@@ -30,3 +30,11 @@ int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats
 bool refid_wgrad_pws_ok(const refid_wgrad_desc* d);
 void refid_wgrad_pws_geo(const refid_wgrad_desc* d, int* ncoT, int* nciT, int* nsplit, int* CoP, int* CiP);
 int refid_wgrad_pws_launch(const refid_wgrad_desc* d, const WgKArgs& a, int nciT, int ncoT, hipStream_t st);
+
+// Deferred second stage of the slab reductions (refid_wgrad_desc.phase = 4 + refid_wgrad_finish_flush): a phase-4 call runs its
+// streaming fold at once and QUEUES its element-wise stage; the flush issues every queued stage of a family as ONE launch
+// (the job blocks travel as kernel arguments, at most REFID_FINISH_BATCH per launch: no device table, graph-capturable).
+// ~130 dependent 10-300 us launches of 1-30 workgroups per step become three or four.
+constexpr int REFID_FINISH_BATCH = 40;
+bool refid_finish_defer_now();                          // conv_wgrad.hip: is the running refid_conv2d_wgrad call a phase-4 call?
+int refid_wino24_finish_flush(hipStream_t st);          // wgrad_wino24.hip: its queue

@@ -37,8 +37,11 @@
 // Split-K slabs [split][24][o][i] persist over the T recurrent steps exactly like wgrad_wino.hip's (phase 1 / 2 / 3); the
 // bias gradient is the transform point (1, 1) of Gy dY Gx^T (rows {1,1} x {1,1,1,1}: the tile sum), summed by wave 1.
 #include "common.h"
+#include "wgrad_args.h"
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
+#include <vector>
 
 // Timing experiments only (tools/probes/w24_ablate.py builds the variants; results are wrong for n != 0):
 //   1: no DMA requests (stale tiles: no global traffic, no LDS writes)   2: no MFMAs (operands kept alive)
@@ -442,6 +445,7 @@ struct W24rArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
     int nsplitW;                           // slabs behind `slabs` (= nsplit, or the folded count); bslabs always has nsplit rows
+    int down;                              // (batched launch) the conv_down form of the stage
 };
 
 // First stage of the slab reduction.  Reading the slabs per (co, ci) element touches 64-256 contiguous bytes of each of 24 planes
@@ -471,13 +475,12 @@ __global__ __launch_bounds__(256) void wgrad_wino24_fold_kernel(const float* __r
 //   Ay^T = [ 1 1/2  1/2 0 ]      Ax^T = [ 1/4 -1/6 -1/6 1/24  1/24 0 ]
 //          [ 0 1/2 -1/2 0 ]             [ 0   -1/6  1/6 1/12 -1/12 0 ]
 //          [ 0 1/2  1/2 1 ]             [ 0   -1/6 -1/6 1/6   1/6  1 ]
-__global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs a) {
-    __shared__ float part[256 * (NXI + 1)];
+__device__ __forceinline__ void w24_reduce_body(const W24rArgs& a, const int blk, float* part) {
     const long long plane = (long long)a.CoP * a.CiP;
     const long long slabStride = NXI * plane;
     const int lpe = a.perGroup, eb = 256 / lpe;
     const int el = threadIdx.x % eb, sub = threadIdx.x / eb;
-    const long long e = (long long)blockIdx.x * eb + el;           // (co, ci), ci fastest
+    const long long e = (long long)blk * eb + el;           // (co, ci), ci fastest
     const bool live = e < (long long)a.Co * a.Ci;
     const int ci = live ? (int)(e % a.Ci) : 0, co = live ? (int)(e / a.Ci) : 0;
     {
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs
             for (int k = 0; k < 9; ++k) dst[k] += dg[k];
         }
     }
-    if (a.db != nullptr && blockIdx.x == 0) {
+    if (a.db != nullptr && blk == 0) {
         for (int c2 = threadIdx.x; c2 < a.Co; c2 += 256) {
             float s = 0.f;
             for (int k = 0; k < a.nsplit; ++k) s += a.bslabs[(long long)k * a.CoP + c2];
@@ -533,13 +536,18 @@ __global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs
     }
 }
 
+__global__ __launch_bounds__(256) void wgrad_wino24_reduce_kernel(const W24rArgs a) {
+    __shared__ float part[256 * (NXI + 1)];
+    w24_reduce_body(a, blockIdx.x, part);
+}
+
 // DOWN form: per (co, ci) the four phases' 24 planes -> four 3x3 blocks -> the 2x2 sub-block of each that exists in the 4x4
 // gradient (ky = 2u + p - 1, kx = 2v + q - 1), accumulated into OIHW (16 contiguous floats).  Reads the (folded) slab image
 // [split][phase][xi][co][ci]; one thread per element, slabs in order (deterministic).
-__global__ __launch_bounds__(256) void wgrad_wino24_reduce_down_kernel(const W24rArgs a) {
+__device__ __forceinline__ void w24_reduce_down_body(const W24rArgs& a, const int blk) {
     const long long plane = (long long)a.CoP * a.CiP;
     const long long slabStride = 4 * NXI * plane;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long gid = (long long)blk * 256 + threadIdx.x;
     const long long e = gid >> 2;                              // (co, ci), ci fastest; four threads = the four phases: every tap
     const int ph = (int)(gid & 3);                             // of the 4x4 gradient belongs to exactly one of them
     const bool live = e < (long long)a.Co * a.Ci;
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(256) void wgrad_wino24_reduce_down_kernel(const W24
             }
         }
     }
-    if (a.db != nullptr && blockIdx.x == 0) {
+    if (a.db != nullptr && blk == 0) {
         for (int c2 = threadIdx.x; c2 < a.Co; c2 += 256) {
             float sacc = 0.f;
             for (int k = 0; k < a.nsplit; ++k) sacc += a.bslabs[(long long)k * a.CoP + c2];
@@ -582,6 +590,23 @@ __global__ __launch_bounds__(256) void wgrad_wino24_reduce_down_kernel(const W24
         }
     }
 }
+
+__global__ __launch_bounds__(256) void wgrad_wino24_reduce_down_kernel(const W24rArgs a) { w24_reduce_down_body(a, blockIdx.x); }
+
+// every queued reduction of the family in ONE launch (refid_wgrad_desc.phase = 4 + refid_wgrad_finish_flush)
+struct W24rBatch { W24rArgs job[REFID_FINISH_BATCH]; int blk0[REFID_FINISH_BATCH + 1]; int n; };
+static_assert(sizeof(W24rBatch) <= 4096, "kernel-argument block");
+__global__ __launch_bounds__(256) void wgrad_wino24_reduce_batch_kernel(const W24rBatch b) {
+    __shared__ float part[256 * (NXI + 1)];
+    int j = 0;
+    for (int k = 1; k < b.n; ++k) j = (int)blockIdx.x >= b.blk0[k] ? k : j;       // (workgroup-uniform)
+    const int blk = (int)blockIdx.x - b.blk0[j];
+    if (b.job[j].down) w24_reduce_down_body(b.job[j], blk);
+    else w24_reduce_body(b.job[j], blk, part);
+}
+
+struct W24rQueued { W24rArgs r; int nblocks; };
+thread_local std::vector<W24rQueued> w24_queue;
 
 struct Geo24 { int ncoT, nciT, tilesX, tilesY, ntiles, nsplit, CoP, CiP; };
 
@@ -627,6 +652,25 @@ int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats
     hipLaunchKernelGGL(wgrad_wino24_fold_kernel, dim3((unsigned)((slabFloats / 4 + 255) / 256), S), dim3(256), 0, st, slabs, part,
                        slabFloats, nsplit, S);
     REFID_LAUNCH_CHECK("wgrad_slab_fold");
+    return 0;
+}
+
+int refid_wino24_finish_flush(hipStream_t st) {
+    size_t at = 0;
+    while (at < w24_queue.size()) {
+        W24rBatch b;
+        memset(&b, 0, sizeof(b));
+        int n = 0, blk = 0;
+        for (; n < REFID_FINISH_BATCH && at < w24_queue.size(); ++n, ++at) {
+            b.job[n] = w24_queue[at].r;
+            b.blk0[n] = blk;
+            blk += w24_queue[at].nblocks;
+        }
+        b.blk0[n] = blk; b.n = n;
+        hipLaunchKernelGGL(wgrad_wino24_reduce_batch_kernel, dim3(blk), dim3(256), 0, st, b);
+        if (hipGetLastError() != hipSuccess) { w24_queue.clear(); refid_set_error("wgrad_wino24_reduce_batch: launch failed"); return 1; }
+    }
+    w24_queue.clear();
     return 0;
 }
 
@@ -717,6 +761,13 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     while (lpe < 16 && (long long)lpe * 2 * total <= 65536 && lpe * 2 <= nred) lpe *= 2;
     r.perGroup = lpe;
     r.nsplitW = nred;
+    r.down = down ? 1 : 0;
+    if (refid_finish_defer_now()) {
+        for (const W24rQueued& q : w24_queue)              // (two jobs on one gradient block would race: flush first)
+            if (q.r.dw == r.dw && q.r.iBase == r.iBase) { if (int rc = refid_wino24_finish_flush(st)) return rc; break; }
+        w24_queue.push_back({r, down ? (int)((total * 4 + 255) / 256) : (int)((total + 256 / lpe - 1) / (256 / lpe))});
+        return 0;
+    }
     if (down) {
         hipLaunchKernelGGL(wgrad_wino24_reduce_down_kernel, dim3((int)((total * 4 + 255) / 256)), dim3(256), 0, st, r);
         REFID_LAUNCH_CHECK("wgrad_wino24_reduce_down");

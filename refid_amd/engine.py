@@ -178,6 +178,8 @@ def use_pipeline(b, h, w):
 PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
 # fp32 Winograd packings of convs that run on their Winograd x six planes: packed on demand instead of every step (ConvOp)
 LAZY_FALLBACK_PACKS = os.environ.get("REFID_LAZY_PACKS", "1") != "0"
+# the element-wise slab-reduction stages at the end of BPTT as one launch per kernel family (finish_wgrads)
+FINISH_BATCH = os.environ.get("REFID_FINISH_BATCH", "1") != "0"
 # The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
 # 199-203,211) and their BPTT counterparts (g_di + g_hd, g_b0 + g_skip) leave with the PRODUCING tile as a second output
 # (refid_conv_desc.out2 = out + add2) instead of a separate add kernel each.  0: one add kernel per sum.
@@ -772,8 +774,10 @@ class ConvOp:
         self.w_last = (g, a, b, self.w_algo)
         self.w_pend = []
 
-    def finish_wgrad(self):
-        """Reduce the accumulated slabs into the parameter gradient (once per step, after BPTT)."""
+    def finish_wgrad(self, batched=False):
+        """Reduce the accumulated slabs into the parameter gradient (once per step, after BPTT).  batched: the element-wise
+        stage is only queued (phase 4); the caller ends its loop over the ops with ops.wgrad_finish_flush()
+        (finish_wgrads below)."""
         side = WGRAD_STREAM.get(self.w.device) if overlap_wgrad() else None
         if side is not None:
             flush_wgrads(self.w.device)                    # this op's launches may still be deferred
@@ -783,16 +787,29 @@ class ConvOp:
             with torch.cuda.stream(side):
                 self._finish_wgrad()
         else:
-            self._finish_wgrad()
+            self._finish_wgrad(batched)
 
-    def _finish_wgrad(self):
+    def _finish_wgrad(self, batched=False):
         if self.w_pend:
             self._launch_group()                           # the last, possibly shorter, group
         g, a, b, algo = self.w_last
         ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                         db=self.gb, i_total=self.ci, algo=algo, phase=3, slabs=self.wslab)
+                         db=self.gb, i_total=self.ci, algo=algo, phase=4 if batched else 3, slabs=self.wslab)
         self.w_calls = 0
         self.w_last = None
+
+
+def finish_wgrads(op_list):
+    """finish_wgrad() of every op, with the ~130 small element-wise reduction stages of a step issued as one launch per
+    kernel family (refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush; REFID_FINISH_BATCH=0: one launch per op).  The ops'
+    gradient tensors are distinct, so the queued stages are independent."""
+    batched = FINISH_BATCH and not overlap_wgrad()
+    try:
+        for o in op_list:
+            o.finish_wgrad(batched)
+    finally:
+        if batched:
+            ops.wgrad_finish_flush()                       # (also after an error: nothing stays queued in the library)
 
 
 class _Trunk:
@@ -1459,8 +1476,7 @@ class Engine:
         # forward-sweep, bottleneck, decoder and pred weights are final from here on -- except the
         # folded EGACA convs, un-folded now so the early bucket is complete
         self._egaca_img_bwd(self.enc_f[1].att, xb[0], g_xb[0], c["ip_f"])
-        for o in self.early_ops:
-            o.finish_wgrad()
+        finish_wgrads(self.early_ops)
         WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_f[1].att)
         return dict(c=c, B=B, dev=dev, g_xb=g_xb, g_Sb=g_Sb, g_e=g_e, g_head=g_head)
@@ -1510,8 +1526,7 @@ class Engine:
             else:
                 g = E["conv_1"].dgrad(g_c1, res=t1, mask=head, slope_mask=0.2)
         self.head_img.wgrad(g, c["x_in"])
-        for o in self.all_ops:
-            o.finish_wgrad()
+        finish_wgrads(self.all_ops)
         WGRAD_STREAM.join(dev)
         self._egaca_fold_back(self.enc_b[1].att)
 

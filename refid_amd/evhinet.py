@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from ._lib import RefidHipError
-from .engine import ConvOp, ParamArena, WGRAD_STREAM, _pad4
+from .engine import ConvOp, ParamArena, WGRAD_STREAM, _pad4, finish_wgrads
 
 
 def param_shapes(in_chn=3, ev_chn=6, wf=64, depth=3, fac_place=2, hin_position_left=0, hin_position_right=4):
@@ -275,8 +275,7 @@ class EvhinetEngine:
                 g_out = Bk.down.dgrad(g_e1, res=g_out)
             g_e1 = self._block_bwd(Bk, g_out, c["ev"][i])
         self.conv_ev1.wgrad(g_e1, c["ev_in"])
-        for o in self.all_ops:
-            o.finish_wgrad()
+        finish_wgrads(self.all_ops)
         WGRAD_STREAM.join(self.device)
         if grad_sync is not None:
             grad_sync("early")

@@ -276,7 +276,8 @@ def _workspace(nbytes, device, kind="wgrad"):
 def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_base=0, i_total=None, algo=0,
                  phase=0, slabs=None, more=()):
     """phase 0: one-shot.  phase 1/2: partial products into the caller's persistent `slabs`
-    (overwrite / add); phase 3: reduce `slabs` into dw/db (see refid_wgrad_desc).  Returns `slabs`."""
+    (overwrite / add); phase 3: reduce `slabs` into dw/db (see refid_wgrad_desc); phase 4: as 3 with the element-wise
+    stage queued until wgrad_finish_flush().  Returns `slabs`."""
     """dw (+)= wgrad, db (+)= sum g; dw in the reference layout (c_o, i_total, kh, kw)."""
     d = WgradDesc()
     d.g, d.ld_g = _nhwc(g, "g")
@@ -328,7 +329,7 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
                                      "see the geometry of the phase-1 call)")
         ws = slabs
     d.slabs = ws.data_ptr()
-    if PROFILE is None or phase == 3:
+    if PROFILE is None or phase >= 3:
         check(lib().refid_conv2d_wgrad(C.byref(d), _stream()), "refid_conv2d_wgrad")
         return slabs
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -342,6 +343,12 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
                                                            f"wgrad_kernel<{kh}x{kw}s{stride}>")), flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, d.c_o, 0, 0, int(db is not None)), nbytes))
     return slabs
+
+
+def wgrad_finish_flush():
+    """Issue the element-wise slab-reduction stages queued by conv2d_wgrad(..., phase=4) calls: one launch per kernel
+    family on the current stream (refid_wgrad_finish_flush)."""
+    check(lib().refid_wgrad_finish_flush(_stream()), "refid_wgrad_finish_flush")
 
 
 def nchw_to_nhwc(src, c_pad=None, out=None):

@@ -68,6 +68,33 @@ def test_outputs_and_gradients_are_bit_deterministic():
         assert not diff, diff[:8]
 
 
+def test_batched_slab_reductions_equal_the_one_by_one_launches():
+    """refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush: the element-wise stages of every op's slab reduction issued as one
+    launch per kernel family give the BITS of the per-op launches (same per-element order of additions) -- all 183
+    gradients, two backward passes each way (a second pass shows nothing stayed queued)."""
+    from refid_amd import engine as E
+    P = O.make_params(26, base_num_channels=32, mode="hash", seed=7)
+    net = build(26, 32, P)
+    x, ev, gt = O.make_inputs(2, 3, 64, 64, 26, seed=7, mode="hash")
+    x, ev, gt = x.cuda(), ev.cuda(), gt.cuda()
+    old = E.FINISH_BATCH
+    runs = []
+    try:
+        for flag in (True, False, True, False):
+            E.FINISH_BATCH = flag
+            net.zero_grad(set_to_none=False)
+            pred = net(x=x, event=ev)
+            torch.sqrt((pred - gt) ** 2 + 1e-12).mean().backward()
+            torch.cuda.synchronize()
+            runs.append({k: p.grad.clone() for k, p in net.named_parameters()})
+    finally:
+        E.FINISH_BATCH = old
+    assert any(float(g.abs().max()) > 0 for g in runs[0].values())
+    for grads in runs[1:]:
+        diff = [k for k in grads if not torch.equal(grads[k], runs[0][k])]
+        assert not diff, diff[:8]
+
+
 def _grad_check(net, P, grads_ref, rtol=2e-3):
     worst = []
     for k, p in net.named_parameters():

@@ -861,9 +861,10 @@ extern "C" int refid_conv2d_wgrad(const refid_wgrad_desc* d, void* stream) {
 
 extern "C" int refid_wgrad_finish_flush(void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int rc0 = refid_slab_fold_flush(st);             // first stages before the element-wise stages that read them
     const int rc = red_flush(st);
     const int rc2 = refid_wino24_finish_flush(st);
-    return rc ? rc : rc2;
+    return rc0 ? rc0 : (rc ? rc : rc2);
 }
 
 static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
@@ -1019,7 +1020,11 @@ static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
     if (defer_now) {
         // two queued jobs must not add into the same gradient block (they would run concurrently): flush first
         for (const RedQueued& q : red_queue)
-            if (q.r.dw == r.dw && q.r.iBase == r.iBase) { if (int rc2 = red_flush(st)) return rc2; break; }
+            if (q.r.dw == r.dw && q.r.iBase == r.iBase) {
+                if (int rc2 = refid_slab_fold_flush(st)) return rc2;
+                if (int rc2 = red_flush(st)) return rc2;
+                break;
+            }
         red_queue.push_back({r, nblocks});
         return 0;
     }

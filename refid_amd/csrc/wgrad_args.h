@@ -38,3 +38,4 @@ int refid_wgrad_pws_launch(const refid_wgrad_desc* d, const WgKArgs& a, int nciT
 constexpr int REFID_FINISH_BATCH = 40;
 bool refid_finish_defer_now();                          // conv_wgrad.hip: is the running refid_conv2d_wgrad call a phase-4 call?
 int refid_wino24_finish_flush(hipStream_t st);          // wgrad_wino24.hip: its queue
+int refid_slab_fold_flush(hipStream_t st);              // wgrad_wino24.hip: the queued first stages (before either family's second)

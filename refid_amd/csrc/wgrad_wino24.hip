@@ -453,10 +453,9 @@ struct W24rArgs {
 // consecutive floats of the slab image (4 KB contiguous per slab) and adds the slabs s, s + S, s + 2S, ... in order into partial
 // slab s: plain streaming at ~6 TB/s.  The second stage (below) then reads S <= 16 slabs instead of nsplit.  Deterministic:
 // fixed partition, fixed order.
-__global__ __launch_bounds__(256) void wgrad_wino24_fold_kernel(const float* __restrict__ slabs, float* __restrict__ part,
-                                                                long long slabFloats, int nsplit, int S) {
-    const long long off = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    const int s = blockIdx.y;
+__device__ __forceinline__ void w24_fold_body(const float* __restrict__ slabs, float* __restrict__ part, long long slabFloats,
+                                              int nsplit, int S, int piece, int s) {
+    const long long off = ((long long)piece * 256 + threadIdx.x) * 4;
     if (off >= slabFloats) return;
     const f32x4* p = reinterpret_cast<const f32x4*>(slabs + off);
     const long long st4 = slabFloats / 4;
@@ -466,6 +465,25 @@ __global__ __launch_bounds__(256) void wgrad_wino24_fold_kernel(const float* __r
     if (k < nsplit) a0 += p[k * st4];
     *reinterpret_cast<f32x4*>(part + (long long)s * slabFloats + off) = a0 + a1;
 }
+__global__ __launch_bounds__(256) void wgrad_wino24_fold_kernel(const float* __restrict__ slabs, float* __restrict__ part,
+                                                                long long slabFloats, int nsplit, int S) {
+    w24_fold_body(slabs, part, slabFloats, nsplit, S, blockIdx.x, blockIdx.y);
+}
+
+// the folds queued by phase-4 calls in ONE launch (before the batched element-wise stages): job j owns pieces x S workgroups
+constexpr int FOLD_BATCH = 96;
+struct FoldJob { const float* slabs; float* part; long long slabFloats; int nsplit, S; };
+struct FoldBatch { FoldJob job[FOLD_BATCH]; int blk0[FOLD_BATCH + 1]; int n; };
+static_assert(sizeof(FoldBatch) <= 4096, "kernel-argument block");
+__global__ __launch_bounds__(256) void wgrad_fold_batch_kernel(const FoldBatch b) {
+    int j = 0;
+    for (int k = 1; k < b.n; ++k) j = (int)blockIdx.x >= b.blk0[k] ? k : j;       // (workgroup-uniform)
+    const FoldJob& f = b.job[j];
+    const int blk = (int)blockIdx.x - b.blk0[j];
+    const int pieces = (int)((f.slabFloats / 4 + 255) / 256);
+    w24_fold_body(f.slabs, f.part, f.slabFloats, f.nsplit, f.S, blk % pieces, blk / pieces);
+}
+thread_local std::vector<FoldJob> fold_queue;
 
 // slab reduction + inverse transform dg = Ay^T dU Ax, accumulated into OIHW (9 contiguous floats).  Deterministic (no atomics).
 // A workgroup owns EB = 256 / LPE consecutive (co, ci) elements (ci fastest); thread (sub = t / EB, e = t % EB) adds the slabs
@@ -649,9 +667,37 @@ int refid_slab_fold_count(long long slabFloats, int nsplit) {
     return S < 1 ? 1 : S;
 }
 int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats, int nsplit, int S, hipStream_t st) {
+    static const bool batch_folds = !(getenv("REFID_FOLD_BATCH") && getenv("REFID_FOLD_BATCH")[0] == '0');
+    if (batch_folds && refid_finish_defer_now()) {         // phase 4: with the other queued folds (refid_slab_fold_flush)
+        fold_queue.push_back({slabs, part, slabFloats, nsplit, S});
+        return 0;
+    }
     hipLaunchKernelGGL(wgrad_wino24_fold_kernel, dim3((unsigned)((slabFloats / 4 + 255) / 256), S), dim3(256), 0, st, slabs, part,
                        slabFloats, nsplit, S);
     REFID_LAUNCH_CHECK("wgrad_slab_fold");
+    return 0;
+}
+
+int refid_slab_fold_flush(hipStream_t st) {
+    size_t at = 0;
+    while (at < fold_queue.size()) {
+        FoldBatch b;
+        memset(&b, 0, sizeof(b));
+        int n = 0;
+        long long blk = 0;
+        for (; n < FOLD_BATCH && at < fold_queue.size(); ++n, ++at) {
+            const FoldJob& f = fold_queue[at];
+            const long long nb = ((f.slabFloats / 4 + 255) / 256) * f.S;
+            if (n > 0 && blk + nb > 0x3fffffffLL) break;
+            b.job[n] = f;
+            b.blk0[n] = (int)blk;
+            blk += nb;
+        }
+        b.blk0[n] = (int)blk; b.n = n;
+        hipLaunchKernelGGL(wgrad_fold_batch_kernel, dim3((unsigned)blk), dim3(256), 0, st, b);
+        if (hipGetLastError() != hipSuccess) { fold_queue.clear(); refid_set_error("wgrad_fold_batch: launch failed"); return 1; }
+    }
+    fold_queue.clear();
     return 0;
 }
 
@@ -764,7 +810,11 @@ int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st) {
     r.down = down ? 1 : 0;
     if (refid_finish_defer_now()) {
         for (const W24rQueued& q : w24_queue)              // (two jobs on one gradient block would race: flush first)
-            if (q.r.dw == r.dw && q.r.iBase == r.iBase) { if (int rc = refid_wino24_finish_flush(st)) return rc; break; }
+            if (q.r.dw == r.dw && q.r.iBase == r.iBase) {
+                if (int rc = refid_slab_fold_flush(st)) return rc;
+                if (int rc = refid_wino24_finish_flush(st)) return rc;
+                break;
+            }
         w24_queue.push_back({r, down ? (int)((total * 4 + 255) / 256) : (int)((total + 256 / lpe - 1) / (256 / lpe))});
         return 0;
     }

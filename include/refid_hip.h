@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions); 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -113,7 +113,10 @@ typedef struct refid_conv_desc {
                                                    from the REFID_ROLE_WINO_* packings);
                                                    3 = register-operand pointwise tile (1x1, stride 1,
                                                    mode 0; w_packed = REFID_ROLE_FWD/DGRAD packing with
-                                                   kc = 8);
+                                                   kc = 8) -- and mode 1, ConvTranspose2d(2,2) as the 1x1
+                                                   GEMM over its 4 Co columns with a pixel-shuffle store
+                                                   (REFID_ROLE_CONVT packing, kc = 8, bn = 32; bias / res /
+                                                   slopes only; Co a multiple of 4, 4 Co > 32);
                                                    2 = direct tile with bf16 MFMA operands (fp32
                                                    accumulate/epilogue/tensors; w_packed from
                                                    refid_pack_conv_weights_bf16 with kc doubled);
@@ -448,6 +451,13 @@ int refid_nchw_tsum_to_nhwc(const float* src, long long src_batch_stride, long l
  * (B,T,3,H,W) stack is written in place: XXNet_final_attenfusion_arch.py:218). */
 int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch_stride,
                        int n, int c, int h, int w, void* stream);
+/* The two conversions for a whole (B, T, C, H, W) stack in ONE launch, TIME-MAJOR on the NHWC side: NHWC sample t nb + b
+ * <-> the stack's (b, t) block at b b_stride + t t_stride floats.  The event stack in (XXNet_final_attenfusion_arch.py:149,
+ * 172-176: the recurrent loops read e[:, t]), the output stack out and its gradient back in (arch:218). */
+int refid_nchw_to_nhwc_tb(const float* src, long long b_stride, long long t_stride, float* dst, int nb, int nt, int c, int h,
+                          int w, int c_pad, void* stream);
+int refid_nhwc_to_nchw_tb(const float* src, int ld, float* dst, long long b_stride, long long t_stride, int nb, int nt, int c,
+                          int h, int w, void* stream);
 /* out = a + b (skip sums: XXNet_final_attenfusion_arch.py:16-17,199-203,211,215;
  * recurrent_sub_modules.py:278). count = number of floats, multiple of 4. */
 int refid_add(const float* a, const float* b, float* out, long long count, void* stream);

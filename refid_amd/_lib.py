@@ -110,6 +110,8 @@ def lib():
     L.refid_nchw_tsum_to_nhwc.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_int, C.c_void_p] + [C.c_int] * 5 + \
         [C.c_void_p]
     L.refid_nhwc_to_nchw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong] + [C.c_int] * 4 + [C.c_void_p]
+    L.refid_nchw_to_nhwc_tb.argtypes = [C.c_void_p, C.c_longlong, C.c_longlong, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p]
+    L.refid_nhwc_to_nchw_tb.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_longlong] + [C.c_int] * 5 + [C.c_void_p]
     L.refid_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
     L.refid_sum_n.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]
     L.refid_act_bwd.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int, C.c_longlong, C.c_void_p]

@@ -23,6 +23,9 @@ struct ConvKArgs {
     // and their backward counterparts leave with the producing tile instead of a separate add kernel); NULL = off
     const float* add2 = nullptr; float* out2 = nullptr; int ldA2 = 0, ldO2 = 0;
     int maskMode = 0;          // 0: out *= (mask > 0 ? 1 : slopeMask);  1 (pointwise tile): out *= GELU'(mask)
+    // pointwise tile only: ConvTranspose2d(2,2) forward (refid_conv_desc.mode 1) -- GEMM column j = (q, co) of pixel (n, y, x)
+    // is channel co of output pixel (n, 2y + q/2, 2x + q%2); Cout = 4 Co; the bias has Co entries
+    int shuffle = 0;
 };
 
 

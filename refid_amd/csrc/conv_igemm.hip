@@ -474,9 +474,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
     REFID_CHECK(d->pw == nullptr || d->algo == 3, "conv2d: pw fusions belong to the pointwise tile (algo 3)");
-    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 5) && f == F_3x3) || (d->algo == 3 && f == F_1x1) ||
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 5) && f == F_3x3) || (d->algo == 3 && (f == F_1x1 || f == F_convT)) ||
                     (d->algo == 4 && (f == F_3x3 || f == F_4x4s2 || f == F_downDgrad)),
-                "conv2d: algo %d does not fit this geometry (1 / 5 = 3x3 stride 1, 3 = 1x1, 4 = 3x3 stride 1 / 4x4 stride 2 and "
+                "conv2d: algo %d does not fit this geometry (1 / 5 = 3x3 stride 1, 3 = 1x1 and ConvTranspose2d(2,2), 4 = 3x3 stride 1 / 4x4 stride 2 and "
                 "its input gradient)", d->algo);
     REFID_CHECK(d->algo != 2 || d->c_b == 0 || d->c_a % 8 == 0, "conv2d: bf16 tile needs c_a %% 8 == 0 for two sources");
     const int bn = refid_conv_bn(d->kh, d->kw, d->stride, d->mode, d->cout);
@@ -519,6 +519,9 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     const int kc = refid_conv_kc(d->kh, d->kw, d->stride, d->mode) * (a.bf16 ? 2 : 1);
     a.wClsStride = (long long)cdiv(a.Ctot, kc) * 4 * d->cout_pad * kc;   // mode 2 only
     if (d->algo == 3) {
+        a.shuffle = (d->mode == 1) ? 1 : 0;                 // ConvTranspose2d(2,2) as a 1x1 GEMM over 4 Co columns + pixel shuffle
+        REFID_CHECK(!a.shuffle || (d->pw == nullptr && d->mask == nullptr && d->out2 == nullptr && d->co_base == 0),
+                    "conv2d: ConvTranspose2d on the pointwise tile takes no mask / second output / fusions / row range");
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: pointwise tile needs c_a %% 8 == 0 for two sources");
         const long long lim = 0x7fffffffLL;
         REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&

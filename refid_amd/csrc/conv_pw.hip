@@ -304,6 +304,18 @@ __global__ __launch_bounds__(256, (SIX || NT > 2) ? 3 : 4) void conv_pw_kernel(c
                 const int j0 = n0 + h0 * 32 + c4 * 4;
                 if (pp >= npix || j0 >= a.Cout) continue;
                 f32x4 v = t[px * PITCH + c4];
+                if (a.shuffle) {                            // (workgroup-uniform) ConvTranspose2d(2,2): pixel-shuffle store
+                    const int Co1 = a.Cout >> 2;
+                    const unsigned qd = (unsigned)j0 / (unsigned)Co1, ch = (unsigned)j0 - qd * Co1;
+                    const unsigned up = (unsigned)pp, row = up / (unsigned)a.W, x = up - row * a.W;   // row = n H + y
+                    const long long op = (long long)(2 * row + (qd >> 1)) * (2 * a.W) + 2 * x + (qd & 1);
+                    if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + ch);
+                    lrelu4(v, a.slopePre, a.slopePre != 1.f);
+                    if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + op * a.ldR + ch);
+                    lrelu4(v, a.slopePost, a.slopePost != 1.f);
+                    *reinterpret_cast<f32x4*>(a.out + op * a.ldO + ch) = v;
+                    continue;
+                }
                 if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + a.coBase + j0);
                 lrelu4(v, a.slopePre, a.slopePre != 1.f);
                 if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + pp * a.ldR + j0);
@@ -363,6 +375,10 @@ int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* e
     const long long npix = (long long)a.N * a.H * a.W;
     const int nb = (int)((npix + 127) / 128);
     const bool six = terms == 6;
+    REFID_CHECK(!a.shuffle || (a.vecOK && ex == nullptr && terms == 0 && a.mask == nullptr && a.Cout > 32 && (a.Cout / 4) % 4 == 0 &&
+                               npix < 0x7fffffffLL),
+                "conv2d: ConvTranspose2d on the pointwise tile needs 16-byte aligned tensors, fp32 products, no mask / fusions and "
+                "at least 16 output channels");
     REFID_CHECK(terms == 0 || terms == 6, "conv2d: the pointwise tile has fp32 products (0) or six bf16 products (6), got %d", terms);
     REFID_CHECK(!six || (a.Ctot % 16 == 0 && (a.inB == nullptr || a.Ca % 16 == 0) && a.Cout > 32),
                 "conv2d: the six-product pointwise tile needs channel counts that are multiples of 16 and more than 32 outputs");

@@ -38,10 +38,13 @@ namespace {
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
                                                           long long srcBatchStride,
                                                           float* __restrict__ dst, int C, int HW,
-                                                          int Cpad, int tCount, long long tStride) {
-    // grid.x = pixel blocks of 64, grid.y = n
+                                                          int Cpad, int tCount, long long tStride, int nb) {
+    // grid.x = pixel blocks of 64, grid.y = n.  nb > 0 (time-major form, tCount = 1): output sample n = t nb + b reads the
+    // source's (b, t) block, at b srcBatchStride + t tStride
     __shared__ float tile[64][65];
     const int n = blockIdx.y;
+    const long long srcOff = nb > 0 ? (long long)(n % nb) * srcBatchStride + (long long)(n / nb) * tStride
+                                    : (long long)n * srcBatchStride;
     const int p0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // ty in 0..3
     for (int c0 = 0; c0 < Cpad; c0 += 64) {
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
             const int c = c0 + cc, p = p0 + tx;
             float v = 0.f;
             if (c < C && p < HW) {
-                const float* sp = src + (long long)n * srcBatchStride + (long long)c * HW + p;
+                const float* sp = src + srcOff + (long long)c * HW + p;
                 for (int t = 0; t < tCount; ++t) v += sp[t * tStride];
             }
             tile[cc][tx] = v;
@@ -67,9 +70,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld,
                                                           float* __restrict__ dst,
-                                                          long long dstBatchStride, int C, int HW) {
+                                                          long long dstBatchStride, int C, int HW, int nb, long long tStride) {
+    // nb > 0: source sample n = t nb + b (time-major) goes to the destination's (b, t) block
     __shared__ float tile[64][65];
     const int n = blockIdx.y;
+    const long long dstOff = nb > 0 ? (long long)(n % nb) * dstBatchStride + (long long)(n / nb) * tStride
+                                    : (long long)n * dstBatchStride;
     const int p0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int c0 = 0; c0 < C; c0 += 64) {
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
         __syncthreads();
         for (int cc = ty; cc < 64; cc += 4) {
             const int c = c0 + cc, p = p0 + tx;
-            if (c < C && p < HW) dst[(long long)n * dstBatchStride + (long long)c * HW + p] = tile[tx][cc];
+            if (c < C && p < HW) dst[dstOff + (long long)c * HW + p] = tile[tx][cc];
         }
         __syncthreads();
     }
@@ -576,8 +582,19 @@ extern "C" int refid_nchw_to_nhwc(const float* src, long long src_batch_stride, 
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc: bad arguments");
     dim3 grid(cdiv(h * w, 64), n);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
-                       h * w, c_pad, 1, 0ll);
+                       h * w, c_pad, 1, 0ll, 0);
     REFID_LAUNCH_CHECK("nchw_to_nhwc");
+    return 0;
+}
+
+extern "C" int refid_nchw_to_nhwc_tb(const float* src, long long b_stride, long long t_stride, float* dst, int nb, int nt,
+                                     int c, int h, int w, int c_pad, void* stream) {
+    REFID_CHECK(src && dst && nb > 0 && nt > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc_tb: bad arguments");
+    REFID_CHECK((long long)nb * nt <= 65535, "nchw_to_nhwc_tb: more than 65535 (sample, step) blocks");
+    dim3 grid(cdiv(h * w, 64), nb * nt);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, b_stride, dst, c, h * w, c_pad, 1,
+                       t_stride, nb);
+    REFID_LAUNCH_CHECK("nchw_to_nhwc_tb");
     return 0;
 }
 
@@ -587,7 +604,7 @@ extern "C" int refid_nchw_tsum_to_nhwc(const float* src, long long src_batch_str
                 "nchw_tsum_to_nhwc: bad arguments");
     dim3 grid(cdiv(h * w, 64), n);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
-                       h * w, c_pad, t_count, t_stride);
+                       h * w, c_pad, t_count, t_stride, 0);
     REFID_LAUNCH_CHECK("nchw_tsum_to_nhwc");
     return 0;
 }
@@ -597,8 +614,19 @@ extern "C" int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long lon
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && ld >= c, "nhwc_to_nchw: bad arguments");
     dim3 grid(cdiv(h * w, 64), n);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, dst,
-                       dst_batch_stride, c, h * w);
+                       dst_batch_stride, c, h * w, 0, 0ll);
     REFID_LAUNCH_CHECK("nhwc_to_nchw");
+    return 0;
+}
+
+extern "C" int refid_nhwc_to_nchw_tb(const float* src, int ld, float* dst, long long b_stride, long long t_stride, int nb,
+                                     int nt, int c, int h, int w, void* stream) {
+    REFID_CHECK(src && dst && nb > 0 && nt > 0 && c > 0 && h > 0 && w > 0 && ld >= c, "nhwc_to_nchw_tb: bad arguments");
+    REFID_CHECK((long long)nb * nt <= 65535, "nhwc_to_nchw_tb: more than 65535 (sample, step) blocks");
+    dim3 grid(cdiv(h * w, 64), nb * nt);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, dst, b_stride, c, h * w, nb,
+                       t_stride);
+    REFID_LAUNCH_CHECK("nhwc_to_nchw_tb");
     return 0;
 }
 

@@ -178,6 +178,7 @@ def use_pipeline(b, h, w):
 PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight packings of a step in one launch
 # fp32 Winograd packings of convs that run on their Winograd x six planes: packed on demand instead of every step (ConvOp)
 LAZY_FALLBACK_PACKS = os.environ.get("REFID_LAZY_PACKS", "1") != "0"
+CONVT_PW = os.environ.get("REFID_CONVT_PW", "1") != "0"           # ConvTranspose2d forward on the pointwise tile
 # the element-wise slab-reduction stages at the end of BPTT as one launch per kernel family (finish_wgrads)
 FINISH_BATCH = os.environ.get("REFID_FINISH_BATCH", "1") != "0"
 # The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
@@ -377,6 +378,11 @@ class ConvOp:
             self.d_algo, self.d_role = 1, ops.ROLE_WINO_DGRAD
         elif pointwise:
             self.f_algo = self.d_algo = 3
+            self.f_kc, self.f_bn = 8, 32
+        elif kind == "convT" and USE_POINTWISE and CONVT_PW and self.ci % 16 == 0 and self.co % 4 == 0 and 4 * self.co > 32:
+            # ConvTranspose2d(2,2) forward = a 1x1 GEMM over 4 Co columns: the register-operand pointwise tile with a
+            # pixel-shuffle store (the LDS-staged direct tile ran it at 0.24 of the fp32 pipe with 0.78 LDS bank conflicts)
+            self.f_algo = 3
             self.f_kc, self.f_bn = 8, 32
         self.f_pad = -(-self.f_rows // self.f_bn) * self.f_bn
         dev = self.w.device
@@ -704,11 +710,12 @@ class ConvOp:
                              algo=0, phase=0)
             return
         if self.kind == "convT":
-            # roles swapped (refid_hip.h): "g" := layer input (low res), "src" := output gradient
-            ops.conv2d_wgrad(a, g, self.gw, kh=2, kw=2, stride=2, pad=0)
+            # roles swapped (refid_hip.h): "g" := layer input (low res), "src" := output gradient: a 2x2 stride-2 weight
+            # gradient in the IOHW layout; grouped over the time steps and reduced once per backward like the others
+            # (round 5; it was a one-shot call per step: 69 partial-product + 69 reduction launches per step)
             if self.has_bias and bias:
                 ops.colsum(g, self.gb)
-            return
+            g, a, b, bias = a, g, None, False
         gb = self.gb if bias else None
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
         if algo == 1 and b is not None and a.shape[3] % 32 != 0:
@@ -725,7 +732,7 @@ class ConvOp:
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         pws = PWS_WGRAD and self.kind == "conv" and self.k == 1 and algo == 0 and self._pws_ok(a, b)
-        if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind == "down" or pws):
+        if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind in ("down", "convT") or pws):
             # same source split, algorithm and bias mode as the waiting calls (the first recurrent step has no second source yet)?
             if self.w_pend and ((self.w_pend[0][2] is None) != (b is None) or self.w_algo != algo or self.w_bias != bias):
                 self._launch_group()
@@ -735,11 +742,16 @@ class ConvOp:
                 self._launch_group()
             return
         self._slab_layout(algo)
-        self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                                      db=gb, i_total=self.ci, algo=algo, phase=1 if self.w_calls == 0 else 2,
-                                      slabs=self.wslab)
+        self.wslab = ops.conv2d_wgrad(g, a, self.gw, in_b=b, db=gb, algo=algo, phase=1 if self.w_calls == 0 else 2,
+                                      slabs=self.wslab, **self._wg_geo())
         self.w_calls += 1
         self.w_last = (g, a, b, algo)
+
+    def _wg_geo(self):
+        """Geometry keywords of this op's refid_conv2d_wgrad calls (ConvTranspose2d: the 2x2 stride-2 conv of the swapped roles)."""
+        if self.kind == "convT":
+            return dict(kh=2, kw=2, stride=2, pad=0, i_total=self.co)
+        return dict(kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, i_total=self.ci)
 
     def _pws_ok(self, a, b):
         """Mirror of refid_wgrad_pws_ok (csrc/wgrad_pws.hip): does this 1x1 weight gradient take the streaming form?  (Only it
@@ -760,16 +772,15 @@ class ConvOp:
         into the parameter gradient (phase 3 ACCUMULATES into dw) and the slabs start over."""
         if self.w_calls and self.w_last is not None and self.w_last[3] != algo:
             g, a, b, old = self.w_last
-            ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                             db=self.gb, i_total=self.ci, algo=old, phase=3, slabs=self.wslab)
+            ops.conv2d_wgrad(g, a, self.gw, in_b=b, db=self.gb if self.kind != "convT" else None, algo=old, phase=3,
+                             slabs=self.wslab, **self._wg_geo())
             self.w_calls = 0
 
     def _launch_group(self):
         (g, a, b), more = self.w_pend[0], self.w_pend[1:]
         self._slab_layout(self.w_algo)
-        self.wslab = ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                                      db=self.gb if self.w_bias else None, i_total=self.ci, algo=self.w_algo,
-                                      phase=1 if self.w_calls == 0 else 2, slabs=self.wslab, more=more)
+        self.wslab = ops.conv2d_wgrad(g, a, self.gw, in_b=b, db=self.gb if self.w_bias else None, algo=self.w_algo,
+                                      phase=1 if self.w_calls == 0 else 2, slabs=self.wslab, more=more, **self._wg_geo())
         self.w_calls += 1
         self.w_last = (g, a, b, self.w_algo)
         self.w_pend = []
@@ -793,8 +804,8 @@ class ConvOp:
         if self.w_pend:
             self._launch_group()                           # the last, possibly shorter, group
         g, a, b, algo = self.w_last
-        ops.conv2d_wgrad(g, a, self.gw, kh=self.k, kw=self.k, stride=self.stride, pad=self.pad, in_b=b,
-                         db=self.gb, i_total=self.ci, algo=algo, phase=4 if batched else 3, slabs=self.wslab)
+        ops.conv2d_wgrad(g, a, self.gw, in_b=b, db=self.gb if self.kind != "convT" else None, algo=algo,
+                         phase=4 if batched else 3, slabs=self.wslab, **self._wg_geo())
         self.w_calls = 0
         self.w_last = None
 
@@ -1203,9 +1214,7 @@ class Engine:
         x = x.contiguous()
         event = event.contiguous()
         x_in = ops.nchw_to_nhwc(x, _pad4(self.img_chn))
-        ev_in = torch.empty((T * B, H, W, _pad4(self.ev_chn)), dtype=torch.float32, device=dev)
-        for t in range(T):
-            ops.nchw_to_nhwc(event[:, t], _pad4(self.ev_chn), out=ev_in[t * B:(t + 1) * B])
+        ev_in = ops.nchw_to_nhwc_tb(event, _pad4(self.ev_chn))            # time-major: step t = samples t B .. (t+1) B
         head = self.head_img.fwd(x_in, slope_pre=0.2)                      # arch:147-148
         e_all = self.head_ev.fwd(ev_in, slope_pre=0.2)                     # arch:149
         xb, img_saved = [], []
@@ -1275,7 +1284,8 @@ class Engine:
                         L.p_fuse = L.fuse.fwd(L.zero_s, Sb[i])
 
         out = torch.empty((B, T, self.out_chn, H, W), dtype=torch.float32, device=dev)
-        out4 = torch.zeros((B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
+        # pred's NHWC outputs of all T steps (time-major); converted to the (B,T,C,H,W) stack in one launch after the loop
+        out4 = torch.zeros((T * B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
         hf = [None, None, None]
         hd = [None, None, None]
         steps_f = []
@@ -1315,12 +1325,10 @@ class Engine:
                 ds.append(dst)
             if q_pred is not None:                                         # pred(z + head) = pred(z) + q_pred
                 pi = z
-                self.pred.fwd(z, res=q_pred[..., :self.out_chn], out=out4[..., :self.out_chn], bias=False)
+                self.pred.fwd(z, res=q_pred[..., :self.out_chn], out=out4[t * B:(t + 1) * B, ..., :self.out_chn], bias=False)
             else:
                 pi = ops.add(z, head)
-                self.pred.fwd(pi, out=out4[..., :self.out_chn])            # arch:215 (no activation)
-            ops.nhwc_to_nchw(out4[..., :self.out_chn], self.out_chn, out[:, t],
-                             dst_batch_stride=T * self.out_chn * H * W)
+                self.pred.fwd(pi, out=out4[t * B:(t + 1) * B, ..., :self.out_chn])   # arch:215 (no activation)
             if save:
                 steps_f.append(dict(lv=sts, bs=bs, ds=ds, pi=pi))
 
@@ -1349,6 +1357,7 @@ class Engine:
         for s_ in lvs[1:] + ([dstream] if dstream is not None else []):
             if s_ is not main:
                 main.wait_stream(s_)
+        ops.nhwc_to_nchw_tb(out4[..., :self.out_chn], self.out_chn, out)    # arch:218 (torch.stack)
         if save:
             self.ctx = dict(B=B, T=T, H=H, W=W, x_in=x_in, ev_in=ev_in, head=head, e_all=e_all, xb=xb,
                             img_saved=img_saved, ip_b=ip_b, ip_f=ip_f, steps_b=steps_b, steps_f=steps_f, Sb=Sb, lin=lin)
@@ -1393,6 +1402,7 @@ class Engine:
         zeros = lambda t: torch.zeros(t.shape, dtype=torch.float32, device=dev)  # noqa: E731
         lin = c["lin"]
         # pred has no activation (arch:215), so head's share sum_t dgrad(g_t) is dgrad(sum_t g_t): one launch
+        g4_all = ops.nchw_to_nhwc_tb(gout, _pad4(self.out_chn))           # all T steps' output gradients, time-major, one launch
         g4sum = ops.nchw_tsum_to_nhwc(gout, _pad4(self.out_chn))
         g_head = self.pred.dgrad(g4sum)
         # gradients of the image branch's x_blocks: with the linearity split they are assembled once per sweep from the kept
@@ -1407,8 +1417,7 @@ class Engine:
         g_hd = [None, None, None]
         for t in range(T - 1, -1, -1):
             S = c["steps_f"][t]
-            # a fresh buffer per step: pred's weight-gradient kernel reads it on the side stream
-            g4 = ops.nchw_to_nhwc(gout[:, t], _pad4(self.out_chn))
+            g4 = g4_all[t * B:(t + 1) * B]
             self.pred.wgrad(g4, S["pi"])
             g_sd = self.pred.dgrad(g4, res=g_hd[2])           # + decoder 2's state gradient, fused
             g_skip = [None, None, None]

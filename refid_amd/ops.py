@@ -363,6 +363,30 @@ def nchw_to_nhwc(src, c_pad=None, out=None):
     return dst
 
 
+def nchw_to_nhwc_tb(src, c_pad=None):
+    """(B,T,C,H,W) stack with dense (C,H,W) blocks -> (T*B,H,W,c_pad), TIME-major (sample t*B + b), one launch."""
+    b, t, c, h, w = src.shape
+    if src.stride(4) != 1 or src.stride(3) != w or src.stride(2) != h * w:
+        raise _lib.RefidHipError("nchw_to_nhwc_tb: per-(sample, step) (C,H,W) block must be dense")
+    c_pad = c_pad or ((c + 3) // 4) * 4
+    dst = torch.empty((t * b, h, w, c_pad), dtype=torch.float32, device=src.device)
+    check(lib().refid_nchw_to_nhwc_tb(src.data_ptr(), src.stride(0), src.stride(1), dst.data_ptr(), b, t, c, h, w, c_pad,
+                                      _stream()), "refid_nchw_to_nhwc_tb")
+    return dst
+
+
+def nhwc_to_nchw_tb(src, c, dst):
+    """First c channels of the time-major NHWC stack src (T*B,H,W,ld) -> dst (B,T,c,H,W), one launch."""
+    ptr, ld = _nhwc(src, "src")
+    b, t = dst.shape[0], dst.shape[1]
+    n, h, w, _ = src.shape
+    if n != b * t or dst.shape[2:] != (c, h, w) or dst.stride(4) != 1 or dst.stride(3) != w or dst.stride(2) != h * w:
+        raise _lib.RefidHipError("nhwc_to_nchw_tb: dst must be (B,T,c,H,W) with dense (c,H,W) blocks matching src")
+    check(lib().refid_nhwc_to_nchw_tb(ptr, ld, dst.data_ptr(), dst.stride(0), dst.stride(1), b, t, c, h, w, _stream()),
+          "refid_nhwc_to_nchw_tb")
+    return dst
+
+
 def nchw_tsum_to_nhwc(src, c_pad=None):
     """(N,T,C,H,W) contiguous -> sum over T as (N,H,W,c_pad)."""
     n, t, c, h, w = src.shape

@@ -180,6 +180,17 @@ def test_conv_transpose_fwd_and_dgrad(cfg):
     ops.conv2d(nhwc(x.detach()), wp, out, kh=1, kw=1, stride=1, pad=0, mode=1, cout=4 * Co, cout_pad=rp,
                bias=b.float().cuda())
     np.testing.assert_allclose(nchw(out).numpy(), y.detach().numpy(), rtol=RTOL, atol=ATOL)
+    # the same GEMM on the register-operand pointwise tile (algo 3, mode 1): pixel-shuffle store, bias per real channel,
+    # + residual (sample / row / column wrap of the 32-pixel wave tiles: W = 8, 20, 32)
+    wq = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_CONVT, 32, 8, 2, 2, Co, Ci)
+    out3 = torch.full((N, 2 * H, 2 * W, Co), 7.0, device="cuda")
+    ops.conv2d(nhwc(x.detach()), wq, out3, kh=1, kw=1, stride=1, pad=0, mode=1, cout=4 * Co, cout_pad=-(-4 * Co // 32) * 32,
+               bias=b.float().cuda(), algo=3)
+    np.testing.assert_allclose(nchw(out3).numpy(), y.detach().numpy(), rtol=RTOL, atol=ATOL)
+    r = rnd(N, Co, 2 * H, 2 * W, seed=5)
+    ops.conv2d(nhwc(x.detach()), wq, out3, kh=1, kw=1, stride=1, pad=0, mode=1, cout=4 * Co, cout_pad=-(-4 * Co // 32) * 32,
+               bias=b.float().cuda(), res=nhwc(r), slope_post=0.2, algo=3)
+    np.testing.assert_allclose(nchw(out3).numpy(), F.leaky_relu(y.detach() + r, 0.2).numpy(), rtol=RTOL, atol=ATOL)
     wd, rd = _pack_dgrad(ops, w, ops.ROLE_CONVT_DGRAD, 2, 2, 0, Ci, Co)
     dx = torch.empty(N, H, W, Ci, device="cuda")
     ops.conv2d(nhwc(g), wd, dx, kh=2, kw=2, stride=2, pad=0, cout=Ci, cout_pad=rd)
@@ -373,6 +384,16 @@ def test_layout_and_elementwise():
     ops.nhwc_to_nchw(src[..., :3], 3, stack[:, 1], dst_batch_stride=3 * 3 * 8 * 24)
     np.testing.assert_array_equal(stack[:, 1].cpu().numpy(), src[..., :3].permute(0, 3, 1, 2).cpu().numpy())
     assert float(stack[:, 0].abs().max()) == 0.0 and float(stack[:, 2].abs().max()) == 0.0
+    # whole (B,T,C,H,W) stacks in one launch, time-major on the NHWC side (sample t B + b)
+    ev = torch.rand(3, 5, 2, 8, 24, device="cuda")
+    tb = ops.nchw_to_nhwc_tb(ev, 4)
+    assert tb.shape == (15, 8, 24, 4) and float(tb[..., 2:].abs().max()) == 0.0
+    np.testing.assert_array_equal(tb[..., :2].reshape(5, 3, 8, 24, 2).permute(1, 0, 4, 2, 3).cpu().numpy(), ev.cpu().numpy())
+    sl = ops.nchw_to_nhwc_tb(ev[:2], 4)                             # a batch slice: batch stride != T * block
+    np.testing.assert_array_equal(sl.reshape(5, 2, 8, 24, 4).cpu().numpy(), tb.reshape(5, 3, 8, 24, 4)[:, :2].cpu().numpy())
+    back = torch.zeros(3, 5, 2, 8, 24, device="cuda")
+    ops.nhwc_to_nchw_tb(tb[..., :2], 2, back)
+    np.testing.assert_array_equal(back.cpu().numpy(), ev.cpu().numpy())
     a, b = torch.rand(2, 8, 8, 64, device="cuda"), torch.rand(2, 8, 8, 64, device="cuda") - 0.5
     np.testing.assert_array_equal(ops.add(a, b).cpu().numpy(), (a + b).cpu().numpy())
     o = ops.act_bwd(a, b, 0.1)

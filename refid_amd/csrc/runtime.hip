@@ -68,6 +68,44 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     }
 }
 
+// Thin tensors (C <= 4: event voxels 2 -> 4, the 3-channel output and its gradient): the 64-channel LDS transpose above moves
+// 16 bytes per store instruction for them (0.06-0.13 of HBM).  Here a thread owns a PIXEL: C coalesced plane reads, one 16-byte
+// NHWC access (a wave writes 1 KB contiguous) -- and the reverse.  Same sample addressing (time-major form, sum over T).
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ src, long long srcBatchStride,
+                                                           f32x4* __restrict__ dst, int C, int HW, int tCount, long long tStride,
+                                                           int nb) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const long long srcOff = nb > 0 ? (long long)(n % nb) * srcBatchStride + (long long)(n / nb) * tStride
+                                    : (long long)n * srcBatchStride;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= C) break;
+        const float* sp = src + srcOff + (long long)c * HW + p;
+        float acc = 0.f;
+        for (int t = 0; t < tCount; ++t) acc += sp[t * tStride];
+        v[c] = acc;
+    }
+    dst[(long long)n * HW + p] = v;
+}
+
+__global__ __launch_bounds__(256) void nhwc4_to_nchw_kernel(const f32x4* __restrict__ src, float* __restrict__ dst,
+                                                           long long dstBatchStride, int C, int HW, int nb, long long tStride) {
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const long long dstOff = nb > 0 ? (long long)(n % nb) * dstBatchStride + (long long)(n / nb) * tStride
+                                    : (long long)n * dstBatchStride;
+    const f32x4 v = src[(long long)n * HW + p];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c >= C) break;
+        dst[dstOff + (long long)c * HW + p] = v[c];
+    }
+}
+
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld,
                                                           float* __restrict__ dst,
                                                           long long dstBatchStride, int C, int HW, int nb, long long tStride) {
@@ -577,57 +615,65 @@ static int pack_impl(const float* w, const float* oscale, float* packed, int rol
     return 0;
 }
 
+// one launcher for the four NCHW -> NHWC entry points: thin tensors (c_pad == 4, 16-byte aligned dst) take the pixel-per-thread form
+static int launch_to_nhwc(const float* src, long long b_stride, float* dst, int n, int c, int hw, int c_pad, int t_count,
+                          long long t_stride, int nb, hipStream_t st, const char* what) {
+    // a tCount sum in the time-major form would need two time strides: the entry points never combine them
+    if (c_pad == 4 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3(cdiv(hw, 256), n), dim3(256), 0, st, src, b_stride,
+                           reinterpret_cast<f32x4*>(dst), c, hw, t_count, t_stride, nb);
+    } else {
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(hw, 64), n), dim3(256), 0, st, src, b_stride, dst, c, hw, c_pad, t_count,
+                           t_stride, nb);
+    }
+    REFID_LAUNCH_CHECK(what);
+    return 0;
+}
+
 extern "C" int refid_nchw_to_nhwc(const float* src, long long src_batch_stride, float* dst, int n, int c, int h,
                                   int w, int c_pad, void* stream) {
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc: bad arguments");
-    dim3 grid(cdiv(h * w, 64), n);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
-                       h * w, c_pad, 1, 0ll, 0);
-    REFID_LAUNCH_CHECK("nchw_to_nhwc");
-    return 0;
+    return launch_to_nhwc(src, src_batch_stride, dst, n, c, h * w, c_pad, 1, 0ll, 0, (hipStream_t)stream, "nchw_to_nhwc");
 }
 
 extern "C" int refid_nchw_to_nhwc_tb(const float* src, long long b_stride, long long t_stride, float* dst, int nb, int nt,
                                      int c, int h, int w, int c_pad, void* stream) {
     REFID_CHECK(src && dst && nb > 0 && nt > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c, "nchw_to_nhwc_tb: bad arguments");
     REFID_CHECK((long long)nb * nt <= 65535, "nchw_to_nhwc_tb: more than 65535 (sample, step) blocks");
-    dim3 grid(cdiv(h * w, 64), nb * nt);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, b_stride, dst, c, h * w, c_pad, 1,
-                       t_stride, nb);
-    REFID_LAUNCH_CHECK("nchw_to_nhwc_tb");
-    return 0;
+    return launch_to_nhwc(src, b_stride, dst, nb * nt, c, h * w, c_pad, 1, t_stride, nb, (hipStream_t)stream, "nchw_to_nhwc_tb");
 }
 
 extern "C" int refid_nchw_tsum_to_nhwc(const float* src, long long src_batch_stride, long long t_stride, int t_count,
                                        float* dst, int n, int c, int h, int w, int c_pad, void* stream) {
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && c_pad >= c && t_count > 0,
                 "nchw_tsum_to_nhwc: bad arguments");
-    dim3 grid(cdiv(h * w, 64), n);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, src_batch_stride, dst, c,
-                       h * w, c_pad, t_count, t_stride, 0);
-    REFID_LAUNCH_CHECK("nchw_tsum_to_nhwc");
+    return launch_to_nhwc(src, src_batch_stride, dst, n, c, h * w, c_pad, t_count, t_stride, 0, (hipStream_t)stream,
+                          "nchw_tsum_to_nhwc");
+}
+
+static int launch_to_nchw(const float* src, int ld, float* dst, long long b_stride, int n, int c, int hw, int nb,
+                          long long t_stride, hipStream_t st, const char* what) {
+    if (ld == 4 && c <= 4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        hipLaunchKernelGGL(nhwc4_to_nchw_kernel, dim3(cdiv(hw, 256), n), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src), dst,
+                           b_stride, c, hw, nb, t_stride);
+    } else {
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(hw, 64), n), dim3(256), 0, st, src, ld, dst, b_stride, c, hw, nb, t_stride);
+    }
+    REFID_LAUNCH_CHECK(what);
     return 0;
 }
 
 extern "C" int refid_nhwc_to_nchw(const float* src, int ld, float* dst, long long dst_batch_stride, int n,
                                   int c, int h, int w, void* stream) {
     REFID_CHECK(src && dst && n > 0 && c > 0 && h > 0 && w > 0 && ld >= c, "nhwc_to_nchw: bad arguments");
-    dim3 grid(cdiv(h * w, 64), n);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, dst,
-                       dst_batch_stride, c, h * w, 0, 0ll);
-    REFID_LAUNCH_CHECK("nhwc_to_nchw");
-    return 0;
+    return launch_to_nchw(src, ld, dst, dst_batch_stride, n, c, h * w, 0, 0ll, (hipStream_t)stream, "nhwc_to_nchw");
 }
 
 extern "C" int refid_nhwc_to_nchw_tb(const float* src, int ld, float* dst, long long b_stride, long long t_stride, int nb,
                                      int nt, int c, int h, int w, void* stream) {
     REFID_CHECK(src && dst && nb > 0 && nt > 0 && c > 0 && h > 0 && w > 0 && ld >= c, "nhwc_to_nchw_tb: bad arguments");
     REFID_CHECK((long long)nb * nt <= 65535, "nhwc_to_nchw_tb: more than 65535 (sample, step) blocks");
-    dim3 grid(cdiv(h * w, 64), nb * nt);
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, ld, dst, b_stride, c, h * w, nb,
-                       t_stride);
-    REFID_LAUNCH_CHECK("nhwc_to_nchw_tb");
-    return 0;
+    return launch_to_nchw(src, ld, dst, b_stride, nb * nt, c, h * w, nb, t_stride, (hipStream_t)stream, "nhwc_to_nchw_tb");
 }
 
 extern "C" int refid_add(const float* a, const float* b, float* out, long long count, void* stream) {

@@ -6,8 +6,11 @@
 tag=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+# PROFILE_LIGHT=1: the step-level artefacts only (kernel stats, counters, roofline table, bench lines) -- not the tile benches,
+# ablations and the gradient-error report, whose kernels a late change did not touch
+LIGHT=${PROFILE_LIGHT:-0}
 # the ablation libraries must have been built from the current sources (tools/build_probes.sh, CPU container)
-python - <<PY || { echo "profile_round: stale or missing probe libraries -- run tools/build_probes.sh first"; exit 1; }
+[ "$LIGHT" = 1 ] || python - <<PY || { echo "profile_round: stale or missing probe libraries -- run tools/build_probes.sh first"; exit 1; }
 import sys; sys.path.insert(0, "$R/tools/probes")
 import wino6_ablate as a, wgrad_wino_ablate as b
 a.check_fresh(a.lib_path(0)); b.check_fresh(b.lib_path(0))
@@ -39,12 +42,14 @@ python tools/roofline_report.py --stats gpurun_out/${tag}_bench_n1_nooverlap_ker
   --algo gpurun_out/${tag}_algorithmic.json --traffic gpurun_out/${tag}_pmc_traffic.json \
   --sq $(find /tmp/pmc_3 /tmp/pmc_4 -name "*counter_collection.csv") \
   --out gpurun_out/${tag}_roofline_per_kernel.csv --summary gpurun_out/${tag}_pmc_summary.txt > gpurun_out/${tag}_roofline_report.txt 2>&1
+if [ "$LIGHT" != 1 ]; then
 python tools/bench_wino6.py > gpurun_out/${tag}_wino6_tiles_bench.txt 2>&1
 python tools/probes/wino6_ablate.py > gpurun_out/${tag}_wino6_ablation.txt 2>&1
 python tools/probes/w24_ablate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_wgrad_w24_ablation.txt
 python tools/bench_wgrad_wino.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_wgrad_tiles_bench.txt
 tools/probes/bin/wino6_loop > gpurun_out/${tag}_wino6_loop_probe.txt 2>&1
 python tools/grad_error_report.py > gpurun_out/${tag}_grad_error_report.txt 2>&1
+fi
 for d in fp32 bf16x3 bf16; do python bench.py --dtype $d --steps 5 --warmup 2 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_$d.json; done
 # GPU busy fraction without a tracer in the timed run: serial kernel time (traced durations) / untraced single-stream step
 REFID_OVERLAP_WGRAD=0 REFID_PIPELINE=0 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_n1_single_stream_untraced.json

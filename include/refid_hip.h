@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -116,7 +116,12 @@ typedef struct refid_conv_desc {
                                                    kc = 8) -- and mode 1, ConvTranspose2d(2,2) as the 1x1
                                                    GEMM over its 4 Co columns with a pixel-shuffle store
                                                    (REFID_ROLE_CONVT packing, kc = 8, bn = 32; bias / res /
-                                                   slopes only; Co a multiple of 4, 4 Co > 32);
+                                                   slopes only; Co a multiple of 4, 4 Co > 32) -- and the 2x2
+                                                   stride-2 conv (ConvTranspose2d's input gradient: non-
+                                                   overlapping patches) as one GEMM with K = 4 c_a: a pixel's
+                                                   patch is two contiguous runs of 2 c_a floats (dense pixels:
+                                                   ld_a == c_a, one source; REFID_ROLE_CONVT_DGRAD_PW packing;
+                                                   out2 / add2 supported);
                                                    2 = direct tile with bf16 MFMA operands (fp32
                                                    accumulate/epilogue/tensors; w_packed from
                                                    refid_pack_conv_weights_bf16 with kc doubled);
@@ -270,7 +275,10 @@ int refid_wgrad_finish_flush(void* stream);
 enum { REFID_ROLE_FWD = 0, REFID_ROLE_DGRAD = 1, REFID_ROLE_CONVT = 2, REFID_ROLE_CONVT_DGRAD = 3,
        REFID_ROLE_DOWN_DGRAD = 4,
        /* Winograd-domain weights U = G g G^T, 16 "taps" (algo 1; kc = 8): */
-       REFID_ROLE_WINO_FWD = 5, REFID_ROLE_WINO_DGRAD = 6 };
+       REFID_ROLE_WINO_FWD = 5, REFID_ROLE_WINO_DGRAD = 6,
+       /* ConvTranspose2d(2,2) input gradient as ONE GEMM over 2x2 patches (refid_conv2d algo 3 on a 2x2 stride-2 conv): rows = Ci,
+          k = (dy, dx, co) = 4 Co columns, one "tap"; kc = 8, bn = 32: */
+       REFID_ROLE_CONVT_DGRAD_PW = 7 };
 size_t refid_packed_weight_floats(int role, int o, int i, int kh, int kw, int kc, int bn);
 int refid_pack_conv_weights(const float* w, float* packed, int role, int o, int i, int kh, int kw,
                             int kc, int bn, void* stream);

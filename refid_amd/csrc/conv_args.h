@@ -26,6 +26,9 @@ struct ConvKArgs {
     // pointwise tile only: ConvTranspose2d(2,2) forward (refid_conv_desc.mode 1) -- GEMM column j = (q, co) of pixel (n, y, x)
     // is channel co of output pixel (n, 2y + q/2, 2x + q%2); Cout = 4 Co; the bias has Co entries
     int shuffle = 0;
+    // pointwise tile only, patch form (a 2x2 stride-2 conv as one GEMM): source pixel p sits at
+    // (p / patchW) * patchRow + (p % patchW) * ld floats instead of p * ld (both sources); 0 = dense
+    int patchW = 0, patchRow = 0;
 };
 
 

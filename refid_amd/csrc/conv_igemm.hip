@@ -474,7 +474,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
                 "conv2d: empty problem (n=%d h=%d w=%d ho=%d wo=%d cout=%d)", d->n, d->h, d->w, d->ho,
                 d->wo, d->cout);
     REFID_CHECK(d->pw == nullptr || d->algo == 3, "conv2d: pw fusions belong to the pointwise tile (algo 3)");
-    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 5) && f == F_3x3) || (d->algo == 3 && (f == F_1x1 || f == F_convT)) ||
+    REFID_CHECK(d->algo == 0 || d->algo == 2 || ((d->algo == 1 || d->algo == 5) && f == F_3x3) || (d->algo == 3 && (f == F_1x1 || f == F_convT || f == F_2x2s2)) ||
                     (d->algo == 4 && (f == F_3x3 || f == F_4x4s2 || f == F_downDgrad)),
                 "conv2d: algo %d does not fit this geometry (1 / 5 = 3x3 stride 1, 3 = 1x1 and ConvTranspose2d(2,2), 4 = 3x3 stride 1 / 4x4 stride 2 and "
                 "its input gradient)", d->algo);
@@ -503,8 +503,8 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
     a.maskMode = d->mask_mode;
     REFID_CHECK(d->mask_mode == 0 || (d->mask_mode == 1 && d->algo == 3 && d->mask != nullptr),
                 "conv2d: mask_mode 1 (GELU derivative) belongs to the pointwise tile (algo 3) and needs a mask tensor");
-    REFID_CHECK(d->out2 == nullptr || (d->add2 != nullptr && d->algo != 3),
-                "conv2d: out2 needs add2 and is not implemented by the pointwise tile (algo 3)");
+    REFID_CHECK(d->out2 == nullptr || (d->add2 != nullptr && (d->algo != 3 || d->pw == nullptr)),
+                "conv2d: out2 needs add2 (and, on the pointwise tile, no fusions)");
     a.N = d->n; a.H = d->h; a.W = d->w; a.Ho = d->ho; a.Wo = d->wo;
     a.Cout = d->cout; a.CoutPad = d->cout_pad; a.coBase = d->co_base;
     a.pad = d->pad; a.nchunks = 0; a.tilesX = a.tilesY = 0;
@@ -522,6 +522,21 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         a.shuffle = (d->mode == 1) ? 1 : 0;                 // ConvTranspose2d(2,2) as a 1x1 GEMM over 4 Co columns + pixel shuffle
         REFID_CHECK(!a.shuffle || (d->pw == nullptr && d->mask == nullptr && d->out2 == nullptr && d->co_base == 0),
                     "conv2d: ConvTranspose2d on the pointwise tile takes no mask / second output / fusions / row range");
+        if (f == F_2x2s2) {
+            // non-overlapping 2x2 patches: output pixel (n, y, x) reads rows 2y and 2y+1, pixels 2x and 2x+1 -- two contiguous
+            // runs of 2 c_a floats when pixels are dense: a two-source 1x1 GEMM with K = 4 c_a over row-pitched sources
+            REFID_CHECK(d->c_b == 0 && d->ld_a == d->c_a && d->pad == 0 && d->h == 2 * d->ho && d->w == 2 * d->wo && d->pw == nullptr &&
+                            (2 * d->c_a) % 8 == 0,
+                        "conv2d: the 2x2 stride-2 patch GEMM (algo 3) needs one source with dense pixels (ld_a == c_a), pad 0, "
+                        "even input sizes and c_a %% 4 == 0");
+            a.inB = d->in_a + (long long)d->w * d->ld_a;       // the odd rows
+            a.ldA = a.ldB = 2 * d->ld_a;
+            a.Ca = 2 * d->c_a; a.Ctot = 4 * d->c_a;
+            a.patchW = d->wo; a.patchRow = 2 * d->w * d->ld_a;
+            a.H = d->ho; a.W = d->wo;                          // the GEMM's pixels
+            REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < 0x7fffffffLL, "conv2d: tensor too large for the pointwise tile's 32-bit offsets");
+            return refid_launch_pointwise(a, st, nullptr, 0);
+        }
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: pointwise tile needs c_a %% 8 == 0 for two sources");
         const long long lim = 0x7fffffffLL;
         REFID_CHECK((long long)d->n * d->h * d->w * d->ld_a * 4 < lim &&

@@ -82,17 +82,21 @@ __global__ __launch_bounds__(256, (SIX || NT > 2) ? 3 : 4) void conv_pw_kernel(c
     const long long p = p0 + li;
     const int n0 = blockIdx.y * (32 * NT);
 
+    // (patch form: the sources are the even / odd rows of one tensor of npix / patchW row pairs; live lanes stay inside it)
+    const long long spanA = a.patchW ? (npix / a.patchW) * (long long)a.patchRow : npix * a.ldA;
+    const long long spanB = a.patchW ? spanA - a.patchRow / 2 : npix * (a.inB ? a.ldB : a.ldA);
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.inA), 0, (int)min(npix * a.ldA * 4, 0x7fffffffLL), 0x00020000);
+        const_cast<float*>(a.inA), 0, (int)min(spanA * 4, 0x7fffffffLL), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.inB ? a.inB : a.inA), 0, (int)min(npix * (a.inB ? a.ldB : a.ldA) * 4, 0x7fffffffLL),
-        0x00020000);
+        const_cast<float*>(a.inB ? a.inB : a.inA), 0, (int)min(spanB * 4, 0x7fffffffLL), 0x00020000);
     // (SIX: [chunk16][plane][row][16] bf16 = 3 x 32 bytes per row and 16 channels -- 1.5x the fp32 bytes)
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * a.CoutPad * KC * (SIX ? 6 : 4), 0x7fffffffLL), 0x00020000);
     const bool pok = p < npix;
-    const int voA = pok ? (int)(p * a.ldA * 4) + kh * 16 : OOB;
-    const int voB = pok ? (int)(p * a.ldB * 4) + kh * 16 : OOB;
+    const long long pA = a.patchW ? (p / a.patchW) * a.patchRow + (p % a.patchW) * a.ldA : p * a.ldA;      // floats
+    const long long pB = a.patchW ? (p / a.patchW) * a.patchRow + (p % a.patchW) * a.ldB : p * a.ldB;
+    const int voA = pok ? (int)(pA * 4) + kh * 16 : OOB;
+    const int voB = pok ? (int)(pB * 4) + kh * 16 : OOB;
     int voW[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -334,6 +338,8 @@ __global__ __launch_bounds__(256, (SIX || NT > 2) ? 3 : 4) void conv_pw_kernel(c
                     }
                 }
                 *reinterpret_cast<f32x4*>(a.out + pp * a.ldO + j0) = v;
+                if (a.out2)                                  // (workgroup-uniform) the skip sum leaves with the tile
+                    *reinterpret_cast<f32x4*>(a.out2 + pp * a.ldO2 + j0) = v + *reinterpret_cast<const f32x4*>(a.add2 + pp * a.ldA2 + j0);
                 if constexpr (EX) {
                     if (e.out2) {
                         f32x4 gl;
@@ -379,6 +385,8 @@ int refid_launch_pointwise(const ConvKArgs& ka, hipStream_t st, const PwExtra* e
                                npix < 0x7fffffffLL),
                 "conv2d: ConvTranspose2d on the pointwise tile needs 16-byte aligned tensors, fp32 products, no mask / fusions and "
                 "at least 16 output channels");
+    REFID_CHECK(a.out2 == nullptr || (a.vecOK && ex == nullptr), "conv2d: the pointwise tile's second output needs 16-byte aligned tensors and no fusions");
+    REFID_CHECK(!a.patchW || (terms == 0 && ex == nullptr && a.inB != nullptr), "conv2d: the patch form of the pointwise tile has fp32 products, no fusions");
     REFID_CHECK(terms == 0 || terms == 6, "conv2d: the pointwise tile has fp32 products (0) or six bf16 products (6), got %d", terms);
     REFID_CHECK(!six || (a.Ctot % 16 == 0 && (a.inB == nullptr || a.Ca % 16 == 0) && a.Cout > 32),
                 "conv2d: the six-product pointwise tile needs channel counts that are multiples of 16 and more than 32 outputs");

@@ -183,6 +183,8 @@ __device__ __forceinline__ float pack_fetch(const PackArgs& p, int cls, int tap,
         }
         case REFID_ROLE_CONVT_DGRAD:    // rows = ci, k = co, tap = dy*2+dx
             return p.w[((long long)row * p.O + k) * 4 + tap];
+        case REFID_ROLE_CONVT_DGRAD_PW: // rows = ci, k = (dy, dx, co): the patch GEMM of the pointwise tile
+            return p.w[((long long)row * p.O + k % p.O) * 4 + k / p.O];
         case REFID_ROLE_WINO_FWD:       // U[xi=(i,j)] = sum_ab G[i][a] G[j][b] g[a][b]
         case REFID_ROLE_WINO_DGRAD: {
             const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
@@ -400,6 +402,7 @@ int pack_geometry(int role, int o, int i, int kh, int kw, int kc, int bn, PackAr
         case REFID_ROLE_DGRAD: p->rows = i; p->K = o; p->ntaps = kh * kw; break;
         case REFID_ROLE_CONVT: p->rows = 4 * o; p->K = i; p->ntaps = 1; break;
         case REFID_ROLE_CONVT_DGRAD: p->rows = i; p->K = o; p->ntaps = 4; break;
+        case REFID_ROLE_CONVT_DGRAD_PW: p->rows = i; p->K = 4 * o; p->ntaps = 1; break;
         case REFID_ROLE_DOWN_DGRAD: p->rows = i; p->K = o; p->ntaps = 4; p->ncls = 4; break;
         case REFID_ROLE_WINO_FWD: p->rows = o; p->K = i; p->ntaps = 16; break;
         case REFID_ROLE_WINO_DGRAD: p->rows = i; p->K = o; p->ntaps = 16; break;
@@ -531,7 +534,7 @@ extern "C" int refid_pack_entry_fill(void* entry_host, int kind, const float* w,
         // the same conditions as refid_pack_conv_weights / _scaled / _bf16 (pack_impl)
         REFID_FILL_CHECK(planes == 0 || planes == 1, "pack_entry_fill: kind 0 takes planes = 0 (fp32) or 1 (bf16), got %d", planes);
         REFID_FILL_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
-        REFID_FILL_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),
+        REFID_FILL_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD && role != REFID_ROLE_CONVT_DGRAD_PW) || (kh == 2 && kw == 2),
                          "pack_entry_fill: convT roles need a 2x2 kernel");
         REFID_FILL_CHECK(role != REFID_ROLE_DOWN_DGRAD || (kh == 4 && kw == 4), "pack_entry_fill: down-dgrad needs a 4x4 kernel");
         const bool wino = role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD;
@@ -603,7 +606,7 @@ static int pack_impl(const float* w, const float* oscale, float* packed, int rol
     p.bf16 = 0;
     REFID_CHECK(w && packed, "pack: null pointer");
     REFID_CHECK(pack_geometry(role, o, i, kh, kw, kc, bn, &p) == 0, "pack: unknown role %d", role);
-    REFID_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD) || (kh == 2 && kw == 2),
+    REFID_CHECK((role != REFID_ROLE_CONVT && role != REFID_ROLE_CONVT_DGRAD && role != REFID_ROLE_CONVT_DGRAD_PW) || (kh == 2 && kw == 2),
                 "pack: convT roles need a 2x2 kernel");
     REFID_CHECK(role != REFID_ROLE_DOWN_DGRAD || (kh == 4 && kw == 4), "pack: down-dgrad needs a 4x4 kernel");
     REFID_CHECK((role != REFID_ROLE_WINO_FWD && role != REFID_ROLE_WINO_DGRAD) || (kh == 3 && kw == 3 && kc == 8),

@@ -398,6 +398,10 @@ class ConvOp:
             self.d_bn = ops.conv_bn(kh, kw, st, md, self.d_rows if self.d_rows <= 128 else 128)
             if kind == "conv" and self.ci == 2 * self.co and self.k in (1, 3):
                 self.d_bn = ops.conv_bn(kh, kw, st, md, self.co)     # issued as two halves of co rows
+            if kind == "convT" and self.f_algo == 3 and (2 * self.co) % 8 == 0:
+                # its input gradient (2x2 stride 2: non-overlapping patches) as ONE GEMM with K = 4 Co on the pointwise tile: a
+                # pixel's patch is two contiguous runs of 2 Co floats (the direct tile fetched 3.3-4.4x its bytes, 0.29 of HBM)
+                self.d_algo, self.d_role = 3, ops.ROLE_CONVT_DGRAD_PW
             if self.d_algo == 1:
                 self.d_kc, self.d_bn = 8, 64
             if self.d_algo == 3:
@@ -671,7 +675,10 @@ class ConvOp:
                        res=res, mask=mask, slope_mask=slope_mask, algo=3, terms=6)
             return out if plus is None else (out, ops.add(out, plus, out=o2))
         fused_two = bool(two)                                    # was the second output handed to the tile?
-        if self.d_algo == 3:                                      # (the pointwise tile has no second output)
+        if self.d_algo == 3 and self.kind == "convT":            # the patch GEMM: dense pixels; second output supported
+            if g.stride(2) != g.shape[3]:
+                g = g.contiguous()
+        elif self.d_algo == 3:                                    # (the 1x1 layers keep their separate skip-sum launch)
             two, fused_two = {}, False
             if gelu_mask:
                 two = dict(mask_mode=1)

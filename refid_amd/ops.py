@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, WgradDesc, check, lib
 
-ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_FWD, ROLE_WINO_DGRAD = range(7)
+ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_FWD, ROLE_WINO_DGRAD, ROLE_CONVT_DGRAD_PW = range(8)
 
 
 # split-K policy for small grids (refid_conv_desc.split_k): REFID_SPLITK = auto (default: by total grid size) |

@@ -195,6 +195,18 @@ def test_conv_transpose_fwd_and_dgrad(cfg):
     dx = torch.empty(N, H, W, Ci, device="cuda")
     ops.conv2d(nhwc(g), wd, dx, kh=2, kw=2, stride=2, pad=0, cout=Ci, cout_pad=rd)
     np.testing.assert_allclose(nchw(dx).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+    # the same input gradient as ONE patch GEMM (K = 4 Co) on the pointwise tile, with a mask and a second output
+    wq = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_CONVT_DGRAD_PW, 32, 8, 2, 2, Co, Ci)
+    dx3 = torch.full((N, H, W, Ci), 7.0, device="cuda")
+    ops.conv2d(nhwc(g), wq, dx3, kh=2, kw=2, stride=2, pad=0, cout=Ci, cout_pad=-(-Ci // 32) * 32, algo=3)
+    np.testing.assert_allclose(nchw(dx3).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
+    m, plus = rnd(N, Ci, H, W, seed=6), rnd(N, Ci, H, W, seed=7)
+    o2 = torch.empty_like(dx3)
+    ops.conv2d(nhwc(g), wq, dx3, kh=2, kw=2, stride=2, pad=0, cout=Ci, cout_pad=-(-Ci // 32) * 32, algo=3, mask=nhwc(m),
+               slope_mask=0.1, add2=nhwc(plus), out2=o2)
+    want = x.grad * torch.where(m > 0, 1.0, 0.1)
+    np.testing.assert_allclose(nchw(dx3).numpy(), want.numpy(), rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(nchw(o2).numpy(), (want + plus).numpy(), rtol=RTOL, atol=ATOL)
 
 
 @pytest.mark.parametrize("cfg", [

@@ -133,8 +133,8 @@ typedef struct refid_conv_desc {
                                                    rounding (see `mfma_terms`);
                                                    5 = Winograd F(2x2,3x3) with the transform-domain products on the bf16
                                                    matrix cores, six bf16 MFMAs per fp32 product on exactly split
-                                                   operands (3x3, stride 1, mode 0, at least 8 output channels -- a 64-channel
-                                                   workgroup tile above 32, a 32-channel one up to 32 --, two
+                                                   operands (3x3, stride 1, mode 0; a 64-channel workgroup tile above 32 output
+                                                   channels, a 32-channel one up to 32, thin outputs included --, two
                                                    sources: c_a a multiple of 16; w_packed from
                                                    refid_pack_conv_weights_wino6): the fp32 Winograd tile's result to
                                                    fp32 rounding at 2.67x fewer matrix-pipe cycles            */

@@ -427,7 +427,9 @@ int launch_wino6(const ConvKArgs& a, dim3 grid, hipStream_t st, const char* what
 
 bool refid_wino6_eligible(const ConvKArgs& a) {
     const long long lim = 0x7fffffffLL;
-    return a.Cout >= 8 && a.Ctot % 4 == 0 && (a.inB == nullptr || a.Ca % KC == 0) &&
+    // (thin outputs -- pred's 3 channels -- ride the 32-channel form: its MFMAs are cheap, the direct fp32 tile that padded them
+    //  to 32 columns was bound by the fp32 matrix pipe at 100 us per launch)
+    return a.Cout >= 1 && a.Ctot % 4 == 0 && (a.inB == nullptr || a.Ca % KC == 0) &&
            (long long)a.N * a.H * a.W * a.ldA * 4 < lim && (!a.inB || (long long)a.N * a.H * a.W * a.ldB * 4 < lim) &&
            (long long)cdiv(a.Ctot, KC) * 16 * 3 * a.CoutPad * KC * 2 < lim;
 }
@@ -445,7 +447,7 @@ size_t refid_wino6_workspace_bytes(const ConvKArgs& ka, int split_mode) {
 int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
     ConvKArgs a = ka;
     REFID_CHECK(refid_wino6_eligible(a),
-                "conv2d: the Winograd six-product tile needs at least 8 output channels, channel counts that are multiples "
+                "conv2d: the Winograd six-product tile needs input-channel counts that are multiples "
                 "of 4 (two sources: c_a a multiple of 16) and tensors below 2 GiB");
     // Wide tile (experimental/conv_wino6w.hip: 8x32 pixels, 8 waves, weight fragments shared through an LDS ring, same
     // bits): measured 0-10 % slower, only in libraries built with REFID_EXPERIMENTAL_TILES=1 and only on request

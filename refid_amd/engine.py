@@ -235,6 +235,7 @@ MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
 # 2.67x fewer matrix-pipe cycles.  0 = fp32 Winograd tile everywhere.
 WINO6 = os.environ.get("REFID_WINO6", "1") != "0"
 WINO6_MIN_CO = int(os.environ.get("REFID_WINO6_MIN_CO", "32"))
+WINO6_THIN = os.environ.get("REFID_WINO6_THIN", "1") != "0"        # pred's forward (32 -> 3) on the 32-channel Winograd x six form
 # conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
 # fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
 # split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
@@ -423,7 +424,10 @@ class ConvOp:
         # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T.  From 32 output channels
         # on (round 4: the tile's 32-channel form; REFID_WINO6_MIN_CO=33 restores round 3's choice for an A/B)
         self.wp6 = self.wd6 = None
-        if WINO6 and not bf16 and self.f_algo == 1 and self.co >= WINO6_MIN_CO and self.ci % 4 == 0 and \
+        # ... and thin outputs (pred, 32 -> 3): the direct fp32 tile pads them to 32 GEMM columns and is bound by the fp32
+        # matrix pipe (100 us per launch at B=8); on the 32-channel Winograd x six form the padding costs cheap bf16 MFMAs
+        thin6 = WINO6_THIN and kind == "conv" and k == 3 and self.co <= 4 and self.ci % 16 == 0 and USE_WINOGRAD
+        if WINO6 and not bf16 and ((self.f_algo == 1 and self.co >= WINO6_MIN_CO) or thin6) and self.ci % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) < 2 ** 31 - 1:
             self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) // 2,
                                    dtype=torch.bfloat16, device=dev)
@@ -594,7 +598,7 @@ class ConvOp:
                        bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=4, terms=self.split, **two)
             return out if plus is None else (out, o2)
         if self.wp6 is not None and self.split == 0 and (b is None or a.shape[3] % 16 == 0):
-            ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
+            ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=-(-self.f_rows // 64) * 64, in_b=b,
                        bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5, **two)
             return out if plus is None else (out, o2)
         if self.wpp6 is not None and a.shape[3] % 16 == 0 and (b is None or b.shape[3] % 16 == 0):
@@ -657,7 +661,7 @@ class ConvOp:
             pad = self.k - 1 - self.pad
         # GELU' rides only in the fp32 pointwise tile (refid_conv_desc.mask_mode = 1); every other tile would silently apply
         # the leaky-step mask instead, so a request that cannot be honoured is an error, never a wrong gradient
-        gelu_ok = self.d_algo == 3 and self.wds is None and not (self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO) \
+        gelu_ok = self.kind == "conv" and self.d_algo == 3 and self.wds is None and not (self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO) \
             and not (self.wdp6 is not None and cnt > 32 and g.shape[3] % 16 == 0)
         if gelu_mask and not gelu_ok:
             raise RefidHipError(f"{self.name}: gelu_mask needs the fp32 pointwise input-gradient tile (d_algo {self.d_algo}); "

@@ -486,6 +486,8 @@ def test_winograd_fused_epilogues():
     # the 32-output-channel form (round 4: one column tile per wave, three workgroups per CU): decoder 2's trunk shapes,
     # ragged sizes, a partial channel tile (24, 12 of 32), two sources, a split-K grid (256 -> 32 at 8x8)
     (2, 16, 32, 32, 0, 32), (1, 24, 40, 32, 32, 32), (1, 7, 33, 64, 0, 24), (1, 5, 3, 36, 0, 12), (1, 8, 8, 256, 0, 32),
+    # thin outputs (pred: 32 -> 3, written into a 4-channel buffer), one and four channels
+    (1, 16, 32, 32, 0, 3), (2, 9, 17, 32, 0, 3), (1, 8, 32, 16, 0, 1), (1, 8, 32, 32, 0, 4),
 ])
 @pytest.mark.parametrize("tile", [1, 3])
 def test_wino6_forward_geometries(cfg, tile):
@@ -601,11 +603,6 @@ def test_wino6_accuracy_class_and_tiny_gradients():
 def test_wino6_rejects_bad_arguments():
     ops = _ops()
     from refid_amd._lib import RefidHipError
-    x = torch.randn(1, 8, 32, 64, device="cuda")
-    w = torch.randn(4, 64, 3, 3, device="cuda")
-    with pytest.raises(RefidHipError, match="at least 8 output channels"):
-        ops.conv2d(x, ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, 4, 64), torch.empty(1, 8, 32, 4, device="cuda"),
-                   kh=3, kw=3, pad=1, cout=4, cout_pad=64, algo=5)
     w = torch.randn(64, 48, 3, 3, device="cuda")
     xa, xb = torch.randn(1, 8, 32, 24, device="cuda"), torch.randn(1, 8, 32, 24, device="cuda")
     with pytest.raises(RefidHipError, match="multiple of 16"):

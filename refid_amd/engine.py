@@ -248,13 +248,13 @@ DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
 PW6 = os.environ.get("REFID_PW6", "0") == "1"
 # smallest output-channel count whose 3x3 weight gradient goes to the Winograd tile (64 x 32 channel tiles)
 WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
-# (round 4: the ABI takes up to 24 steps per launch.  All T steps of a sweep in ONE launch write the partial-sum slabs once
-#  instead of read-modify-writing them per group -- measured: B=8 460.5 vs 458.3 ms, B=1 109.3 vs 106.0 ms at 24 vs 8 steps: the
-#  later start of the weight-gradient kernels costs more overlap than the slab passes save.  8 stays -- for large batches.
-#  Round 5: small batches run their weight gradients on the MAIN stream (overlap_wgrad()), where a launch is a link of the
-#  dependent chain: there 24 steps per launch win (B=1: 99.6 -> 98.0 ms on a fast host, 107.8 -> 96.0 on a slow one).)
+# Time steps per weight-gradient launch (the ABI takes up to 24): all T steps of a sweep in ONE launch write the partial-sum slabs
+# once instead of read-modify-writing them per group.  Round 4 (weight gradients on a side stream): 8, because a later start of
+# the weight-gradient kernels cost more overlap than the slab passes saved (B=8 460.5 vs 458.3 ms at 24 vs 8).  Round 5: the
+# weight gradients run on the MAIN stream at every batch size, a launch is a link of the one chain, and 24 wins everywhere:
+# B=8 400.2 / 399.9 vs 404.9 / 403.5 ms (alternating, one box; 12 steps: 405.0 / 402.8), B=1 99.6 -> 98.0 ms.
 _WG_ENV = os.environ.get("REFID_WGRAD_GROUP")
-WGRAD_GROUP = max(1, min(24, int(_WG_ENV))) if _WG_ENV else 8
+WGRAD_GROUP = max(1, min(24, int(_WG_ENV))) if _WG_ENV else (24 if os.environ.get("REFID_OVERLAP_WGRAD", "0") == "0" else 8)
 WGRAD_GROUP_SMALL = max(1, min(24, int(_WG_ENV))) if _WG_ENV else 24
 # Experiment (REFID_EXPERIMENTAL_TILES builds only): Winograd weight gradient with six exact-split bf16 products per fp32
 # product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands

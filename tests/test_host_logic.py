@@ -367,3 +367,57 @@ def test_every_shipped_yaml_of_the_reference_parses_and_builds(monkeypatch):
             assert 0 < lr <= model.base_lr
         else:
             assert not hasattr(model, "exp_avg") and opt["val"].get("max_minibatch", 1) >= 1
+
+
+def test_batched_finish_always_flushes_and_fallback_packs_stay_out_of_the_plan(monkeypatch):
+    """Host logic of two round-5 changes, no GPU: (1) engine.finish_wgrads queues every op's element-wise reduction stage
+    (phase 4) and ALWAYS ends with refid_wgrad_finish_flush -- also when an op fails, so nothing stays queued in the library;
+    with the side-stream switch on it falls back to per-op launches.  (2) The fp32 Winograd packings of convs that run on their
+    Winograd x six planes are not in the per-step pack plan (packed on demand), everything else is."""
+    from refid_amd import engine, ops
+    calls = []
+    monkeypatch.setattr(ops, "wgrad_finish_flush", lambda: calls.append("flush"))
+
+    class Op:
+        def __init__(self, fail=False):
+            self.fail = fail
+
+        def finish_wgrad(self, batched=False):
+            calls.append(("finish", batched))
+            if self.fail:
+                raise RuntimeError("boom")
+
+    monkeypatch.setattr(engine, "FINISH_BATCH", True)
+    monkeypatch.setattr(engine, "OVERLAP_WGRAD", 0)
+    engine.finish_wgrads([Op(), Op()])
+    assert calls == [("finish", True), ("finish", True), "flush"]
+    calls.clear()
+    with pytest.raises(RuntimeError):
+        engine.finish_wgrads([Op(), Op(fail=True), Op()])
+    assert calls == [("finish", True), ("finish", True), "flush"]
+    calls.clear()
+    monkeypatch.setattr(engine, "FINISH_BATCH", False)
+    engine.finish_wgrads([Op()])
+    assert calls == [("finish", False)]
+
+    planned = []
+    monkeypatch.setattr(ops.PackPlan, "build", lambda self: planned.extend(self.items) or self)
+    monkeypatch.setattr(ops.PackPlan, "run", lambda self: None)
+    monkeypatch.setattr(ops, "add", lambda a, b, out=None: out)
+    eng = engine.Engine(26, device="cpu")
+    eng.repack()
+    lazy = [o for o in eng.all_ops if o.wp_lazy or o.wd_lazy]
+    assert len(lazy) >= 40 and eng.arena.pack_epoch == 1
+    dsts = {it[3].data_ptr() for it in planned}
+    for o in eng.all_ops:
+        assert (o.wp.data_ptr() in dsts) == (not o.wp_lazy), o.name
+        if o.wd is not None:
+            assert (o.wd.data_ptr() in dsts) == (not o.wd_lazy), o.name
+        for nm in ("wp6", "wd6", "wps", "wds"):
+            t = getattr(o, nm)
+            assert t is None or t.data_ptr() in dsts, (o.name, nm)
+    # ConvTranspose2d ops: pointwise-tile GEMMs both ways, weight gradient with the swapped-role 2x2 stride-2 geometry
+    t2 = eng.dec[0]["t2"]
+    assert t2.kind == "convT" and t2.f_algo == 3 and t2.d_algo == 3 and t2.d_role == ops.ROLE_CONVT_DGRAD_PW
+    assert t2._wg_geo() == dict(kh=2, kw=2, stride=2, pad=0, i_total=t2.co)
+    assert eng.pred.wp6 is not None and eng.pred.f_algo == 0 and not eng.pred.wp_lazy      # thin output on the Winograd x six form

@@ -414,7 +414,7 @@ class ConvOp:
                                   dtype=pdt, device=dev)
         # pointwise tile, six bf16 products per fp32 product: second packing (three bf16 planes, 16-channel chunks)
         self.wpp6 = self.wdp6 = None
-        if PW6 and self.f_algo == 3 and self.ci % 16 == 0 and self.co % 16 == 0:
+        if PW6 and self.kind == "conv" and self.f_algo == 3 and self.ci % 16 == 0 and self.co % 16 == 0:
             if self.co > 32:
                 self.wpp6 = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, 3) // 2,
                                         dtype=torch.bfloat16, device=dev)

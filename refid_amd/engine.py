@@ -245,7 +245,10 @@ DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
 # operands, NO gain inside the train step (676 launches: 39.8 vs 39.2 ms; the squeeze-excite fused conv3 is slower, 116
 # vs 90 us) -- on cold operands these tiles wait for HBM, not for the matrix pipe, and the six-product form runs 3 instead of
 # 4 waves per SIMD (144 registers).  Off; the form stays reachable through the C ABI and is tested.
-PW6 = os.environ.get("REFID_PW6", "0") == "1"
+# six bf16 products on the pointwise tile: "1" every 1x1 layer (round 3: flat in the step), "2" only where the reduction runs over
+# 128 channels or more (those layers are bound by the fp32 matrix pipe), "0" never
+PW6 = int(os.environ.get("REFID_PW6", "0") or 0)
+PW6_MIN_K = 128
 # smallest output-channel count whose 3x3 weight gradient goes to the Winograd tile (64 x 32 channel tiles)
 WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
 # Time steps per weight-gradient launch (the ABI takes up to 24): all T steps of a sweep in ONE launch write the partial-sum slabs
@@ -415,10 +418,10 @@ class ConvOp:
         # pointwise tile, six bf16 products per fp32 product: second packing (three bf16 planes, 16-channel chunks)
         self.wpp6 = self.wdp6 = None
         if PW6 and self.kind == "conv" and self.f_algo == 3 and self.ci % 16 == 0 and self.co % 16 == 0:
-            if self.co > 32:
+            if self.co > 32 and (PW6 == 1 or self.ci >= PW6_MIN_K):
                 self.wpp6 = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, 32, 1, 1, self.co, self.ci, 3) // 2,
                                         dtype=torch.bfloat16, device=dev)
-            if need_dgrad and self.ci > 32:
+            if need_dgrad and self.ci > 32 and (PW6 == 1 or self.co >= PW6_MIN_K):
                 self.wdp6 = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, 3) // 2,
                                         dtype=torch.bfloat16, device=dev)
         # Winograd x six bf16 products (algo 5): third packing -- three bf16 planes of U = G g G^T.  From 32 output channels

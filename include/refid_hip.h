@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -231,6 +231,12 @@ typedef struct refid_wgrad_desc {
                                                    parity phases of the input (a stride-2 conv is four 2x2-tap stride-1 convs on
                                                    them): 12 instead of 16 fp32 MFMA-units per output pixel; slabs
                                                    [split][phase][24][o][i];
+                                                   8 = the 2x2 stride-2 pad-0 weight gradient over NON-overlapping patches
+                                                   (ConvTranspose2d(2,2) with the roles swapped, see above) as one streaming 1x1
+                                                   weight gradient (wgrad_pws.hip): K = (dy, dx, c) over the even / odd rows of
+                                                   the source, which must have dense pixels (ld_a == c_a; one source, no db,
+                                                   c_o >= 64 and a multiple of 32, c_a a multiple of 16, wo a multiple of 32);
+                                                   the reduction permutes the columns into dw's [o][c][dy][dx] layout;
                                                    6 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured no faster
                                                    than algo 1): Winograd F(3x3,4x4), 36 MFMAs per 16 pixels, six-wave
                                                    workgroups (experimental/wgrad_wino4.hip)                          */

@@ -648,6 +648,7 @@ struct RedArgs {
     const float* slabs; const float* bslabs; float* dw; float* db;
     int nsplit, ntaps, Co, Ci, CoP, CiP, iBase, iTotal, perGroup;
     int nsplitW;               // slabs behind `slabs` (nsplit, or the folded count); bslabs always has nsplit rows
+    int permCo;                // algo 8 (ntaps = 1): slab column k = (tap, co) goes to dw column (k % permCo) * 4 + k / permCo; 0 = none
 };
 
 // Slab reduction, deterministic.  `perGroup` = LPE (a power of two <= 8) adjacent lanes share ONE float4 element (4
@@ -687,11 +688,20 @@ __device__ __forceinline__ void wgrad_reduce_body(const RedArgs& a, const int bl
             for (int j = 0; j < 4; ++j) sum[j] += __shfl_xor(sum[j], o, 64);
         }
         if (live && sub == 0) {
-            float* d = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * a.ntaps + tap;
+            if (a.permCo) {                                  // [ci][(tap, co)] -> IOHW [ci][co][tap] (ConvTranspose2d, algo 8)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ci + j >= a.Ci) break;
-                d[(long long)j * a.ntaps] += sum[j];
+                for (int j = 0; j < 4; ++j) {
+                    const int k = ci + j;
+                    if (k >= a.Ci) break;
+                    a.dw[(long long)co * a.iTotal + (k % a.permCo) * 4 + k / a.permCo] += sum[j];
+                }
+            } else {
+                float* d = a.dw + ((long long)co * a.iTotal + a.iBase + ci) * a.ntaps + tap;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ci + j >= a.Ci) break;
+                    d[(long long)j * a.ntaps] += sum[j];
+                }
             }
         }
     }
@@ -824,8 +834,36 @@ size_t refid_wgrad_wino4_workspace_bytes(const refid_wgrad_desc* d);
 int refid_wgrad_wino4_launch(const refid_wgrad_desc* d, hipStream_t st);
 #endif
 
+// algo 8: the weight gradient of a 2x2 stride-2 conv over NON-overlapping patches (ConvTranspose2d(2,2) with the roles swapped,
+// refid_hip.h) as ONE streaming 1x1 weight gradient: an output pixel's patch is two contiguous runs of 2 c_a floats (rows 2y and
+// 2y + 1 of dense pixels), i.e. a two-source 1x1 problem with 4 c_a "input channels" k = (dy, dx, c) over row-pitched sources
+// (WgKArgs.patchW / patchRow); the reduction permutes the columns into the [o][c][dy][dx] gradient.  Returns false when the
+// geometry does not fit (caller: error).
+static bool patch_translate(const refid_wgrad_desc* d, refid_wgrad_desc* t, int* patchW, int* patchRow) {
+    if (d->kh != 2 || d->kw != 2 || d->stride != 2 || d->pad != 0 || d->c_b != 0 || d->ld_a != d->c_a || d->h != 2 * d->ho ||
+        d->w != 2 * d->wo || d->i_base != 0 || d->i_total != d->c_a || d->db != nullptr)
+        return false;
+    *t = *d;
+    t->algo = 0; t->kh = t->kw = 1; t->stride = 1; t->pad = 0;
+    t->h = d->ho; t->w = d->wo;
+    t->in_b = d->in_a + (long long)d->w * d->ld_a;
+    t->ld_a = t->ld_b = 2 * d->ld_a;
+    t->c_a = t->c_b = 2 * d->c_a;
+    t->i_total = 4 * d->c_a;
+    for (int k = 0; k + 1 < REFID_WGRAD_MAX_GROUPS; ++k)
+        t->in_b_more[k] = d->in_a_more[k] ? d->in_a_more[k] + (long long)d->w * d->ld_a : nullptr;
+    *patchW = d->wo; *patchRow = 2 * d->w * d->ld_a;
+    return refid_wgrad_pws_ok(t) && (long long)d->n * d->h * d->w * d->ld_a * 4 < 0x7fffffffLL;
+}
+
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (!d) return 0;
+    refid_wgrad_desc tt;
+    if (d->algo == 8) {
+        int pw, pr;
+        if (!patch_translate(d, &tt, &pw, &pr)) return 0;
+        d = &tt;
+    }
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
     if (d->algo == 5) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
     if (d->algo == 7) return (d->kh == 4 && d->kw == 4 && d->stride == 2) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
@@ -868,6 +906,16 @@ extern "C" int refid_wgrad_finish_flush(void* stream) {
 }
 
 static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
+    refid_wgrad_desc tt;
+    int patchW = 0, patchRow = 0, permCo = 0;
+    if (d->algo == 8) {
+        REFID_CHECK(d->g && d->in_a && d->dw && d->slabs, "wgrad: null tensor pointer");
+        REFID_CHECK(patch_translate(d, &tt, &patchW, &patchRow),
+                    "wgrad (algo 8): a 2x2 stride-2 pad-0 conv over dense pixels (ld_a == c_a, one source, no bias), even input sizes, "
+                    "c_o >= 64 and a multiple of 32, c_a a multiple of 16");
+        permCo = d->c_a;
+        d = &tt;
+    }
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     REFID_CHECK(p.ok, "wgrad: unsupported geometry k=%dx%d stride=%d", d->kh, d->kw, d->stride);
     REFID_CHECK(d->g && d->in_a && d->dw && d->slabs, "wgrad: null tensor pointer");
@@ -940,6 +988,8 @@ static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
     a.tilesX = g.tilesX; a.tilesY = g.tilesY; a.ntiles = g.ntiles; a.nsplit = g.nsplit;
     a.CoP = g.CoP; a.CiP = g.CiP;
     a.accum = (d->phase == 2);
+    a.patchW = patchW; a.patchRow = patchRow;
+    REFID_CHECK(!patchW || pws, "wgrad (algo 8): the streaming 1x1 form is switched off (REFID_PWS_WGRAD)");
     REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
     int rc = (d->phase == 3) ? 0 : 1;
     if (d->phase != 3 && pws) {
@@ -997,6 +1047,7 @@ static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
     // real rows / columns of the parameter-layout gradient exist
     r.nsplit = g.nsplit; r.ntaps = p.ntaps; r.Co = d->o_real;
     r.nsplitW = g.nsplit;
+    r.permCo = permCo;
     {   // streaming first stage: S partial slabs (wgrad_wino24.hip::refid_launch_slab_fold; the element-wise stage below read
         // 100 MB of slabs at 0.09 of HBM)
         const long long slab = (long long)p.ntaps * g.CoP * g.CiP;

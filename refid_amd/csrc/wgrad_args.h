@@ -16,6 +16,9 @@ struct WgKArgs {
     int tilesX, tilesY, ntiles, nsplit;
     int CoP, CiP;
     int accum;                 // add into the slabs instead of overwriting them
+    // wgrad_pws.hip only, patch form (refid_wgrad_desc.algo 8): input pixel p sits at (p / patchW) * patchRow + (p % patchW) * ld
+    // floats instead of p * ld (both sources: the even / odd rows of ONE tensor); 0 = dense
+    int patchW = 0, patchRow = 0;
 };
 
 // wgrad_bf16.hip: 3x3 / stride-1 partial products with bf16 MFMA operands; geometry = the fp32 W3 plan

@@ -53,7 +53,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_pws_kernel(const WgKArgs a) {
     const bool xFromA = ci0 < a.Ca || ci0 >= a.Ctot;
     const int xld = xFromA ? a.ldA : a.ldB;
     const long long npix = (long long)a.N * a.H * a.W;
-    const int limG = (int)min(npix * a.ldG * 4, 0x7fffffffLL), limX = (int)min(npix * xld * 4, 0x7fffffffLL);
+    // (patch form: the sources are the even / odd rows of one tensor of npix / patchW row pairs; a tile of PB pixels lies in one
+    //  row -- host: patchW % PB == 0 --, pixels past the end land beyond the descriptor's range as in the dense form)
+    const long long spanX = a.patchW ? (npix / a.patchW) * (long long)a.patchRow - (xFromA ? 0 : a.patchRow / 2) : npix * xld;
+    const int limG = (int)min(npix * a.ldG * 4, 0x7fffffffLL), limX = (int)min(spanX * 4, 0x7fffffffLL);
     const int tilesPer = (int)((npix + PB - 1) / PB), ntAll = tilesPer * a.groups;
     const int chunk = (ntAll + a.nsplit - 1) / a.nsplit;
     const int t0 = min(split * chunk, ntAll), t1 = min(t0 + chunk, ntAll);
@@ -70,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pws_kernel(const WgKArgs a) {
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(xFromA ? a.inA[grp] : a.inB[grp]), 0, limX, 0x00020000);
         char* dst = smem + ((qt - t0) % NBUF) * BUF;
+        const int xp0 = a.patchW ? ((p0 / a.patchW) * a.patchRow + (p0 % a.patchW) * xld) * 4 : p0 * xld * 4;   // bytes (wave-uniform)
 #pragma unroll
         for (int k = 0; k < PPW; ++k) {
             const int q = wave + 4 * k;                    // piece of this wave (wave-uniform)
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_pws_kernel(const WgKArgs a) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_s)(dst + q * 1024), 16, ((p0 + q * GPX) * a.ldG * 4 + glc) | gbad, 0, 0, 0);
             else if (q < NP)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr_s)(dst + G_BYTES + (q - GP) * 1024), 16,
-                                                         ((p0 + (q - GP) * XPX) * xld * 4 + xlc) | xbad, 0, 0, 0);
+                                                         (xp0 + (q - GP) * XPX * xld * 4 + xlc) | xbad, 0, 0, 0);
             else                                           // padding piece: every wave issues PPW pieces per tile (the wait counts them)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr_s)(smem + NBUF * BUF), 16, -1, 0, 0, 0);
         }
@@ -227,6 +231,8 @@ int refid_wgrad_pws_launch(const refid_wgrad_desc* d, const WgKArgs& a, int nciT
     for (int k = 0; k < a.groups; ++k)
         REFID_CHECK(((uintptr_t)a.g[k] | (uintptr_t)a.inA[k] | (uintptr_t)(d->c_b ? a.inB[k] : nullptr)) % 16 == 0,
                     "wgrad (1x1 streaming): tensors must be 16-byte aligned (group %d)", k);
+    REFID_CHECK(!a.patchW || a.patchW % pws_pb(p.ow, p.wi) == 0, "wgrad (streaming, patch form): the row width must be a multiple of %d pixels",
+                pws_pb(p.ow, p.wi));
     const dim3 grid(a.nsplit, nciT, ncoT);
     if (p.ow == 2 && p.wi == 1) return launch_pws<2, 1>(a, grid, st);
     if (p.ow == 2 && p.wi == 2) return launch_pws<2, 2>(a, grid, st);

@@ -179,6 +179,7 @@ PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight p
 # fp32 Winograd packings of convs that run on their Winograd x six planes: packed on demand instead of every step (ConvOp)
 LAZY_FALLBACK_PACKS = os.environ.get("REFID_LAZY_PACKS", "1") != "0"
 CONVT_PW = os.environ.get("REFID_CONVT_PW", "1") != "0"           # ConvTranspose2d forward on the pointwise tile
+CONVT_PWS = os.environ.get("REFID_CONVT_PWS", "1") != "0"         # ... its weight gradient as a streaming patch GEMM (algo 8)
 # the element-wise slab-reduction stages at the end of BPTT as one launch per kernel family (finish_wgrads)
 FINISH_BATCH = os.environ.get("REFID_FINISH_BATCH", "1") != "0"
 # The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
@@ -730,6 +731,12 @@ class ConvOp:
             if self.has_bias and bias:
                 ops.colsum(g, self.gb)
             g, a, b, bias = a, g, None, False
+            if CONVT_PWS and PWS_WGRAD and not self.bf16 and a.stride(2) == a.shape[3] and g.shape[2] % 32 == 0 and \
+                    self._pws_plan_ok(self.ci, 2 * self.co, 2 * self.co, 4 * self.co):
+                # non-overlapping patches: ONE streaming 1x1 weight gradient with K = (dy, dx, co) over the even / odd rows of
+                # the output gradient (refid_wgrad_desc.algo 8); the direct 2x2 tile sat at 0.30 of the fp32 pipe
+                return self._wgrad_issue(g, a, None, False, 8)
+            return self._wgrad_issue(g, a, None, False, 0)
         gb = self.gb if bias else None
         algo = 1 if (USE_WINOGRAD and self.kind == "conv" and self.k == 3 and self.co >= WGRAD_WINO_MIN_CO and self.ci >= 32) else 0
         if algo == 1 and b is not None and a.shape[3] % 32 != 0:
@@ -745,6 +752,11 @@ class ConvOp:
             algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
+        return self._wgrad_issue(g, a, b, bias, algo)
+
+    def _wgrad_issue(self, g, a, b, bias, algo):
+        """Queue (grouped time steps) or launch the partial products of one call with the chosen algorithm."""
+        gb = self.gb if bias else None
         pws = PWS_WGRAD and self.kind == "conv" and self.k == 1 and algo == 0 and self._pws_ok(a, b)
         if self.w_group > 1 and ((self.kind == "conv" and self.k == 3 and self.ci > 4) or self.kind in ("down", "convT") or pws):
             # same source split, algorithm and bias mode as the waiting calls (the first recurrent step has no second source yet)?
@@ -770,13 +782,16 @@ class ConvOp:
     def _pws_ok(self, a, b):
         """Mirror of refid_wgrad_pws_ok (csrc/wgrad_pws.hip): does this 1x1 weight gradient take the streaming form?  (Only it
         can take several time steps per launch.)"""
-        ca, cb = a.shape[3], (b.shape[3] if b is not None else 0)
-        if self.co < 64 or self.co % 32 or ca % 32 or cb % 32 or self.ci % 32:
+        return self._pws_plan_ok(self.co, a.shape[3], b.shape[3] if b is not None else 0, self.ci)
+
+    @staticmethod
+    def _pws_plan_ok(co, ca, cb, ci):
+        if co < 64 or co % 32 or ca % 32 or cb % 32 or ci % 32:
             return False
-        wi = 4 if self.ci >= 128 else (2 if self.ci >= 64 else 1)
+        wi = 4 if ci >= 128 else (2 if ci >= 64 else 1)
         while cb and wi > 1 and ca % (32 * wi):
             wi //= 2
-        return not (self.co >= 128 and wi == 1 and cb and ca % 64)
+        return not (co >= 128 and wi == 1 and cb and ca % 64)
 
     def _slab_layout(self, algo):
         """The partial-sum slabs persist over the calls of one backward pass, and their layout belongs to the algorithm

@@ -384,6 +384,40 @@ def test_conv_transpose_wgrad():
     np.testing.assert_allclose(dw.double().cpu().numpy(), w.grad.numpy(), rtol=RTOL, atol=ATOL * 4)
 
 
+@pytest.mark.parametrize("cfg", [(2, 8, 32, 128, 64), (1, 6, 64, 64, 32), (3, 4, 32, 256, 128), (1, 5, 96, 64, 16)])
+def test_conv_transpose_wgrad_as_streaming_patch_gemm(cfg):
+    """refid_wgrad_desc.algo 8: the 2x2 stride-2 weight gradient over non-overlapping patches as ONE streaming 1x1 weight gradient
+    (K = (dy, dx, co) over the even / odd rows of the output gradient, columns permuted into IOHW by the reduction): one-shot,
+    and grouped time steps with persistent slabs + the queued reduction (phase 4 + flush); against autograd and the direct tile."""
+    ops = _ops()
+    N, H, W, Ci, Co = cfg
+    T = 3
+    w = rnd(Ci, Co, 2, 2, seed=2).requires_grad_(True)
+    steps = []
+    for t in range(T):
+        x = rnd(N, Ci, H, W, seed=10 + t)
+        y = F.conv_transpose2d(x, w, None, stride=2)
+        g = rnd(*y.shape, seed=20 + t)
+        y.backward(g)
+        steps.append((nhwc(x), nhwc(g)))
+    scale = float(w.grad.abs().max())
+    dw = torch.zeros(Ci, Co, 2, 2, device="cuda")
+    for xs, gs in steps:                                            # one-shot calls accumulate
+        ops.conv2d_wgrad(xs, gs, dw, kh=2, kw=2, stride=2, pad=0, algo=8)
+    assert float((dw.double().cpu() - w.grad).abs().max()) / scale < 2e-5
+    dw0 = torch.zeros_like(dw)
+    for xs, gs in steps:
+        ops.conv2d_wgrad(xs, gs, dw0, kh=2, kw=2, stride=2, pad=0)
+    assert float((dw0 - dw).abs().max()) / scale < 2e-5
+    dw2 = torch.zeros_like(dw)                                      # grouped: steps 0+1 in one launch, step 2 added, queued reduction
+    sl = ops.conv2d_wgrad(steps[0][0], steps[0][1], dw2, kh=2, kw=2, stride=2, pad=0, algo=8, phase=1,
+                          more=[(steps[1][0], steps[1][1], None)])
+    sl = ops.conv2d_wgrad(steps[2][0], steps[2][1], dw2, kh=2, kw=2, stride=2, pad=0, algo=8, phase=2, slabs=sl)
+    ops.conv2d_wgrad(steps[0][0], steps[0][1], dw2, kh=2, kw=2, stride=2, pad=0, algo=8, phase=4, slabs=sl)
+    ops.wgrad_finish_flush()
+    assert float((dw2.double().cpu() - w.grad).abs().max()) / scale < 2e-5
+
+
 def test_layout_and_elementwise():
     ops = _ops()
     x = rnd(2, 26, 8, 24, seed=1).float()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8, refid_rows_sum_defer / _flush; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -472,6 +472,14 @@ int refid_nchw_to_nhwc_tb(const float* src, long long b_stride, long long t_stri
                           int w, int c_pad, void* stream);
 int refid_nhwc_to_nchw_tb(const float* src, int ld, float* dst, long long b_stride, long long t_stride, int nb, int nt, int c,
                           int h, int w, void* stream);
+/* Deferred per-channel parameter-gradient sums.  refid_layernorm2d_bwd, refid_dwconv3x3_bwd and refid_colsum each end with a
+ * small launch that adds their per-workgroup partial rows into dw / db (autograd's accumulation of the T steps' gradients,
+ * twoImage_event_recurrent_model.py:303).  refid_rows_sum_defer(1) makes these calls (of this host thread) QUEUE that sum
+ * instead; refid_rows_sum_flush issues the queued sums grouped by destination, in call order within a destination (the bits of
+ * the one-by-one launches), as one launch per ~160 sums, and turns deferral off.  Between the two the caller keeps every `parts`
+ * buffer alive and the destinations untouched.  refid_rows_sum_defer also drops whatever an aborted pass left queued. */
+int refid_rows_sum_defer(int on);
+int refid_rows_sum_flush(void* stream);
 /* out = a + b (skip sums: XXNet_final_attenfusion_arch.py:16-17,199-203,211,215;
  * recurrent_sub_modules.py:278). count = number of floats, multiple of 4. */
 int refid_add(const float* a, const float* b, float* out, long long count, void* stream);

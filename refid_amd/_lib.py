@@ -100,6 +100,8 @@ def lib():
     L.refid_wgrad_workspace_bytes.restype = C.c_size_t
     L.refid_conv2d_wgrad.argtypes = [C.POINTER(WgradDesc), C.c_void_p]
     L.refid_wgrad_finish_flush.argtypes = [C.c_void_p]
+    L.refid_rows_sum_defer.argtypes = [C.c_int]
+    L.refid_rows_sum_flush.argtypes = [C.c_void_p]
     L.refid_packed_weight_floats.argtypes = [C.c_int] * 7
     L.refid_packed_weight_floats.restype = C.c_size_t
     L.refid_packed_weight_split_bytes.restype = C.c_size_t

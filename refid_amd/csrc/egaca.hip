@@ -14,6 +14,8 @@
 // the pixel rows of a wave -> the four waves in order through LDS -> one partial row per workgroup in the
 // caller's scratch -> a second tiny kernel adds the rows in a fixed order.  No floating-point atomics.
 #include "common.h"
+#include <vector>
+#include <cstring>
 
 namespace {
 
@@ -58,6 +60,89 @@ __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__
         float* d = i < n_a ? dst_a + i : dst_b + (i - n_a);
         *d = accumulate ? *d + a : a;
     }
+}
+
+// Deferred form (refid_rows_sum_defer / refid_rows_sum_flush): BPTT issues ~210 of these 5 us launches per step (LayerNorm,
+// depthwise and bias gradients of every time step), each a link of the dependent chain although nothing reads the parameter
+// gradients before the end of the BPTT half.  While deferral is on the three callers below QUEUE their sum; the flush groups the
+// queued sums by destination and issues them as one launch per ~160 sums: a wave owns a column of a destination and adds the
+// queued partial-row sets IN CALL ORDER, each with the same lane-strided sum and xor tree as rows_sum_kernel -- the bits of the
+// one-by-one launches.  The caller keeps the `parts` buffers alive and the destinations untouched until the flush.
+constexpr int ROWS_JOBS = 160, ROWS_GROUPS = 24;
+struct RowsJob { const float* parts; int nrows; int pad; };
+struct RowsGroup { float* dst_a; float* dst_b; int ncols, n_a, first, count, blk0, pad; };
+struct RowsBatch { RowsJob job[ROWS_JOBS]; RowsGroup grp[ROWS_GROUPS]; int ngroups; };
+static_assert(sizeof(RowsBatch) <= 4096, "kernel-argument block");
+
+__global__ __launch_bounds__(256) void rows_sum_batch_kernel(const RowsBatch b) {
+    int gi = 0;
+    for (int k = 1; k < b.ngroups; ++k) gi = (int)blockIdx.x >= b.grp[k].blk0 ? k : gi;        // (workgroup-uniform)
+    const RowsGroup& g = b.grp[gi];
+    const int lane = threadIdx.x & 63;
+    const int i = ((int)blockIdx.x - g.blk0) * 4 + (threadIdx.x >> 6);
+    if (i >= g.ncols) return;
+    float* d = i < g.n_a ? g.dst_a + i : g.dst_b + (i - g.n_a);
+    float tot = *d;
+    for (int j = g.first; j < g.first + g.count; ++j) {
+        const float* parts = b.job[j].parts;
+        const int nrows = b.job[j].nrows;
+        float a = 0.f;
+        for (int r = lane; r < nrows; r += 64) a += parts[(long long)r * g.ncols + i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        tot += a;
+    }
+    if (lane == 0) *d = tot;
+}
+
+struct RowsPending { const float* parts; int nrows, ncols; float* dst_a; int n_a; float* dst_b; };
+thread_local std::vector<RowsPending> rows_queue;
+thread_local bool rows_defer = false;
+
+// accumulate == 1 sums only (every caller below)
+int rows_sum_issue(const float* parts, int nrows, int ncols, float* dst_a, int n_a, float* dst_b, hipStream_t st, const char* what) {
+    if (rows_defer) {
+        rows_queue.push_back({parts, nrows, ncols, dst_a, n_a, dst_b});
+        return 0;
+    }
+    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(ncols, 4)), dim3(256), 0, st, parts, nrows, ncols, dst_a, n_a, dst_b, 1);
+    REFID_LAUNCH_CHECK(what);
+    return 0;
+}
+
+int rows_sum_flush(hipStream_t st) {
+    // groups in order of first appearance, jobs of a group in call order; a group split over the job limit continues in a LATER
+    // launch (stream order keeps the order of additions)
+    std::vector<char> done(rows_queue.size(), 0);
+    size_t left = rows_queue.size();
+    while (left) {
+        RowsBatch b;
+        memset(&b, 0, sizeof(b));
+        int nj = 0, ng = 0, blk = 0;
+        for (size_t k = 0; k < rows_queue.size() && ng < ROWS_GROUPS && nj < ROWS_JOBS; ++k) {
+            if (done[k]) continue;
+            const RowsPending& q = rows_queue[k];
+            bool open = false;                              // an earlier, unfinished part of this destination in this batch?
+            for (int g = 0; g < ng; ++g) open = open || (b.grp[g].dst_a == q.dst_a && b.grp[g].dst_b == q.dst_b);
+            if (open) continue;
+            RowsGroup& g = b.grp[ng];
+            g.dst_a = q.dst_a; g.dst_b = q.dst_b; g.ncols = q.ncols; g.n_a = q.n_a; g.first = nj; g.count = 0; g.blk0 = blk;
+            for (size_t m = k; m < rows_queue.size() && nj < ROWS_JOBS; ++m) {
+                const RowsPending& r = rows_queue[m];
+                if (done[m] || r.dst_a != q.dst_a || r.dst_b != q.dst_b) continue;
+                if (r.ncols != q.ncols || r.n_a != q.n_a) break;     // (same destination, another shape: next launch, in order)
+                b.job[nj].parts = r.parts; b.job[nj].nrows = r.nrows;
+                ++nj; ++g.count; done[m] = 1; --left;
+            }
+            blk += cdiv(g.ncols, 4);
+            ++ng;
+        }
+        b.ngroups = ng;
+        hipLaunchKernelGGL(rows_sum_batch_kernel, dim3(blk), dim3(256), 0, st, b);
+        if (hipGetLastError() != hipSuccess) { rows_queue.clear(); refid_set_error("rows_sum_batch: launch failed"); return 1; }
+    }
+    rows_queue.clear();
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -567,9 +652,7 @@ extern "C" int refid_layernorm2d_bwd(const float* g, int ld_g, const float* x, i
     LPP_DISPATCH(c, hipLaunchKernelGGL(ln_bwd_kernel<LPP>, dim3(nb), dim3(256), 0, st,
                                        g, ld_g, x, ld_x, w, gx, ld_gx, res, ld_res, parts, npix, eps));
     REFID_LAUNCH_CHECK("layernorm2d_bwd");
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(2 * c, 4)), dim3(256), 0, st, parts, nb, 2 * c, dw, c, db, 1);
-    REFID_LAUNCH_CHECK("layernorm2d_bwd/sum");
-    return 0;
+    return rows_sum_issue(parts, nb, 2 * c, dw, c, db, st, "layernorm2d_bwd/sum");
 }
 
 extern "C" int refid_dwconv_pool_parts(int h, int wd, int c) {
@@ -601,9 +684,7 @@ extern "C" int refid_dwconv3x3_bwd(const float* gd, const float* in, int ld_in, 
     const int nb = refid_dwconv3x3_bwd_parts(h, wd, c);
     LPP_DISPATCH(c, hipLaunchKernelGGL(dw_bwd_kernel<LPP>, dim3(nb, n), dim3(256), 0, st, gd, in, ld_in, w, gin, parts, h, wd));
     REFID_LAUNCH_CHECK("dwconv3x3_bwd");
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(c * 10, 4)), dim3(256), 0, st, parts, nb * n, c * 10, dw, c * 9, db, 1);
-    REFID_LAUNCH_CHECK("dwconv3x3_bwd/sum");
-    return 0;
+    return rows_sum_issue(parts, nb * n, c * 10, dw, c * 9, db, st, "dwconv3x3_bwd/sum");
 }
 
 extern "C" int refid_se_fwd(const float* pool, int n_parts, float inv_hw, const float* w1, const float* b1,
@@ -696,10 +777,18 @@ extern "C" int refid_colsum(const float* g, int ld_g, float* db, float* parts, l
     const int nb = refid_colsum_parts(npix, c);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, ld_g, parts, c, npix);
     REFID_LAUNCH_CHECK("colsum");
-    hipLaunchKernelGGL(rows_sum_kernel, dim3(cdiv(c, 4)), dim3(256), 0, (hipStream_t)stream, parts, nb, c, db, c,
-                       (float*)nullptr, 1);
-    REFID_LAUNCH_CHECK("colsum/sum");
+    return rows_sum_issue(parts, nb, c, db, c, nullptr, (hipStream_t)stream, "colsum/sum");
+}
+
+extern "C" int refid_rows_sum_defer(int on) {
+    rows_queue.clear();                                     // (a queue left behind by a failed backward pass holds dead pointers)
+    rows_defer = on != 0;
     return 0;
+}
+
+extern "C" int refid_rows_sum_flush(void* stream) {
+    rows_defer = false;
+    return rows_sum_flush((hipStream_t)stream);
 }
 
 extern "C" int refid_fold_back(const float* w, const float* b, const float* scale, const float* gw_folded,

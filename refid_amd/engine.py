@@ -180,6 +180,8 @@ PACK_BATCH = os.environ.get("REFID_PACK_BATCH", "1") != "0"       # all weight p
 LAZY_FALLBACK_PACKS = os.environ.get("REFID_LAZY_PACKS", "1") != "0"
 CONVT_PW = os.environ.get("REFID_CONVT_PW", "1") != "0"           # ConvTranspose2d forward on the pointwise tile
 CONVT_PWS = os.environ.get("REFID_CONVT_PWS", "1") != "0"         # ... its weight gradient as a streaming patch GEMM (algo 8)
+# LayerNorm / depthwise / bias gradient sums of a BPTT half queued and issued grouped by destination (ops.rows_sum_defer)
+ROWS_DEFER = os.environ.get("REFID_ROWS_DEFER", "0") != "0"
 # the element-wise slab-reduction stages at the end of BPTT as one launch per kernel family (finish_wgrads)
 FINISH_BATCH = os.environ.get("REFID_FINISH_BATCH", "1") != "0"
 # The skip sums the reference forms right after a conv (b0 = e + x_blocks[2], decoder inputs z + e_blocks[.], arch:16-17,
@@ -850,6 +852,7 @@ def finish_wgrads(op_list):
     finally:
         if batched:
             ops.wgrad_finish_flush()                       # (also after an error: nothing stays queued in the library)
+        ops.rows_sum_flush()                               # the per-channel sums queued since rows_sum_defer() (no-op otherwise)
 
 
 class _Trunk:
@@ -1423,6 +1426,8 @@ class Engine:
             o.w_calls, o.w_last, o.w_pend = 0, None, []
         self.fold_scratch.zero_()             # folded-weight gradients of THIS backward only (see ConvOp.__init__)
         self.ctx = None
+        if ROWS_DEFER:
+            ops.rows_sum_defer()              # per-channel gradient sums of this half: queued until finish_wgrads
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
         self._set_wgrad_groups(T, use_pipeline(B, H, W))
         dev = gout.device
@@ -1523,6 +1528,8 @@ class Engine:
         """Second half of BPTT: the backward sweep (walked t = 0 .. T-1), event head and image branch."""
         c, B, dev, g_xb, g_Sb, g_e, g_head = (state[k] for k in ("c", "B", "dev", "g_xb", "g_Sb", "g_e", "g_head"))
         xb, head, e_all = c["xb"], c["head"], c["e_all"]
+        if ROWS_DEFER:
+            ops.rows_sum_defer()
         # ---------------- backward sweep (executed t = T-1..0), BPTT in reverse: t = 0 .. T-1 ----
         g_hb = [None, None, None]
         lin = c["lin"]

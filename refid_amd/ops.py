@@ -345,6 +345,33 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     return slabs
 
 
+_ROWS_KEEP = None          # partial-row buffers of the queued per-channel sums (alive until rows_sum_flush)
+
+
+def rows_sum_defer():
+    """From here to rows_sum_flush() the per-channel parameter-gradient sums of layernorm2d_bwd / dwconv3x3_bwd / colsum are
+    queued (refid_rows_sum_defer); the caller must not read those gradients in between."""
+    global _ROWS_KEEP
+    check(lib().refid_rows_sum_defer(1), "refid_rows_sum_defer")
+    _ROWS_KEEP = []
+
+
+def rows_sum_flush():
+    """Issue the queued sums (one launch per ~160, grouped by destination, call order within one) and end the deferral."""
+    global _ROWS_KEEP
+    if _ROWS_KEEP is None:
+        return
+    try:
+        check(lib().refid_rows_sum_flush(_stream()), "refid_rows_sum_flush")
+    finally:
+        _ROWS_KEEP = None
+
+
+def _keep_rows(parts):
+    if _ROWS_KEEP is not None:
+        _ROWS_KEEP.append(parts)
+
+
 def wgrad_finish_flush():
     """Issue the element-wise slab-reduction stages queued by conv2d_wgrad(..., phase=4) calls: one launch per kernel
     family on the current stream (refid_wgrad_finish_flush)."""
@@ -490,6 +517,7 @@ def layernorm2d_bwd(g, x, w, gx, dw, db, accumulate=False, res=None, eps=1e-6):
     parts = torch.empty((nb, 2 * c), dtype=torch.float32, device=x.device)      # fixed-order partial sums of dw / db
     check(lib().refid_layernorm2d_bwd(pg, ldg, px, ldx, _c(w, "w"), pgx, ldgx, pr, ldr, _c(dw, "dw"),
                                       _c(db, "db"), parts.data_ptr(), npix, c, eps, _stream()), "refid_layernorm2d_bwd")
+    _keep_rows(parts)
     return gx
 
 
@@ -525,6 +553,7 @@ def dwconv3x3_bwd(gd, x, w, dw, db):
     parts = torch.empty((n * nparts, 10 * c), dtype=torch.float32, device=x.device)
     check(lib().refid_dwconv3x3_bwd(_c(gd, "gd"), px, ld, _c(w, "w"), gin.data_ptr(), _c(dw, "dw"), _c(db, "db"),
                                     parts.data_ptr(), n, h, wd, c, _stream()), "refid_dwconv3x3_bwd")
+    _keep_rows(parts)
     return gin
 
 
@@ -601,6 +630,7 @@ def colsum(g, db):
         raise _lib.RefidHipError(f"colsum: unsupported channel count {g.shape[3]}")
     parts = torch.empty((nb, g.shape[3]), dtype=torch.float32, device=g.device)
     check(lib().refid_colsum(pg, ld, _c(db, "db"), parts.data_ptr(), npix, g.shape[3], _stream()), "refid_colsum")
+    _keep_rows(parts)
 
 
 class PackPlan:

@@ -77,18 +77,19 @@ def test_batched_slab_reductions_equal_the_one_by_one_launches():
     net = build(26, 32, P)
     x, ev, gt = O.make_inputs(2, 3, 64, 64, 26, seed=7, mode="hash")
     x, ev, gt = x.cuda(), ev.cuda(), gt.cuda()
-    old = E.FINISH_BATCH
+    old, old_rows = E.FINISH_BATCH, E.ROWS_DEFER
     runs = []
     try:
         for flag in (True, False, True, False):
             E.FINISH_BATCH = flag
+            E.ROWS_DEFER = flag                                     # (the queued LayerNorm / depthwise / bias sums: same bits too)
             net.zero_grad(set_to_none=False)
             pred = net(x=x, event=ev)
             torch.sqrt((pred - gt) ** 2 + 1e-12).mean().backward()
             torch.cuda.synchronize()
             runs.append({k: p.grad.clone() for k, p in net.named_parameters()})
     finally:
-        E.FINISH_BATCH = old
+        E.FINISH_BATCH, E.ROWS_DEFER = old, old_rows
     assert any(float(g.abs().max()) > 0 for g in runs[0].values())
     for grads in runs[1:]:
         diff = [k for k in grads if not torch.equal(grads[k], runs[0][k])]

@@ -705,8 +705,9 @@ class ConvOp:
         i_base > 0: `a` holds the input channels i_base .. i_base + C_a of the conv (the time-independent half of a
         linearity split): one-shot launch straight into that column block of the gradient, no bias share.
 
-        Weight gradients are off BPTT's critical path (only input gradients feed the next step), so they are
-        issued on a side stream: their kernels fill the tails/gaps of the dependent dgrad chain."""
+        Weight gradients are off BPTT's critical path (only input gradients feed the next step): the calls of the T steps
+        wait in w_pend and go out as ONE launch per sweep on the main stream (_wgrad_issue / _launch_group); with
+        REFID_OVERLAP_WGRAD=1 they are issued on a side stream instead, as in rounds 1-4."""
         side = WGRAD_STREAM.get(g.device) if overlap_wgrad() else None
         if side is None:
             return self._wgrad(g, a, b, bias, i_base)

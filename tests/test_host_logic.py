@@ -421,3 +421,28 @@ def test_batched_finish_always_flushes_and_fallback_packs_stay_out_of_the_plan(m
     assert t2.kind == "convT" and t2.f_algo == 3 and t2.d_algo == 3 and t2.d_role == ops.ROLE_CONVT_DGRAD_PW
     assert t2._wg_geo() == dict(kh=2, kw=2, stride=2, pad=0, i_total=t2.co)
     assert eng.pred.wp6 is not None and eng.pred.f_algo == 0 and not eng.pred.wp_lazy      # thin output on the Winograd x six form
+
+
+def test_streaming_weight_gradient_eligibility_mirrors_the_library():
+    """ConvOp._pws_plan_ok (Python) decides which weight gradients are handed to the streaming kernel; the library decides the
+    same thing again (refid_wgrad_pws_ok) and would reject a mismatch at launch.  No GPU needed: refid_wgrad_workspace_bytes is
+    host arithmetic and returns 0 for an algo-8 request (ConvTranspose2d's weight gradient as a streaming patch GEMM) exactly when
+    the library would refuse it -- swept over channel counts and row widths."""
+    import ctypes as C
+    from refid_amd import _lib
+    from refid_amd.engine import ConvOp
+    L = _lib.lib()
+    for ci in (32, 48, 64, 96, 128, 256):                 # layer input channels = the GEMM's output rows
+        for co in (8, 16, 24, 32, 64, 128):               # layer output channels: K = 4 co
+            for w_lo in (16, 32, 48, 64):
+                d = _lib.WgradDesc()
+                d.g, d.in_a, d.dw, d.slabs = 4096, 8192, 12288, 16384          # (never dereferenced)
+                d.ld_g, d.c_o = ci, ci
+                d.ld_a, d.c_a = co, co
+                d.n, d.ho, d.wo, d.h, d.w = 2, 8, w_lo, 16, 2 * w_lo
+                d.kh, d.kw, d.stride, d.pad = 2, 2, 2, 0
+                d.i_base, d.i_total, d.o_real, d.algo, d.phase = 0, co, ci, 8, 1
+                lib_ok = L.refid_wgrad_workspace_bytes(C.byref(d)) > 0
+                py_ok = ConvOp._pws_plan_ok(ci, 2 * co, 2 * co, 4 * co)
+                # (the library checks the row width at launch, the engine before choosing: a multiple of 32 pixels)
+                assert lib_ok == py_ok, (ci, co, w_lo, lib_ok, py_ok)

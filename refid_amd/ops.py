@@ -31,11 +31,14 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_REQUIRE_CUDA = True       # (host-logic tests run the wrappers on CPU tensors against a recording library handle)
+
+
 def _nhwc(t, name):
     """(ptr, ld) of an NHWC view; validates layout."""
     if t is None:
         return None, 0
-    if t.dtype != torch.float32 or not t.is_cuda:
+    if t.dtype != torch.float32 or (_REQUIRE_CUDA and not t.is_cuda):
         raise _lib.RefidHipError(f"{name}: expected a CUDA float32 tensor, got {t.dtype} on {t.device}")
     if t.dim() != 4:
         raise _lib.RefidHipError(f"{name}: expected NHWC 4-D tensor, got shape {tuple(t.shape)}")
@@ -175,6 +178,9 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     """out = mask(post(pre(conv([in_a|in_b]) + bias) + res)); see refid_conv_desc.  pw: dict of the pointwise tile's
     EGACA fusions (refid_pw_extras); terms: algo 4's product count (0 / 6, or 3); algo 3: 0 = fp32 MFMA, 6 = six bf16 products
     (w_packed from pack_conv_weights_split with kh = kw = 1).  add2 / out2: second output out2 = out + add2 (not algo 3)."""
+    if DESC_CACHE and pw is None and PROFILE is None:
+        return _conv2d_cached(in_a, w_packed, out, kh, kw, stride, pad, mode, cout, cout_pad, co_base, in_b, bias, res, mask,
+                              slope_pre, slope_post, slope_mask, algo, terms, add2, out2, mask_mode)
     d = ConvDesc()
     d.mfma_terms = terms
     if pw is not None:
@@ -250,6 +256,71 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     PROFILE.append((name, flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, cout, int(res is not None), int(mask is not None), int(bias is not None)),
                     nbytes))
+    return out
+
+
+# ---- descriptor cache (REFID_DESC_CACHE=1; off by default until it has been timed on a GPU box) -------------------------------
+# At B=1 a train step is ~4800 launches of ~18 us of GPU time each, and the Python side of ONE conv2d call above -- ~35 ctypes
+# field stores, five layout checks, the workspace query -- costs ~16 us: the host is part of what the step waits for (the hipGraph
+# replay of the same step is 3.5 ms faster).  Everything in a descriptor except the pointers is a function of the call's scalar
+# arguments and of the operands' shapes and strides: the first call with a given signature goes through conv2d's full path with a
+# recording library handle, later calls copy the recorded descriptor, refresh the pointers (re-checking their alignment) and the
+# workspace, and launch.  tests/test_host_logic.py compares the descriptor BYTES of the two paths call by call.
+DESC_CACHE = os.environ.get("REFID_DESC_CACHE", "0") == "1"
+_DESC_CACHE = {}
+_DESC_PTRS = ("in_a", "in_b", "w_packed", "bias", "out", "res", "mask", "add2", "out2")
+
+
+def _sig(t):
+    return None if t is None else (t.shape, t.stride())
+
+
+def _conv2d_cached(in_a, w_packed, out, kh, kw, stride, pad, mode, cout, cout_pad, co_base, in_b, bias, res, mask,
+                   slope_pre, slope_post, slope_mask, algo, terms, add2, out2, mask_mode):
+    global lib, DESC_CACHE
+    key = (kh, kw, stride, pad, mode, cout, cout_pad, co_base, slope_pre, slope_post, slope_mask, algo, terms, mask_mode,
+           WINO_TILE, WINO_SPLIT, _sig(in_a), _sig(in_b), _sig(out), _sig(res), _sig(mask), _sig(add2), _sig(out2),
+           bias is not None, in_a.dtype, out.dtype)
+    ent = _DESC_CACHE.get(key)
+    if ent is None:
+        # first call with this signature: the validating path, with the launch intercepted to keep its descriptor
+        real, seen = lib(), []
+
+        class _Recorder:
+            def __getattr__(self, name):
+                if name == "refid_conv2d":
+                    def launch(dref, st):
+                        seen.append(ConvDesc.from_buffer_copy(C.string_at(C.addressof(dref._obj), C.sizeof(ConvDesc))))
+                        return real.refid_conv2d(dref, st)
+                    return launch
+                return getattr(real, name)
+
+        keep_lib, keep_flag = lib, DESC_CACHE
+        rec = _Recorder()
+        lib, DESC_CACHE = (lambda: rec), False
+        try:
+            conv2d(in_a, w_packed, out, kh=kh, kw=kw, stride=stride, pad=pad, mode=mode, cout=cout, cout_pad=cout_pad,
+                   co_base=co_base, in_b=in_b, bias=bias, res=res, mask=mask, slope_pre=slope_pre, slope_post=slope_post,
+                   slope_mask=slope_mask, algo=algo, terms=terms, add2=add2, out2=out2, mask_mode=mask_mode)
+        finally:
+            lib, DESC_CACHE = keep_lib, keep_flag
+        _DESC_CACHE[key] = (seen[0], int(seen[0].ws_bytes))
+        return out
+    d, ws_bytes = ent
+    if _REQUIRE_CUDA and not (in_a.is_cuda and out.is_cuda):
+        raise _lib.RefidHipError("conv2d: expected CUDA tensors")
+    ptrs = (in_a.data_ptr(), None if in_b is None else in_b.data_ptr(), w_packed.data_ptr(),
+            None if bias is None else bias.data_ptr(), out.data_ptr(), None if res is None else res.data_ptr(),
+            None if mask is None else mask.data_ptr(), None if add2 is None else add2.data_ptr(),
+            None if out2 is None else out2.data_ptr())
+    for nm, p in zip(_DESC_PTRS, ptrs):
+        if p is not None and p % 16 != 0 and nm not in ("w_packed", "bias"):
+            raise _lib.RefidHipError(f"{nm}: not a dense-pixel NHWC view (ptr%16={p % 16})")
+        setattr(d, nm, p)
+    if ws_bytes:
+        ws = _workspace(ws_bytes, in_a.device, "conv")     # (per launching stream; grow-only)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    check(lib().refid_conv2d(C.byref(d), _stream()), "refid_conv2d")
     return out
 
 

@@ -446,3 +446,87 @@ def test_streaming_weight_gradient_eligibility_mirrors_the_library():
                 py_ok = ConvOp._pws_plan_ok(ci, 2 * co, 2 * co, 4 * co)
                 # (the library checks the row width at launch, the engine before choosing: a multiple of 32 pixels)
                 assert lib_ok == py_ok, (ci, co, w_lo, lib_ok, py_ok)
+
+
+def test_cached_conv_descriptors_equal_the_validating_path_byte_for_byte(monkeypatch):
+    """ops.DESC_CACHE (REFID_DESC_CACHE=1): after the first call with a signature, conv2d copies a recorded descriptor and
+    refreshes only the pointers.  Against a recording library handle on CPU tensors: for a mix of geometries, epilogues, two
+    sources, second outputs, row ranges and fresh tensors per call, the bytes handed to refid_conv2d by the cached path equal the
+    bytes the full path builds -- so whatever the library does with one it does with the other."""
+    import ctypes as C
+    import torch
+    from refid_amd import ops, _lib
+    real = _lib.lib()
+    sent = []
+
+    class Lib:
+        def __getattr__(self, name):
+            if name == "refid_conv2d":
+                return lambda dref, st: sent.append(C.string_at(C.addressof(dref._obj), C.sizeof(_lib.ConvDesc))) or 0
+            return getattr(real, name)
+
+    handle = Lib()
+    monkeypatch.setattr(ops, "lib", lambda: handle)
+    monkeypatch.setattr(ops, "_stream", lambda: C.c_void_p(0))
+    monkeypatch.setattr(ops, "_REQUIRE_CUDA", False)
+    monkeypatch.setattr(ops, "_DESC_CACHE", {})
+    wsbuf = {}
+
+    def workspace(nbytes, device, kind="wgrad"):           # (the real one asks torch.cuda for the current stream)
+        if kind not in wsbuf or wsbuf[kind].numel() * 4 < nbytes:
+            wsbuf[kind] = torch.zeros((nbytes + 3) // 4)
+        return wsbuf[kind]
+
+    monkeypatch.setattr(ops, "_workspace", workspace)
+    gen = torch.Generator().manual_seed(0)
+
+    def t(*shape):
+        return torch.zeros(*shape)
+
+    def calls():
+        w = t(1 << 16)
+        for n, h, wd in ((1, 8, 32), (2, 16, 16)):
+            a, b, o = t(n, h, wd, 64), t(n, h, wd, 64), t(n, h, wd, 64)
+            r, m, p2, o2 = t(n, h, wd, 64), t(n, h, wd, 64), t(n, h, wd, 64), t(n, h, wd, 64)
+            bias = t(64)
+            yield dict(args=(a, w, o), kw=dict(kh=3, kw=3, pad=1, cout=64, cout_pad=64, algo=5, bias=bias, slope_pre=0.1))
+            yield dict(args=(a, w, o), kw=dict(kh=3, kw=3, pad=1, cout=64, cout_pad=64, algo=5, in_b=b, res=r, mask=m, slope_mask=0.1,
+                                                add2=p2, out2=o2))
+            yield dict(args=(a, w, o[..., :32]), kw=dict(kh=3, kw=3, pad=1, cout=32, cout_pad=64, co_base=32, algo=1, res=r[..., 32:]))
+            yield dict(args=(a, w, o), kw=dict(kh=1, kw=1, pad=0, cout=64, cout_pad=64, algo=3, in_b=b, bias=bias, mask=m, mask_mode=1))
+            yield dict(args=(a, w, t(n, h // 2, wd // 2, 64)), kw=dict(kh=4, kw=4, stride=2, pad=1, cout=64, cout_pad=64, algo=4, terms=6))
+            yield dict(args=(a, w, t(n, 2 * h, 2 * wd, 32)), kw=dict(kh=1, kw=1, pad=0, mode=1, cout=128, cout_pad=128, algo=3, bias=t(32)))
+
+    def run(cached):
+        monkeypatch.setattr(ops, "DESC_CACHE", cached)
+        sent.clear()
+        torch.manual_seed(0)
+        out = []
+        for rep in range(3):                               # fresh tensors (pointers) every repetition, the same signatures
+            for c in calls():
+                ops.conv2d(*c["args"], **c["kw"])
+                out.append((tuple(x.data_ptr() for x in c["args"]), sent[-1]))
+        return out
+
+    plain = run(False)
+    cached = run(True)
+    assert len(plain) == len(cached) == 36 and len(ops._DESC_CACHE) == 12
+    # (ws / ws_bytes: address and CAPACITY of the grow-only workspace the wrapper lends -- both paths ask for it when needed)
+    off = {n: getattr(_lib.ConvDesc, n).offset for n in ops._DESC_PTRS + ("ws", "ws_bytes")}
+    for (pp, pb), (cp, cb) in zip(plain, cached):
+        # the two runs allocated different tensors: compare with the pointer fields masked, and the pointer fields by role
+        pbm, cbm = bytearray(pb), bytearray(cb)
+        for o in off.values():
+            pbm[o:o + 8] = cbm[o:o + 8] = bytes(8)
+        assert pbm == cbm
+        dp, dc = _lib.ConvDesc.from_buffer_copy(pb), _lib.ConvDesc.from_buffer_copy(cb)
+        for nm in ops._DESC_PTRS + ("ws",):
+            assert (getattr(dp, nm) is None) == (getattr(dc, nm) is None), nm
+        assert (dp.ws_bytes == 0) == (dc.ws_bytes == 0) and (dp.ws is None) == (dp.ws_bytes == 0)
+        need = real.refid_conv_workspace_bytes(C.byref(dp))
+        assert dp.ws_bytes >= need and dc.ws_bytes >= need
+        assert (dp.in_a, dp.w_packed, dp.out) == pp and (dc.in_a, dc.w_packed, dc.out) == cp
+    # a misaligned operand is still refused on the cached path
+    a, w, o = t(1, 8, 32, 64), t(1 << 16), t(1, 8, 32, 68)[..., 2:66]
+    with pytest.raises(_lib.RefidHipError):
+        ops.conv2d(t(1, 8, 32, 64), w, o, kh=3, kw=3, pad=1, cout=64, cout_pad=64, algo=5, bias=t(64), slope_pre=0.1)

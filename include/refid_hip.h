@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 8     /* 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8, refid_rows_sum_defer / _flush; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 9     /* 9: refid_conv_desc.algo 5 with mfma_terms 3 (Winograd x three fp16 products), refid_pack_conv_weights_wino3h, pack-table kind 5 + refid_pack_batch_prepass; 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8, refid_rows_sum_defer / _flush; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -137,7 +137,9 @@ typedef struct refid_conv_desc {
                                                    channels, a 32-channel one up to 32, thin outputs included --, two
                                                    sources: c_a a multiple of 16; w_packed from
                                                    refid_pack_conv_weights_wino6): the fp32 Winograd tile's result to
-                                                   fp32 rounding at 2.67x fewer matrix-pipe cycles            */
+                                                   fp32 rounding at 2.67x fewer matrix-pipe cycles -- or, with
+                                                   mfma_terms = 3, THREE fp16 products on two-plane operands (22 bits;
+                                                   w_packed from refid_pack_conv_weights_wino3h): half the MFMAs again  */
     int split_k;                                /* small problems (few output tiles, long K): split K over the grid into
                                                    `ws` partial sums + a finishing pass.  0 = never; 1 = decided by the
                                                    per-sample geometry (a sample's bits do not depend on the batch
@@ -161,7 +163,13 @@ typedef struct refid_conv_desc {
                                                    algo 4: 0 / 6 = three bf16 planes per operand, six products
                                                    (error <= 2^-23 per product: fp32 class, closer to the fp64 result
                                                    than the fp32 Winograd tile); 3 = two planes, three products
-                                                   (2^-16 per product: explicit opt-in, still finer than TF32)       */
+                                                   (2^-16 per product: explicit opt-in, still finer than TF32).
+                                                   algo 5: 0 / 6 = six bf16 products on three-plane operands; 3 = three
+                                                   fp16 products on two-plane operands h = rne16(v), l = rne16(v - h)
+                                                   (~2^-22 per product, below the fp32 accumulation's own error at
+                                                   K >= 144; both operands travel scaled by exact powers of two -- U per
+                                                   packing, V per Winograd tile and online along K -- so any finite fp32
+                                                   magnitude keeps the same relative error)                         */
     float* ws;  size_t ws_bytes;                /* caller's scratch, >= refid_conv_workspace_bytes(d) bytes, 16-byte
                                                    aligned, private to this stream until the call's work has run;
                                                    NULL: never split                                            */
@@ -318,11 +326,19 @@ int refid_pack_conv_weights_split(const float* w, const float* oscale, void* pac
 size_t refid_packed_weight_wino6_bytes(int role, int o, int i, int bn);
 int refid_pack_conv_weights_wino6(const float* w, const float* oscale, void* packed, int role, int o, int i, int bn,
                                   void* stream);
+/* The same U for refid_conv2d algo 5 with mfma_terms = 3: a 64-byte header (int eU at byte 0: the packing's power-of-two
+ * scale, max |U| 2^eU in [2^12, 2^15), found by a reduction over the tensor that the call launches first) followed by
+ *   [chunk of 16 input channels][xi = 0..15][plane h / l][rows padded to bn = 64][16]  (fp16),
+ * h = rne16(U 2^eU), l = rne16(U 2^eU - h).  `packed` must be 16-byte aligned. */
+size_t refid_packed_weight_wino3h_bytes(int role, int o, int i, int bn);
+int refid_pack_conv_weights_wino3h(const float* w, const float* oscale, void* packed, int role, int o, int i, int bn,
+                                   void* stream);
 /* All packings of a model in ONE launch.  The caller builds a table of refid_pack_entry_bytes()-sized records in host
  * memory with refid_pack_entry_fill (kind 0: refid_pack_conv_weights[_scaled / _bf16] -- `planes` = 1 selects bf16 output;
  * 1: refid_pack_conv_weights_split, 3x3 / 4x4; 2: the same, 1x1; 3: refid_pack_conv_weights_wino6; 4: dst[e] = w[e] *
- * oscale[e] for e < o (refid_mul_vec)), copies it to device memory once, and calls refid_pack_batch whenever the weights have
- * changed.  `blk0` = the sum of the values returned for the records before this one (each call returns its record's
+ * oscale[e] for e < o (refid_mul_vec); 5: refid_pack_conv_weights_wino3h), copies it to device memory once, and calls
+ * refid_pack_batch whenever the weights have changed -- after refid_pack_batch_prepass on the same stream when the table holds
+ * kind-5 records (their scale exponents: one workgroup per record, a no-op for the other kinds).  `blk0` = the sum of the values returned for the records before this one (each call returns its record's
  * workgroup count >= 1, -1 on error -- the same argument checks as the one-by-one entry points); nblocks = the sum over
  * all records.  refid_pack_table_check walks a finished HOST table (every record filled, first blocks consecutive from 0:
  * the kernel finds a workgroup's record by binary search over them) and returns that sum, -1 on error.  Same bits as the
@@ -331,6 +347,7 @@ size_t refid_pack_entry_bytes(void);
 int refid_pack_table_check(const void* table_host, int n);
 int refid_pack_entry_fill(void* entry_host, int kind, const float* w, const float* oscale, void* dst, int role, int o, int i,
                           int kh, int kw, int kc, int bn, int planes, int blk0);
+int refid_pack_batch_prepass(const void* table_dev, int n, void* stream);
 int refid_pack_batch(const void* table_dev, int n, int nblocks, void* stream);
 int refid_mul_vec(const float* a, const float* b, float* out, int n, void* stream);
 /* After BPTT, turn the gradient of the FOLDED conv (scale[r]*W[r,:], scale[r]*b[r]) of THIS backward pass

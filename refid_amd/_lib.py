@@ -72,7 +72,7 @@ class WgradDesc(C.Structure):
     ]
 
 
-ABI_VERSION = 8          # == REFID_ABI_VERSION in include/refid_hip.h
+ABI_VERSION = 9          # == REFID_ABI_VERSION in include/refid_hip.h
 _lib = None
 
 
@@ -132,6 +132,10 @@ def _bind_extra(L):
     L.refid_packed_weight_wino6_bytes.argtypes = [i] * 4
     L.refid_packed_weight_wino6_bytes.restype = C.c_size_t
     L.refid_pack_conv_weights_wino6.argtypes = [vp, vp, vp] + [i] * 4 + [vp]
+    L.refid_packed_weight_wino3h_bytes.argtypes = [i] * 4
+    L.refid_packed_weight_wino3h_bytes.restype = C.c_size_t
+    L.refid_pack_conv_weights_wino3h.argtypes = [vp, vp, vp] + [i] * 4 + [vp]
+    L.refid_pack_batch_prepass.argtypes = [vp, i, vp]
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
     L.refid_pack_entry_bytes.restype = C.c_size_t
     L.refid_pack_entry_bytes.argtypes = []

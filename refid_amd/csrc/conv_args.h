@@ -43,7 +43,8 @@ int refid_launch_wino3x3_p(const ConvKArgs& a, int cus, hipStream_t st);
 // conv_wino6.hip: Winograd F(2x2,3x3) with six bf16 products per fp32 product (algo 5)
 bool refid_wino6_eligible(const ConvKArgs& a);
 size_t refid_wino6_workspace_bytes(const ConvKArgs& a, int split_mode);
-int refid_launch_wino6(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st);
+// terms: 0 / 6 = six bf16 products (three planes per operand), 3 = three fp16 products (two planes, scaled operands)
+int refid_launch_wino6(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, int terms, hipStream_t st);
 // conv_wino6w.hip: the same arithmetic on 8-wave workgroups (8x32 pixels) that share the weight fragments through LDS
 int refid_wino6w_workgroups(const ConvKArgs& a);
 int refid_launch_wino6w(const ConvKArgs& a, int ks, hipStream_t st);

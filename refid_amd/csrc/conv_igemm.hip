@@ -567,7 +567,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         return refid_launch_split3x3(a, d->mfma_terms ? d->mfma_terms : 6, f == F_3x3 ? 0 : (f == F_4x4s2 ? 1 : 2),
                                      cus > 0 ? cus : 256, st);
     }
-    if (d->algo == 5) return refid_launch_wino6(a, d->ws, d->ws_bytes, d->split_k, d->wino_tile, st);
+    if (d->algo == 5) return refid_launch_wino6(a, d->ws, d->ws_bytes, d->split_k, d->wino_tile, d->mfma_terms, st);
     if (d->algo == 1) {
         REFID_CHECK(d->c_b == 0 || d->c_a % 8 == 0, "conv2d: Winograd tile needs c_a %% 8 == 0 for two sources");
         const long long lim = 0x7fffffffLL;      // buffer-load byte offsets are 32-bit

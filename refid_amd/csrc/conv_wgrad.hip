@@ -853,7 +853,10 @@ static bool patch_translate(const refid_wgrad_desc* d, refid_wgrad_desc* t, int*
     for (int k = 0; k + 1 < REFID_WGRAD_MAX_GROUPS; ++k)
         t->in_b_more[k] = d->in_a_more[k] ? d->in_a_more[k] + (long long)d->w * d->ld_a : nullptr;
     *patchW = d->wo; *patchRow = 2 * d->w * d->ld_a;
-    return refid_wgrad_pws_ok(t) && (long long)d->n * d->h * d->w * d->ld_a * 4 < 0x7fffffffLL;
+    if (!refid_wgrad_pws_ok(t) || (long long)d->n * d->h * d->w * d->ld_a * 4 >= 0x7fffffffLL) return false;
+    // a patch row must fill whole ring buffers (the launch checks the same: the workspace query and the launch agree)
+    const int pb = refid_wgrad_pws_pixels_per_buffer(t);
+    return pb > 0 && *patchW % pb == 0;
 }
 
 extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {

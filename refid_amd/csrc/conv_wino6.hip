@@ -13,6 +13,21 @@
 // The price is VALU: V is split on the fly (44 VALU per 8 values, ~5 VALU per MFMA) -- tools/probes/wino6_loop.hip
 // measured that two waves per SIMD hide it (0.52 of the bf16 peak with the split, 0.58 without, random data).
 //
+// THREE fp16 products (template parameter F16, refid_conv_desc.mfma_terms = 3; round 6): fp16 has 11 significand bits, so TWO
+// planes h = rne16(v), l = rne16(v - h) carry 22 and  u*v = uh*vh + uh*vl + ul*vh + O(2^-22 |uv|)  takes three
+// v_mfma_f32_32x32x16_f16 and two U planes -- half the matrix-pipe cycles and two thirds of the U bytes (the kernel's two
+// measured costs: profiles/r05_wino6_ablation.txt, r06_wino6_f16_ceiling.txt) -- for a per-product error of ~2^-22 instead of
+// ~2^-24, both below what the fp32 accumulation of a K >= 144 dot product adds.  The price is fp16's RANGE (normal numbers
+// 2^-14 .. 2^16: the low plane of a value below 2^-3 is subnormal), so both operands travel scaled by exact powers of two:
+//   * U by 2^eU per packing (max |U| 2^eU in [2^12, 2^15); refid_pack_conv_weights_wino3h, exponent in the packing's header);
+//   * V per LANE = per Winograd tile and transform row, ONLINE along K: a lane's accumulators all belong to its own tile
+//     (MFMA column), so its scale need only be constant along K -- the lane keeps a reference exponent E (of the largest
+//     |B^T d| it has seen), scales a chunk's row-transformed values by 2^(7 - E) (the chunk's largest lands in [2^7, 2^8), V in
+//     < 2^9), and when a later chunk exceeds 2^6 times the reference (V would pass 2^15) it multiplies its accumulators by
+//     2^(E - E') and goes on with E' -- the flash-attention rescale, with powers of two: exact.  Values 2^10 below a chunk's
+//     largest keep all 22 bits; smaller ones an ABSOLUTE error of 2^-32 of the largest, far below the 2^-22 of the large terms
+//     they are added to.  The output transform undoes 2^(7 - E + eU) per lane with v_ldexp before the rows meet in LDS.
+//
 //   out = mask( post( pre(conv3x3(src) + bias) + res ) ),  src = in_a or [in_a | in_b]
 // (same contract, epilogue, split-K form and XCD-aware work mapping as conv_wino.hip; serves the forward conv and,
 // on the flipped/transposed weights, the input gradient.)
@@ -52,6 +67,13 @@ constexpr int R_ITEMS = (4 * HP + 255) / 256;
 constexpr int lds_bytes(int nt) { return nt == 2 ? 64 * 66 * 16 : (32 * 66 * 16 > 2 * R_F4 * 16 ? 32 * 66 * 16 : 2 * R_F4 * 16); }
 constexpr int OOB = -1;                 // voffset 0xFFFFFFFF: buffer loads return 0 (hardware range check)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int W3H_HEADER = 64;          // bytes in front of the fp16 planes: int eU (runtime.hip)
+constexpr int F16_TGT = 7;              // a freshly scaled chunk's largest |B^T d| lands in [2^7, 2^8)
+constexpr int F16_SLACK = 6;            // binades the largest value may grow over the reference before the accumulators are rescaled
+constexpr int F16_E0 = F16_TGT + 1;     // initial (biased) reference exponent: any real data is larger
 
 // v (8 fp32 channels) -> three bf16 planes that sum to v exactly
 __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (&pl)[3]) {
@@ -71,13 +93,32 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (
     pl[2] = __builtin_bit_cast(f32x4, p2);
 }
 
+// v (8 fp32 channels, already scaled into fp16's range) -> two fp16 planes, h + l = v to 22 bits (20 VALU)
+__device__ __forceinline__ void split8h(const f32x4& v0, const f32x4& v1, f32x4 (&pl)[3]) {
+    f16x8 h, l;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const f32x2 ab = {k < 4 ? v0[k] : v1[k - 4], k < 4 ? v0[k + 1] : v1[k - 3]};
+        const f16x2 hh = __builtin_convertvector(ab, f16x2);                  // v_cvt_pk_f16_f32 (RNE)
+        const f32x2 r = ab - __builtin_convertvector(hh, f32x2);              // exact
+        const f16x2 ll = __builtin_convertvector(r, f16x2);
+        h[k] = hh[0]; h[k + 1] = hh[1];
+        l[k] = ll[0]; l[k + 1] = ll[1];
+    }
+    pl[0] = __builtin_bit_cast(f32x4, h);
+    pl[1] = __builtin_bit_cast(f32x4, l);
+}
+
 // NT = 2: 64 output channels per workgroup (8 accumulators per wave, two workgroups per CU).
 // NT = 1: the 32-output-channel layers (decoder 2's trunk, the input gradient of level 0's first conv; round 4 -- they ran
 //         on the fp32 Winograd tile at 0.36 of the fp32 roof): 4 accumulators per wave, three workgroups per CU; every V
 //         split feeds 6 instead of 12 MFMAs, so this form is vector-issue bound -- and still well ahead of 64 fp32 MFMAs.
-template <int NT>
+// F16: the three-fp16-product form (two planes per operand, online power-of-two scaling: see the top of the file)
+template <int NT, bool F16>
 __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const ConvKArgs a) {
     constexpr int BN = 32 * NT;
+    constexpr int NPL = F16 ? 2 : 3;                        // planes per operand
+    constexpr int NPR = (REFID_WINO6_ABLATE == 14 || REFID_WINO6_ABLATE == 15) ? 3 : (F16 ? 3 : 6);   // products kept
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sR = reinterpret_cast<f32x4*>(smem);            // two raw halo buffers
 
@@ -110,10 +151,12 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     const int limA = (int)min((long long)a.N * a.H * a.W * a.ldA * 4, 0x7fffffffLL);
     const int limB = a.inB ? (int)min((long long)a.N * a.H * a.W * a.ldB * 4, 0x7fffffffLL) : 0;
     const int uPlane = a.CoutPad * KC * 2;                 // bytes between two planes of one xi
-    const int uXi = 3 * uPlane;                            // bytes between xi and xi+1
+    const int uXi = NPL * uPlane;                          // bytes between xi and xi+1
     const int uChunk = 16 * uXi;                           // bytes per K chunk
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), 0, (int)min((long long)a.nchunks * uChunk, 0x7fffffffLL), 0x00020000);
+        const_cast<float*>(a.w) + (F16 ? W3H_HEADER / 4 : 0), 0, (int)min((long long)a.nchunks * uChunk, 0x7fffffffLL), 0x00020000);
+    const int eU = F16 ? *reinterpret_cast<const int*>(a.w) : 0;      // U travels as U 2^eU (wave-uniform scalar load)
+    int eRef = F16_E0;                                      // this lane's reference exponent (biased), F16 only
     // raw halo: thread -> (pixel, channel quad); four lanes read one pixel's 64 contiguous bytes
     const int q = tid & 3;
     int pixo[R_ITEMS], sdst[R_ITEMS];
@@ -147,7 +190,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     // 3 = no K loop, 4 = no residual / mask loads and no stores, 5 = raw halo always from chunk 0, 6 = no U loads in the K loop,
     // 7 = no raw loads / LDS stores in the K loop, 8 = 6 + 7, 9 / 11 = the workgroup in the odd wave slot of its SIMD starts
     // 4 / 8 us late (anti-phased pair per CU), 10 = 3 + 4, 12 = every lane of a U load reads the same 16 bytes (same
-    // instruction count, no bandwidth), 13 = half the U loads (column tile 1 reuses tile 0's fragments).  Never in the product.
+    // instruction count, no bandwidth), 13 = half the U loads (column tile 1 reuses tile 0's fragments), 14 = three products on
+    // two planes (the MFMA / U-byte count of a two-plane fp16 form), 15 = 14 without the split.  Never in the product.
     auto load_raw = [&](int ch, f32x4 (&dst)[R_ITEMS]) {
         const int c0 = (REFID_WINO6_ABLATE == 5 ? 0 : ch) * KC;   // chunk-uniform source: Ca % 16 == 0 for two sources
         const bool fromA = c0 < a.Ca;
@@ -169,12 +213,12 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
         for (int it = 0; it < R_ITEMS; ++it) sR[buf * R_F4 + sdst[it]] = src[it];
     };
     // fragments of column j of chunk ch: [plane][nt]
-    auto load_u = [&](int ch, int j, f32x4 (&dst)[3][NT]) {
+    auto load_u = [&](int ch, int j, f32x4 (&dst)[NPL][NT]) {
         // (the hardware range check covers the vector offset only: a chunk past the range must not travel as a scalar offset)
         const bool in = ch < kc1;
         const int so = (REFID_WINO6_ABLATE == 1 ? 0 : ch) * uChunk + j * uXi;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < ((REFID_WINO6_ABLATE == 14 || REFID_WINO6_ABLATE == 15) ? 2 : NPL); ++p)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 if (REFID_WINO6_ABLATE == 13 && nt == 1) { dst[p][nt] = dst[p][0]; continue; }
@@ -204,7 +248,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     constexpr int TA[6] = {0, 0, 1, 0, 2, 1};              // products kept: (V plane, U plane), largest first
     constexpr int TB[6] = {0, 1, 0, 2, 0, 1};
 
-    f32x4 uA[3][NT], uB[3][NT];
+    f32x4 uA[NPL][NT], uB[NPL][NT];
     auto phase = [&](int ch) {
         const int lc = ch - kc0;
         if (REFID_WINO6_ABLATE != 7 && REFID_WINO6_ABLATE != 8) {
@@ -220,10 +264,40 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
         for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
             for (int b = 0; b < 4; ++b) t[qq][b] = r[qq * PLANE + offP + BOFF[b]] + r[qq * PLANE + offM + BOFF[b]] * sgn;
+        if constexpr (F16) {
+            // largest |t| of this lane's tile in this chunk (both K halves: lanes l and l ^ 32 hold the same tile)
+            float m = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    m = fmaxf(fmaxf(m, fmaxf(fabsf(t[qq][b][0]), fabsf(t[qq][b][1]))), fmaxf(fabsf(t[qq][b][2]), fabsf(t[qq][b][3])));
+            const unsigned mb = __float_as_uint(m);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+            const int eb = (int)(max(sw[0], sw[1]) >> 23);
+            const bool grow = eb > eRef + F16_SLACK;
+            if (__builtin_amdgcn_ballot_w64(grow) != 0) {   // rare: at a tile's first chunk with data, then only when the data grow 64x
+                const int en = grow ? eb : eRef;
+                const int fe = 127 + eRef - en;             // accumulators *= 2^(eRef - en)  (more than 2^-126: they no longer count)
+                const float f = fe >= 1 ? __uint_as_float((unsigned)fe << 23) : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int rr2 = 0; rr2 < 16; ++rr2) acc[j][nt][rr2] *= f;
+                eRef = en;
+            }
+            const float sc = __uint_as_float((unsigned)(F16_TGT + 254 - eRef) << 23);      // 2^(TGT - (eRef - 127)), eRef in [8, 255]
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) t[qq][b] *= sc;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x4 (&cur)[3][NT] = (j & 1) ? uB : uA;
-            f32x4 (&nxt)[3][NT] = (j & 1) ? uA : uB;
+            f32x4 (&cur)[NPL][NT] = (j & 1) ? uB : uA;
+            f32x4 (&nxt)[NPL][NT] = (j & 1) ? uA : uB;
             if (REFID_WINO6_ABLATE != 6 && REFID_WINO6_ABLATE != 8) load_u(j == 3 ? ch + 1 : ch, (j + 1) & 3, nxt);
 #ifdef REFID_WINO6_PIN
             __builtin_amdgcn_sched_barrier(0x38F);         // vector-memory instructions stay where they are written
@@ -233,14 +307,20 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
             for (int qq = 0; qq < 2; ++qq)
                 v[qq] = (j == 0) ? t[qq][0] - t[qq][2] : (j == 1) ? t[qq][1] + t[qq][2]
                       : (j == 2) ? t[qq][2] - t[qq][1] : t[qq][1] - t[qq][3];
-            if (REFID_WINO6_ABLATE == 2) { pl[0] = v[0]; pl[1] = v[1]; pl[2] = t[0][j]; }
+            if (REFID_WINO6_ABLATE == 2 || REFID_WINO6_ABLATE == 15) { pl[0] = v[0]; pl[1] = v[1]; pl[2] = t[0][j]; }
+            else if constexpr (F16) split8h(v[0], v[1], pl);
             else split8(v[0], v[1], pl);
 #pragma unroll
-            for (int e = 0; e < 6; ++e)
+            for (int e = 0; e < NPR; ++e)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)            // consecutive MFMAs hit different accumulators
-                    acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, cur[TB[e]][nt]), __builtin_bit_cast(bf16x8, pl[TA[e]]), acc[j][nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {          // consecutive MFMAs hit different accumulators
+                    if constexpr (F16)
+                        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, cur[TB[e]][nt]), __builtin_bit_cast(f16x8, pl[TA[e]]), acc[j][nt], 0, 0, 0);
+                    else
+                        acc[j][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                            __builtin_bit_cast(bf16x8, cur[TB[e]][nt]), __builtin_bit_cast(bf16x8, pl[TA[e]]), acc[j][nt], 0, 0, 0);
+                }
         }
         __syncthreads();                                   // raw(ch) consumed by every wave; raw(ch+1) visible
     };
@@ -275,6 +355,10 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
                 const int r = 4 * rq + k;
                 r0[k] = acc[0][t][r] + acc[1][t][r] + acc[2][t][r];
                 r1[k] = acc[1][t][r] - acc[2][t][r] - acc[3][t][r];
+                if constexpr (F16) {                        // undo U's and this lane's V scale: exact (v_ldexp_f32)
+                    r0[k] = ldexpf(r0[k], eRef - 127 - F16_TGT - eU);
+                    r1[k] = ldexpf(r1[k], eRef - 127 - F16_TGT - eU);
+                }
             }
             xch[(((ti * 2 + 0) * NT + t) * 4 + rq) * XL + kh * 33 + li] = r0;
             xch[(((ti * 2 + 1) * NT + t) * 4 + rq) * XL + kh * 33 + li] = r1;
@@ -414,13 +498,18 @@ Wino6Plan wino6_plan(ConvKArgs& a, int split_mode, int tile_hint = 0) {
     return p;
 }
 
-template <int NT>
-int launch_wino6(const ConvKArgs& a, dim3 grid, hipStream_t st, const char* what) {
+template <int NT, bool F16>
+int launch_wino6_t(const ConvKArgs& a, dim3 grid, hipStream_t st, const char* what) {
     static std::atomic<unsigned long long> done{0};
-    if (int rc = refid_lds_attr_once(done, &conv_wino6_kernel<NT>, lds_bytes(NT), "conv_wino6")) return rc;
-    hipLaunchKernelGGL(conv_wino6_kernel<NT>, grid, dim3(256), lds_bytes(NT), st, a);
+    if (int rc = refid_lds_attr_once(done, &conv_wino6_kernel<NT, F16>, lds_bytes(NT), "conv_wino6")) return rc;
+    hipLaunchKernelGGL((conv_wino6_kernel<NT, F16>), grid, dim3(256), lds_bytes(NT), st, a);
     REFID_LAUNCH_CHECK(what);
     return 0;
+}
+
+template <int NT>
+int launch_wino6(const ConvKArgs& a, bool f16, dim3 grid, hipStream_t st, const char* what) {
+    return f16 ? launch_wino6_t<NT, true>(a, grid, st, what) : launch_wino6_t<NT, false>(a, grid, st, what);
 }
 
 }  // namespace
@@ -444,8 +533,12 @@ size_t refid_wino6_workspace_bytes(const ConvKArgs& ka, int split_mode) {
     return need;
 }
 
-int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
+int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, int terms, hipStream_t st) {
     ConvKArgs a = ka;
+    REFID_CHECK(terms == 0 || terms == 6 || terms == 3, "conv2d: algo 5 takes mfma_terms 0 / 6 (six bf16 products) or 3 (three fp16 "
+                "products, w_packed from refid_pack_conv_weights_wino3h), got %d", terms);
+    const bool f16 = terms == 3;
+    REFID_CHECK(!f16 || (reinterpret_cast<uintptr_t>(a.w) & 15) == 0, "conv2d: the fp16 Winograd packing must be 16-byte aligned");
     REFID_CHECK(refid_wino6_eligible(a),
                 "conv2d: the Winograd six-product tile needs input-channel counts that are multiples "
                 "of 4 (two sources: c_a a multiple of 16) and tensors below 2 GiB");
@@ -453,12 +546,12 @@ int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int spli
     // bits): measured 0-10 % slower, only in libraries built with REFID_EXPERIMENTAL_TILES=1 and only on request
     // (refid_conv_desc.wino_tile = 3)
 #ifdef REFID_EXPERIMENTAL_TILES
-    if (tile_hint == 3 && a.Cout > 32 && a.out2 == nullptr) return refid_launch_wino6w(a, 1, st);   // (no second output there)
+    if (tile_hint == 3 && a.Cout > 32 && a.out2 == nullptr && !f16) return refid_launch_wino6w(a, 1, st);   // (no second output there)
 #endif
     const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0, tile_hint);
     dim3 grid = pl.grid;
     const int ks = pl.ks;
-    if (ks == 1) return pl.nt == 2 ? launch_wino6<2>(a, grid, st, "conv_wino6") : launch_wino6<1>(a, grid, st, "conv_wino6/32");
+    if (ks == 1) return pl.nt == 2 ? launch_wino6<2>(a, f16, grid, st, "conv_wino6") : launch_wino6<1>(a, f16, grid, st, "conv_wino6/32");
     const long long npix = (long long)a.N * a.Ho * a.Wo;
     const int ldW = round_up(a.Cout, 4);
     const size_t need = (size_t)ks * npix * ldW * sizeof(float);
@@ -470,7 +563,7 @@ int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int spli
     ConvKArgs p = a;                       // partial pass: raw sums into the workspace (the finishing pass writes out / out2)
     p.ksplit = ks; p.wsStride = npix * ldW; p.out = ws; p.ldO = ldW; p.out2 = nullptr;
     grid.y = ks;
-    if (int rc = pl.nt == 2 ? launch_wino6<2>(p, grid, st, "conv_wino6/splitk") : launch_wino6<1>(p, grid, st, "conv_wino6/32/splitk"))
+    if (int rc = pl.nt == 2 ? launch_wino6<2>(p, f16, grid, st, "conv_wino6/splitk") : launch_wino6<1>(p, f16, grid, st, "conv_wino6/32/splitk"))
         return rc;
     ConvKArgs f = a;
     f.ksplit = ks; f.wsStride = npix * ldW;

@@ -350,11 +350,102 @@ __global__ __launch_bounds__(256) void pack_wino6_kernel(const PackArgs p) {
     for (unsigned f = blockIdx.x * 256u + threadIdx.x; f < total; f += gridDim.x * 256u) pack_wino6_weight(p, f);
 }
 
+// ---- Winograd-domain weights for the THREE-fp16-product form of conv_wino6.hip (refid_conv2d algo 5, mfma_terms 3) ----------
+// fp16 keeps 11 significand bits, so two planes h = rne16(v), l = rne16(v - h) carry 22 bits and  u v = uh vh + uh vl + ul vh
+// + O(2^-22 |u v|)  needs three MFMAs and two U planes where the bf16 form needs six and three.  The price is fp16's RANGE
+// (2^-14 .. 2^16; the low plane of a value below 2^-3 is subnormal): both operands travel multiplied by an exact power of two.
+// U's is per packing: 2^eU with max |U| 2^eU in [2^12, 2^15) -- |U| <= 2.25 max |w| --, found by a reduction over the tensor
+// (pack_absmax_*: one workgroup per tensor, max is order independent => deterministic) and kept in the packing's 64-byte HEADER
+// (int eU at byte 0), where the pack kernel and the conv tile read it; the conv tile undoes 2^eU together with its own per-tile
+// scale of V in its output transform.  Layout after the header: [chunk16][xi][plane h/l][rowsPad][16] fp16.
+constexpr int W3H_HEADER = 64;
+
+__device__ __forceinline__ int wino3h_scale_exp(float maxabs) {
+    if (!(maxabs > 0.f)) return 0;
+    const int ew = (int)(__float_as_uint(maxabs) >> 23) - 127;                 // max |w| < 2^(ew+1), max |U| < 2^(ew+2.17)
+    const int e = 12 - ew;
+    return e < -110 ? -110 : (e > 110 ? 110 : e);
+}
+
+__device__ __forceinline__ void pack_absmax_block(const PackArgs& p) {       // one workgroup (any size that is a multiple of 64)
+    __shared__ float part[16];
+    const long long total = (long long)p.O * p.I * 9;
+    const int per_o = p.I * 9;
+    float m = 0.f;
+    if (p.oscale == nullptr && total % 4 == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0) {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(p.w);
+        for (long long e = threadIdx.x; e < total / 4; e += blockDim.x) {
+            const f32x4 v = w4[e];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+    } else {
+        for (long long e = threadIdx.x; e < total; e += blockDim.x)
+            m = fmaxf(m, fabsf(p.w[e] * (p.oscale ? p.oscale[e / per_o] : 1.f)));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmaxf(m, part[k]);
+        *reinterpret_cast<int*>(p.dst) = wino3h_scale_exp(m);
+    }
+}
+
+__global__ __launch_bounds__(1024) void pack_absmax_kernel(const PackArgs p) { pack_absmax_block(p); }
+
+// one thread per WEIGHT, as pack_wino6_weight: nine loads, the 16 transform points once, 32 two-byte stores
+__device__ __forceinline__ void pack_wino3h_weight(const PackArgs& p, unsigned f) {
+    const unsigned k16 = f & 15, r = f >> 4;
+    const unsigned row = r % (unsigned)p.rowsPad, chunk = r / (unsigned)p.rowsPad;
+    const int k = chunk * 16 + k16;
+    const int eU = *reinterpret_cast<const int*>(p.dst);
+    float u[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) u[t] = 0.f;
+    if ((int)row < p.rows && k < p.K) {
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+        const bool fwd = p.role == REFID_ROLE_WINO_FWD;
+        const float* g = fwd ? p.w + ((long long)row * p.I + k) * 9 : p.w + ((long long)k * p.I + row) * 9;
+        float gv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gv[t] = fwd ? g[t] : g[8 - t];              // dgrad: flipped taps
+        const float sc = p.oscale ? p.oscale[fwd ? row : k] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float acc = 0.f;                                               // (pack_fetch's order of additions: the fp32 U)
+#pragma unroll
+                for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 3; ++bb) acc += G[i][aa] * G[j][bb] * gv[aa * 3 + bb];
+                u[i * 4 + j] = ldexpf(acc * sc, eU);                           // exact: a power of two, inside the fp32 range
+            }
+    }
+    const long long plane = (long long)p.rowsPad * 16;
+    _Float16* dst = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(p.dst) + W3H_HEADER) +
+                    ((long long)chunk * 32 * p.rowsPad + row) * 16 + k16;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+        const float v = u[xi];
+        const _Float16 h = (_Float16)v;
+        dst[(xi * 2 + 0) * plane] = h;
+        dst[(xi * 2 + 1) * plane] = (_Float16)(v - (float)h);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_wino3h_kernel(const PackArgs p) {
+    const unsigned total = (unsigned)p.nchunks * p.rowsPad * 16;
+    for (unsigned f = blockIdx.x * 256u + threadIdx.x; f < total; f += gridDim.x * 256u) pack_wino3h_weight(p, f);
+}
+
 // ---- all packings of a model in ONE launch (refid_pack_batch): the table lives in device memory, a workgroup finds its
 // entry by binary search over the entries' first block.  ~220 dependent 6-20 us launches per optimiser step become one.
 struct PackEntry {
     PackArgs p;
-    int kind;                  // 0 pack_kernel (fp32 / bf16), 1 split (modes 0-2), 2 1x1 split, 3 Winograd x six, 4 out = a * b (vectors)
+    int kind;                  // 0 pack_kernel (fp32 / bf16), 1 split (modes 0-2), 2 1x1 split, 3 Winograd x six, 4 out = a * b (vectors),
+                               // 5 Winograd x three fp16 products (needs refid_pack_batch_prepass before the batch)
     int planes, mode;
     int blk0, nblk;            // this entry's workgroups: [blk0, blk0 + nblk)
     long long total;           // elements
@@ -373,6 +464,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __rest
     const long long e0 = (long long)(blockIdx.x - en.blk0) * 256 + threadIdx.x;
     if (kind == 3) {                                         // (total = weights, < 2^31: refid_pack_entry_fill)
         for (unsigned f = (unsigned)e0; f < (unsigned)total; f += (unsigned)stride) pack_wino6_weight(p, f);
+    } else if (kind == 5) {
+        for (unsigned f = (unsigned)e0; f < (unsigned)total; f += (unsigned)stride) pack_wino3h_weight(p, f);
     } else if (total < 0x7fffffffLL) {
         for (unsigned e = (unsigned)e0; e < (unsigned)total; e += (unsigned)stride) {
             switch (kind) {
@@ -392,6 +485,14 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __rest
             }
         }
     }
+}
+
+// the scale exponents of every kind-5 record of a table (one workgroup per record; the others leave at once)
+__global__ __launch_bounds__(1024) void pack_prepass_kernel(const PackEntry* __restrict__ table, int n) {
+    const PackEntry& en = table[blockIdx.x];
+    if (en.kind != 5) return;
+    const PackArgs p = en.p;
+    pack_absmax_block(p);
 }
 
 int pack_geometry(int role, int o, int i, int kh, int kw, int kc, int bn, PackArgs* p) {
@@ -506,6 +607,30 @@ extern "C" int refid_pack_conv_weights_wino6(const float* w, const float* oscale
     return 0;
 }
 
+extern "C" size_t refid_packed_weight_wino3h_bytes(int role, int o, int i, int bn) {
+    PackArgs p;
+    if (role != REFID_ROLE_WINO_FWD && role != REFID_ROLE_WINO_DGRAD) return 0;
+    if (pack_geometry(role, o, i, 3, 3, 16, bn, &p)) return 0;
+    return (size_t)W3H_HEADER + (size_t)p.nchunks * 16 * 2 * p.rowsPad * 16 * 2;
+}
+
+extern "C" int refid_pack_conv_weights_wino3h(const float* w, const float* oscale, void* packed, int role, int o, int i,
+                                              int bn, void* stream) {
+    PackArgs p;
+    REFID_CHECK(w && packed, "pack_wino3h: null pointer");
+    REFID_CHECK((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "pack_wino3h: the packing must be 16-byte aligned");
+    REFID_CHECK(role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD, "pack_wino3h: Winograd roles only");
+    REFID_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_wino3h: bad geometry");
+    p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
+    const long long total = (long long)p.nchunks * p.rowsPad * 16;                 // one thread per weight
+    REFID_CHECK(total * 32 < 0x7fffffffLL, "pack_wino3h: packing of %lld elements exceeds the 32-bit index range", total * 32);
+    hipLaunchKernelGGL(pack_absmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+    REFID_LAUNCH_CHECK("pack_conv_weights_wino3h/absmax");
+    hipLaunchKernelGGL(pack_wino3h_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+    REFID_LAUNCH_CHECK("pack_conv_weights_wino3h");
+    return 0;
+}
+
 // ---- batched packing ------------------------------------------------------------------------------------------------
 extern "C" size_t refid_pack_entry_bytes(void) { return sizeof(PackEntry); }
 
@@ -557,6 +682,13 @@ extern "C" int refid_pack_entry_fill(void* entry_host, int kind, const float* w,
         p.bf16 = 1;
         en.total = (long long)p.nchunks * p.rowsPad * 16;    // WEIGHTS (one thread each writes its 48 plane entries)
         REFID_FILL_CHECK(en.total * 48 < 0x7fffffffLL, "pack_entry_fill: Winograd x six packing exceeds the 32-bit index range");
+    } else if (kind == 5) {
+        REFID_FILL_CHECK((role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD) && kh == 3 && kw == 3, "pack_entry_fill: Winograd roles, 3x3");
+        REFID_FILL_CHECK((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "pack_entry_fill: the fp16 Winograd packing must be 16-byte aligned");
+        REFID_FILL_CHECK(pack_geometry(role, o, i, 3, 3, 16, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        p.bf16 = 1;
+        en.total = (long long)p.nchunks * p.rowsPad * 16;    // WEIGHTS (one thread each writes its 32 plane entries)
+        REFID_FILL_CHECK(en.total * 32 < 0x7fffffffLL, "pack_entry_fill: Winograd x three packing exceeds the 32-bit index range");
     } else {
         REFID_FILL_CHECK(false, "pack_entry_fill: unknown kind %d", kind);
     }
@@ -575,13 +707,23 @@ extern "C" int refid_pack_table_check(const void* table_host, int n) {
     const PackEntry* t = reinterpret_cast<const PackEntry*>(table_host);
     long long blk = 0;
     for (int k = 0; k < n; ++k) {
-        REFID_FILL_CHECK(t[k].kind >= 0 && t[k].kind <= 4 && t[k].total > 0 && t[k].nblk >= 1,
+        REFID_FILL_CHECK(t[k].kind >= 0 && t[k].kind <= 5 && t[k].total > 0 && t[k].nblk >= 1,
                          "pack_table_check: record %d was never filled (kind %d, total %lld)", k, t[k].kind, t[k].total);
         REFID_FILL_CHECK(t[k].blk0 == blk, "pack_table_check: record %d starts at block %d, expected %lld", k, t[k].blk0, blk);
         blk += t[k].nblk;
     }
     REFID_FILL_CHECK(blk < 0x7fffffffLL, "pack_table_check: too many workgroups");
     return (int)blk;
+}
+
+// The scale exponents of the table's kind-5 records (Winograd x three fp16 products: max |w| per tensor): one launch, BEFORE
+// refid_pack_batch on the same stream, whenever the table holds such records (a no-op for the others).
+extern "C" int refid_pack_batch_prepass(const void* table_dev, int n, void* stream) {
+    REFID_CHECK(table_dev != nullptr && n > 0, "pack_batch_prepass: empty table");
+    hipLaunchKernelGGL(pack_prepass_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackEntry*>(table_dev), n);
+    REFID_LAUNCH_CHECK("pack_batch_prepass");
+    return 0;
 }
 
 extern "C" int refid_pack_batch(const void* table_dev, int n, int nblocks, void* stream) {

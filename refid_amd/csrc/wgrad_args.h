@@ -31,6 +31,7 @@ int refid_launch_slab_fold(const float* slabs, float* part, long long slabFloats
 
 // wgrad_pws.hip: streaming 1x1 weight gradient (LDS-DMA ring, fp32 MFMA); geometry of its slabs [split][CoP][CiP]
 bool refid_wgrad_pws_ok(const refid_wgrad_desc* d);
+int refid_wgrad_pws_pixels_per_buffer(const refid_wgrad_desc* d);
 void refid_wgrad_pws_geo(const refid_wgrad_desc* d, int* ncoT, int* nciT, int* nsplit, int* CoP, int* CiP);
 int refid_wgrad_pws_launch(const refid_wgrad_desc* d, const WgKArgs& a, int nciT, int ncoT, hipStream_t st);
 

@@ -207,6 +207,13 @@ bool refid_wgrad_pws_ok(const refid_wgrad_desc* d) {
     return npix * d->ld_g * 4 < lim && npix * d->ld_a * 4 < lim && (!d->c_b || npix * d->ld_b * 4 < lim);
 }
 
+// pixels per ring buffer of the tile this geometry takes (the patch form's row width must be a multiple of it); 0: not eligible
+int refid_wgrad_pws_pixels_per_buffer(const refid_wgrad_desc* d) {
+    PwsPlan p;
+    if (!pws_plan(d, p)) return 0;
+    return pws_pb(p.ow, p.wi);
+}
+
 void refid_wgrad_pws_geo(const refid_wgrad_desc* d, int* ncoT, int* nciT, int* nsplit, int* CoP, int* CiP) {
     PwsPlan p;
     pws_plan(d, p);

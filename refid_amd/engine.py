@@ -237,6 +237,11 @@ MFMA_SPLIT = int(os.environ.get("REFID_MFMA_SPLIT", "0"))
 # bf16 products per fp32 product (refid_conv2d algo 5, csrc/conv_wino6.hip): same error class as the fp32 Winograd tile at
 # 2.67x fewer matrix-pipe cycles.  0 = fp32 Winograd tile everywhere.
 WINO6 = os.environ.get("REFID_WINO6", "1") != "0"
+# ... and, round 6, as THREE fp16 products on two-plane operands (refid_conv_desc.mfma_terms = 3): half the MFMAs and two
+# thirds of the U bytes of the six-bf16-product form for a per-product error of ~2^-22 instead of ~2^-24 (still below the fp32
+# accumulation's own error; fp16's range is handled by exact power-of-two scales, csrc/conv_wino6.hip).  REFID_WINO_F16=0: the
+# six-product form (A/B switch).
+WINO_F16 = os.environ.get("REFID_WINO_F16", "1") != "0"
 WINO6_MIN_CO = int(os.environ.get("REFID_WINO6_MIN_CO", "32"))
 WINO6_THIN = os.environ.get("REFID_WINO6_THIN", "1") != "0"        # pred's forward (32 -> 3) on the 32-channel Winograd x six form
 # conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
@@ -260,8 +265,13 @@ WGRAD_WINO_MIN_CO = int(os.environ.get("REFID_WGRAD_WINO_MIN_CO", "32"))
 # weight gradients run on the MAIN stream at every batch size, a launch is a link of the one chain, and 24 wins everywhere:
 # B=8 400.2 / 399.9 vs 404.9 / 403.5 ms (alternating, one box; 12 steps: 405.0 / 402.8), B=1 99.6 -> 98.0 ms.
 _WG_ENV = os.environ.get("REFID_WGRAD_GROUP")
-WGRAD_GROUP = max(1, min(24, int(_WG_ENV))) if _WG_ENV else (24 if os.environ.get("REFID_OVERLAP_WGRAD", "0") == "0" else 8)
+WGRAD_GROUP = max(1, min(24, int(_WG_ENV))) if _WG_ENV else (8 if OVERLAP_WGRAD else 24)
 WGRAD_GROUP_SMALL = max(1, min(24, int(_WG_ENV))) if _WG_ENV else 24
+# What a waiting weight-gradient call keeps alive: the (gradient, input) tensors of its step, which BPTT would otherwise have
+# released -- measured 128 GB (all 23 steps per launch) against 90 GB (8 per launch) at B=8, 256 x 256: ~4.9 KB per pixel and
+# time step.  Engine._set_wgrad_groups shrinks the group when that would not fit into half of the HBM still free when BPTT
+# starts (a larger crop / T / batch then runs in smaller groups instead of running out of memory).
+WGRAD_KEEP_BYTES_PER_PIXEL_STEP = 4900
 # Experiment (REFID_EXPERIMENTAL_TILES builds only): Winograd weight gradient with six exact-split bf16 products per fp32
 # product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
 # are transformed and split on the fly, ~19 VALU per MFMA.  Off.
@@ -278,6 +288,19 @@ WGRAD_F4_MIN_HW = int(os.environ.get("REFID_WGRAD_F4_MIN_HW", "16"))
 # conv_down's weight gradient (4x4 stride 2) on the same kernel through the input's four parity phases (algo 7: 12 instead of
 # 16 fp32 MFMA-units per output pixel).  REFID_WGRAD_DOWN_F4=0: the direct tile.
 WGRAD_DOWN_F4 = os.environ.get("REFID_WGRAD_DOWN_F4", "1") != "0"
+
+
+def wgrad_group_cap(n, pixels, device, free_bytes=None):
+    """Largest group size <= n whose waiting operands (WGRAD_KEEP_BYTES_PER_PIXEL_STEP per pixel and step) fit into half of
+    the free HBM: the device's free memory plus what torch's caching allocator holds unallocated."""
+    if n <= 1 or pixels <= 0:
+        return n
+    if free_bytes is None:
+        if torch.device(device).type != "cuda":
+            return n
+        free_bytes = torch.cuda.mem_get_info(device)[0] + (torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+    per_step = pixels * WGRAD_KEEP_BYTES_PER_PIXEL_STEP
+    return max(1, min(n, int(free_bytes // 2 // per_step)))
 
 
 def flush_wgrads(device):
@@ -433,13 +456,15 @@ class ConvOp:
         # ... and thin outputs (pred, 32 -> 3): the direct fp32 tile pads them to 32 GEMM columns and is bound by the fp32
         # matrix pipe (100 us per launch at B=8); on the 32-channel Winograd x six form the padding costs cheap bf16 MFMAs
         thin6 = WINO6_THIN and kind == "conv" and k == 3 and self.co <= 4 and self.ci % 16 == 0 and USE_WINOGRAD
+        self.w6_f16 = WINO_F16                 # the packing's form: two fp16 planes + header (terms 3) or three bf16 planes
+        self.w6_terms = 3 if self.w6_f16 else 0
         if WINO6 and not bf16 and ((self.f_algo == 1 and self.co >= WINO6_MIN_CO) or thin6) and self.ci % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) < 2 ** 31 - 1:
-            self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) // 2,
+            self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci, self.w6_f16) // 2,
                                    dtype=torch.bfloat16, device=dev)
         if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci >= WINO6_MIN_CO and self.co % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) < 2 ** 31 - 1:
-            self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) // 2,
+            self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci, self.w6_f16) // 2,
                                    dtype=torch.bfloat16, device=dev)
         # split-bf16 direct tile (algo 4): second packing next to the default one
         terms = 1 if bf16 else (split or ConvOp.default_split or MFMA_SPLIT)
@@ -507,9 +532,9 @@ class ConvOp:
         if self.wdp6 is not None:
             plan.add_split(self.w, ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, 3, self.wdp6, oscale=self.scale)
         if self.wp6 is not None:
-            plan.add_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, self.wp6, oscale=self.scale)
+            plan.add_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, self.wp6, oscale=self.scale, f16=self.w6_f16)
         if self.wd6 is not None:
-            plan.add_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, self.wd6, oscale=self.scale)
+            plan.add_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, self.wd6, oscale=self.scale, f16=self.w6_f16)
         if self.wps is not None:
             plan.add_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, self.s_planes, self.wps, oscale=self.scale)
         if self.wds is not None:
@@ -551,9 +576,9 @@ class ConvOp:
         if self.wdp6 is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, planes=3, out=self.wdp6, oscale=self.scale)
         if self.wp6 is not None:
-            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, out=self.wp6, oscale=self.scale)
+            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, out=self.wp6, oscale=self.scale, f16=self.w6_f16)
         if self.wd6 is not None:
-            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, out=self.wd6, oscale=self.scale)
+            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, out=self.wd6, oscale=self.scale, f16=self.w6_f16)
         if self.wps is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, planes=self.s_planes,
                                         out=self.wps, oscale=self.scale)
@@ -605,7 +630,7 @@ class ConvOp:
             return out if plus is None else (out, o2)
         if self.wp6 is not None and self.split == 0 and (b is None or a.shape[3] % 16 == 0):
             ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=-(-self.f_rows // 64) * 64, in_b=b,
-                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5, **two)
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5, terms=self.w6_terms, **two)
             return out if plus is None else (out, o2)
         if self.wpp6 is not None and a.shape[3] % 16 == 0 and (b is None or b.shape[3] % 16 == 0):
             ops.conv2d(a, self.wpp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
@@ -678,7 +703,7 @@ class ConvOp:
             return out if plus is None else (out, o2)
         if self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO:
             ops.conv2d(g, self.wd6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
-                       res=res, mask=mask, slope_mask=slope_mask, algo=5, **two)
+                       res=res, mask=mask, slope_mask=slope_mask, algo=5, terms=self.w6_terms, **two)
             return out if plus is None else (out, o2)
         if self.wdp6 is not None and cnt > 32 and g.shape[3] % 16 == 0:
             ops.conv2d(g, self.wdp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
@@ -851,9 +876,12 @@ def finish_wgrads(op_list):
         for o in op_list:
             o.finish_wgrad(batched)
     finally:
-        if batched:
-            ops.wgrad_finish_flush()                       # (also after an error: nothing stays queued in the library)
-        ops.rows_sum_flush()                               # the per-channel sums queued since rows_sum_defer() (no-op otherwise)
+        try:
+            if batched:
+                ops.wgrad_finish_flush()                   # (also after an error: nothing stays queued in the library)
+        finally:
+            ops.rows_sum_flush()                           # the per-channel sums queued since rows_sum_defer() (no-op otherwise;
+                                                           #  its own `finally`: a failing slab flush must not leave them queued)
 
 
 class _Trunk:
@@ -994,10 +1022,12 @@ class Engine:
         img_ops = {id(o) for e in self.img for o in e.values()} | {id(self.head_img), id(self.head_ev)}
         self.recurrent_ops = [o for o in self.all_ops if id(o) not in img_ops]
 
-    def _set_wgrad_groups(self, T, small=False):
+    def _set_wgrad_groups(self, T, small=False, pixels=0):
         """Group size of the deferred weight-gradient launches: min(WGRAD_GROUP, T) on the recurrent convs (a group
-        never outlives a sweep; small batches: WGRAD_GROUP_SMALL), 1 elsewhere."""
+        never outlives a sweep; small batches: WGRAD_GROUP_SMALL), 1 elsewhere; capped by the HBM that is still free
+        (`pixels` = B H W of the step: a waiting call keeps its step's tensors alive)."""
         n = max(1, min(WGRAD_GROUP_SMALL if small else WGRAD_GROUP, T))
+        n = wgrad_group_cap(n, pixels, self.device)
         for o in self.recurrent_ops:
             o.w_group = n
 
@@ -1430,7 +1460,7 @@ class Engine:
         if ROWS_DEFER:
             ops.rows_sum_defer()              # per-channel gradient sums of this half: queued until finish_wgrads
         B, T, H, W = c["B"], c["T"], c["H"], c["W"]
-        self._set_wgrad_groups(T, use_pipeline(B, H, W))
+        self._set_wgrad_groups(T, use_pipeline(B, H, W), B * H * W)
         dev = gout.device
         gout = gout.contiguous()
         xb, head, e_all, Sb = c["xb"], c["head"], c["e_all"], c["Sb"]

@@ -123,14 +123,18 @@ def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscal
     return out
 
 
-def packed_weight_wino6_bytes(role, o, i):
-    return lib().refid_packed_weight_wino6_bytes(role, o, i, 64)
-
-
-def pack_conv_weights_wino6(w, role, o, i, out=None, oscale=None):
-    """Winograd-domain weights as three bf16 planes for conv2d(algo=5); role = ROLE_WINO_FWD / ROLE_WINO_DGRAD."""
+def packed_weight_wino6_bytes(role, o, i, f16=False):
+    """Bytes of the Winograd-domain packing for conv2d(algo=5): three bf16 planes (terms 0 / 6), or -- f16 -- a 64-byte header
+    + two fp16 planes (terms 3)."""
     L = lib()
-    nb = L.refid_packed_weight_wino6_bytes(role, o, i, 64)
+    return L.refid_packed_weight_wino3h_bytes(role, o, i, 64) if f16 else L.refid_packed_weight_wino6_bytes(role, o, i, 64)
+
+
+def pack_conv_weights_wino6(w, role, o, i, out=None, oscale=None, f16=False):
+    """Winograd-domain weights as three bf16 planes for conv2d(algo=5); role = ROLE_WINO_FWD / ROLE_WINO_DGRAD.
+    f16: the two-fp16-plane packing of conv2d(algo=5, terms=3) (scaled by a per-tensor power of two kept in its header)."""
+    L = lib()
+    nb = packed_weight_wino6_bytes(role, o, i, f16)
     if nb == 0:
         raise _lib.RefidHipError("pack_conv_weights_wino6: bad geometry")
     if not w.is_contiguous():
@@ -139,8 +143,9 @@ def pack_conv_weights_wino6(w, role, o, i, out=None, oscale=None):
         out = torch.empty(nb // 2, dtype=torch.bfloat16, device=w.device)
     elif out.numel() * out.element_size() != nb:
         raise _lib.RefidHipError("pack_conv_weights_wino6: out has the wrong size")
-    check(L.refid_pack_conv_weights_wino6(w.data_ptr(), oscale.data_ptr() if oscale is not None else None, out.data_ptr(),
-                                          role, o, i, 64, _stream()), "refid_pack_conv_weights_wino6")
+    fn = L.refid_pack_conv_weights_wino3h if f16 else L.refid_pack_conv_weights_wino6
+    check(fn(w.data_ptr(), oscale.data_ptr() if oscale is not None else None, out.data_ptr(), role, o, i, 64, _stream()),
+          "refid_pack_conv_weights_wino3h" if f16 else "refid_pack_conv_weights_wino6")
     return out
 
 
@@ -246,6 +251,8 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
         name = "conv_wino_kernel<1, 2>" if cout <= 32 else "conv_wino_kernel<2, 1>"
     if algo == 5:
         name = "conv_wino6_kernel<2>" if cout > 32 else "conv_wino6_kernel<1>"     # 64- / 32-channel workgroup tile
+        if terms == 3:
+            name = name[:-1] + ", true>"                                           # three fp16 products
     if algo == 4:
         name = "conv_split_kernel<%d>" % (terms or 6)
     if algo == 3:
@@ -280,7 +287,7 @@ def _conv2d_cached(in_a, w_packed, out, kh, kw, stride, pad, mode, cout, cout_pa
     global lib, DESC_CACHE
     key = (kh, kw, stride, pad, mode, cout, cout_pad, co_base, slope_pre, slope_post, slope_mask, algo, terms, mask_mode,
            WINO_TILE, WINO_SPLIT, _sig(in_a), _sig(in_b), _sig(out), _sig(res), _sig(mask), _sig(add2), _sig(out2),
-           bias is not None, in_a.dtype, out.dtype)
+           bias is not None, in_a.dtype, out.dtype, in_a.device)
     ent = _DESC_CACHE.get(key)
     if ent is None:
         # first call with this signature: the validating path, with the launch intercepted to keep its descriptor
@@ -306,12 +313,13 @@ def _conv2d_cached(in_a, w_packed, out, kh, kw, stride, pad, mode, cout, cout_pa
             lib, DESC_CACHE = keep_lib, keep_flag
         _DESC_CACHE[key] = (seen[0], int(seen[0].ws_bytes))
         return out
-    d, ws_bytes = ent
+    d, ws_bytes = ConvDesc.from_buffer_copy(ent[0]), ent[1]     # (a private copy: the recorded descriptor is shared by threads)
     if _REQUIRE_CUDA and not (in_a.is_cuda and out.is_cuda):
         raise _lib.RefidHipError("conv2d: expected CUDA tensors")
     ptrs = (in_a.data_ptr(), None if in_b is None else in_b.data_ptr(), w_packed.data_ptr(),
             None if bias is None else bias.data_ptr(), out.data_ptr(), None if res is None else res.data_ptr(),
-            None if mask is None else mask.data_ptr(), None if add2 is None else add2.data_ptr(),
+            None if mask is None else mask.data_ptr(),
+            None if (add2 is None or out2 is None) else add2.data_ptr(),      # (as the validating path: add2 only with out2)
             None if out2 is None else out2.data_ptr())
     for nm, p in zip(_DESC_PTRS, ptrs):
         if p is not None and p % 16 != 0 and nm not in ("w_packed", "bias"):
@@ -366,7 +374,8 @@ def conv2d_wgrad(g, in_a, dw, *, kh, kw, stride=1, pad=0, in_b=None, db=None, i_
     d.o_real = dw.shape[0]
     d.algo = algo
     d.phase = phase
-    # more: up to 3 further (g, in_a, in_b) triples -- other time steps of the same conv, added in the same launch
+    # more: up to 23 further (g, in_a, in_b) triples (refid_wgrad_desc.groups <= 24) -- other time steps of the same conv, added
+    # in the same launch
     if more:
         d.groups = 1 + len(more)
         for k, (g2, a2, b2) in enumerate(more):
@@ -732,8 +741,8 @@ class PackPlan:
     def add_split(self, w, role, bn, kh, kw, o, i, planes, out, oscale=None):
         self._add(2 if kh == 1 and kw == 1 else 1, w, oscale, out, role, o, i, kh, kw, 8, bn, planes)
 
-    def add_wino6(self, w, role, o, i, out, oscale=None):
-        self._add(3, w, oscale, out, role, o, i, 3, 3, 16, 64, 3)
+    def add_wino6(self, w, role, o, i, out, oscale=None, f16=False):
+        self._add(5 if f16 else 3, w, oscale, out, role, o, i, 3, 3, 16, 64, 2 if f16 else 3)
 
     def add_mul_vec(self, a, b, out):
         self._add(4, a, b, out, o=a.numel())
@@ -757,6 +766,8 @@ class PackPlan:
         return self
 
     def run(self):
+        if any(it[0] == 5 for it in self.items):            # the fp16 Winograd packings' scale exponents (max |w| per tensor) first
+            check(lib().refid_pack_batch_prepass(self.table.data_ptr(), len(self.items), _stream()), "refid_pack_batch_prepass")
         check(lib().refid_pack_batch(self.table.data_ptr(), len(self.items), self.nblocks, _stream()), "refid_pack_batch")
 
 

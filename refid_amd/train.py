@@ -62,6 +62,7 @@ SCHEDULERS = ("TrueCosineAnnealingLR", "MultiStepLR", "MultiStepRestartLR", "Cos
 
 class TwoImageEventRecurrentRestorationModel:
     PIXEL_LOSSES = ("CharbonnierLoss",)            # the only one the reference's configs for this model use
+    LOWLR_RATIO = 0.1                              # twoImage_event_recurrent_model.py:81 (`ratio`)
 
     def __init__(self, opt):
         self.opt = opt
@@ -112,6 +113,10 @@ class TwoImageEventRecurrentRestorationModel:
         self.sqnorm = torch.zeros(ops.SQNORM_WORDS, dtype=torch.float64, device=self.device)
         self.step_count = 0
         self.cur_lr = self.base_lr
+        # the reference's optimizer has a SECOND, empty param group at lr * 0.1 ('module.offsets' / 'module.dcns' parameters,
+        # which this network does not have: twoImage_event_recurrent_model.py:72-90); its lr is tracked only so that a
+        # reference-layout `.state` carries the two groups / two-entry scheduler lists torch's load_state_dict insists on
+        self.cur_lr_low = self.base_lr * self.LOWLR_RATIO
         self.sched_epoch = 0
         # the collectives also run in a 1-rank process group (REFID_FORCE_GRADSYNC=1): lets a single-GPU box
         # exercise the exact RCCL code path of the multi-GPU job
@@ -129,8 +134,11 @@ class TwoImageEventRecurrentRestorationModel:
             self.sched_epoch += 1
             self.cur_lr = scheduler_lr(self.sched_type, self.sched_cfg, self.sched_epoch, self.base_lr, self.cur_lr,
                                        self.total_iter)
+            self.cur_lr_low = scheduler_lr(self.sched_type, self.sched_cfg, self.sched_epoch, self.base_lr * self.LOWLR_RATIO,
+                                           getattr(self, "cur_lr_low", self.base_lr * self.LOWLR_RATIO), self.total_iter)
         if current_iter < warmup_iter:
             self.cur_lr = self.base_lr / warmup_iter * current_iter
+            self.cur_lr_low = self.base_lr * self.LOWLR_RATIO / warmup_iter * current_iter
 
     def get_current_learning_rate(self):
         return [self.cur_lr]
@@ -359,8 +367,9 @@ class TwoImageEventRecurrentRestorationModel:
         """base_model.py:283-306: {opt['path']['training_states']}/{iter}.state with one optimizer / scheduler entry.
         Default: the fused AdamW's state as it lives here, two flat arenas.  reference_layout=True (or
         opt['path']['state_layout'] == 'reference'): the layout the REFERENCE writes -- `torch.optim.AdamW.state_dict()`
-        (per-parameter `step` / `exp_avg` / `exp_avg_sq` keyed by the parameter's index in named_parameters order, one
-        param group) and a torch scheduler-style dict -- so basicsr's own `resume_training` (base_model.py:308-323:
+        (per-parameter `step` / `exp_avg` / `exp_avg_sq` keyed by the parameter's index in named_parameters order; TWO
+        param groups like the reference's optimizer, twoImage_event_recurrent_model.py:88-90: every parameter in the first,
+        the second -- lr * 0.1 -- empty) and a torch scheduler-style dict with two-entry `base_lrs` / `_last_lr` -- so basicsr's own `resume_training` (base_model.py:308-323:
         `optimizer.load_state_dict` / `scheduler.load_state_dict`) can continue a run started here.  `resume_training`
         below reads both."""
         if self.rank != 0 or current_iter == -1:
@@ -378,17 +387,20 @@ class TwoImageEventRecurrentRestorationModel:
             group = {"lr": self.cur_lr, "betas": tuple(self.betas), "eps": self.adam_eps, "weight_decay": self.weight_decay,
                      "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                      "fused": None, "initial_lr": self.base_lr, "params": list(range(len(st)))}
-            sched = {"last_epoch": self.sched_epoch, "_step_count": self.sched_epoch + 1, "base_lrs": [self.base_lr],
-                     "_last_lr": [self.cur_lr], "_get_lr_called_within_step": False}
+            low = dict(group, lr=self.cur_lr_low, initial_lr=self.base_lr * self.LOWLR_RATIO, params=[])
+            sched = {"last_epoch": self.sched_epoch, "_step_count": self.sched_epoch + 1,
+                     "base_lrs": [self.base_lr, self.base_lr * self.LOWLR_RATIO],
+                     "_last_lr": [self.cur_lr, self.cur_lr_low], "_get_lr_called_within_step": False}
             sched.update({k: v for k, v in self.sched_cfg.items() if isinstance(v, (int, float, list, tuple))})
             state = {"epoch": epoch, "iter": current_iter,
-                     "optimizers": [{"state": st if self.step_count else {}, "param_groups": [group]}],
+                     "optimizers": [{"state": st if self.step_count else {}, "param_groups": [group, low]}],
                      "schedulers": [sched]}
         else:
             state = {"epoch": epoch, "iter": current_iter,
                      "optimizers": [{"type": "refid_amd.fused_adamw", "step": self.step_count,
                                      "exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()}],
-                     "schedulers": [{"type": self.sched_type, "last_epoch": self.sched_epoch, "lr": self.cur_lr}]}
+                     "schedulers": [{"type": self.sched_type, "last_epoch": self.sched_epoch, "lr": self.cur_lr,
+                                     "lr_low": self.cur_lr_low}]}
         save_path = os.path.join(self.opt["path"]["training_states"], f"{current_iter}.state")
         torch.save(state, save_path)
         return save_path
@@ -441,8 +453,10 @@ class TwoImageEventRecurrentRestorationModel:
                              "torch.optim.AdamW state_dict)")
         if "lr" in sc:
             self.sched_epoch, self.cur_lr = int(sc["last_epoch"]), float(sc["lr"])
+            self.cur_lr_low = float(sc.get("lr_low", self.cur_lr * self.LOWLR_RATIO))
         elif "_last_lr" in sc:                                   # torch scheduler.state_dict()
             self.sched_epoch, self.cur_lr = int(sc["last_epoch"]), float(sc["_last_lr"][0])
+            self.cur_lr_low = float(sc["_last_lr"][1]) if len(sc["_last_lr"]) > 1 else self.cur_lr * self.LOWLR_RATIO
         else:
             raise ValueError("resume_training: unknown scheduler entry (no 'lr' / '_last_lr')")
 

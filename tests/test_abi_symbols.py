@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(libpath):
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, f"declared in refid_hip.h but not exported: {missing}"
     lib.refid_abi_version.restype = ctypes.c_int
-    assert lib.refid_abi_version() == 8
+    assert lib.refid_abi_version() == 9
 
 
 def test_python_binding_loads_and_host_queries_work(libpath):

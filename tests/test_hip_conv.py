@@ -461,7 +461,7 @@ def test_errors_are_loud():
 # ---------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) tile (algo=1): same contract as the direct tile
 # ---------------------------------------------------------------------------------------------
-def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_post=1.0, mask=False, algo=1):
+def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_post=1.0, mask=False, algo=1, terms=0):
     ops = _ops()
     Ci = Ca + Cb
     xa = rnd(N, Ca, H, W, seed=1)
@@ -478,14 +478,14 @@ def run_wino(N, H, W, Ca, Cb, Co, bias=True, res=False, slope_pre=1.0, slope_pos
     if mask:
         ref = ref * torch.where(m > 0, 1.0, 0.3)
     if algo == 5:
-        wp = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_FWD, Co, Ci)
+        wp = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_FWD, Co, Ci, f16=terms == 3)
     else:
         wp = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
     copad = -(-Co // 64) * 64
     Cop = -(-Co // 4) * 4
     outbuf = torch.full((N, H, W, Cop), 7.0, device="cuda")
     out = outbuf[..., :Co]
-    ops.conv2d(nhwc(xa), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=copad, algo=algo,
+    ops.conv2d(nhwc(xa), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=copad, algo=algo, terms=terms,
                in_b=nhwc(xb) if Cb else None, bias=b.float().cuda() if bias else None,
                res=nhwc(r) if res else None, mask=nhwc(m) if mask else None,
                slope_pre=slope_pre, slope_post=slope_post, slope_mask=0.3)
@@ -523,90 +523,50 @@ def test_winograd_fused_epilogues():
     # thin outputs (pred: 32 -> 3, written into a 4-channel buffer), one and four channels
     (1, 16, 32, 32, 0, 3), (2, 9, 17, 32, 0, 3), (1, 8, 32, 16, 0, 1), (1, 8, 32, 32, 0, 4),
 ])
-@pytest.mark.parametrize("tile", [1, 3])
-def test_wino6_forward_geometries(cfg, tile):
+@pytest.mark.parametrize("terms", [0, 3])
+def test_wino6_forward_geometries(cfg, terms):
     """Ragged tiles, a partial last 16-channel chunk (36, 8, 48 channels), a partial channel tile (96, 40), two sources,
-    and a small grid that takes the split-K form (512 -> 256 at 8x8); on the 4-wave tile (1) and the wide 8-wave tile with
-    the LDS-shared weight ring (3; more than 32 output channels only -- smaller layers stay on the 4-wave tile)."""
-    ops = _ops()
-    if tile == 3:
-        _need_experimental()
-    old, ops.WINO_TILE = ops.WINO_TILE, tile
-    try:
-        run_wino(*cfg, algo=5)
-    finally:
-        ops.WINO_TILE = old
+    and a small grid that takes the split-K form (512 -> 256 at 8x8); six bf16 products (terms 0) and three fp16 products on
+    scaled two-plane operands (terms 3, round 6)."""
+    run_wino(*cfg, algo=5, terms=terms)
 
 
-def test_wino6_wide_tile_is_bit_identical_to_the_four_wave_tile():
-    """Same chunk order, same products: the wide tile (LDS-DMA weight ring, 8x32 pixels) returns the 4-wave tile's bits, so
-    an experiment that is switched on changes no result.  Two sources, residual + mask epilogue, ragged size."""
-    ops = _ops()
-    _need_experimental()
-    g = torch.Generator(device="cuda").manual_seed(5)
-    N, H, W, Ca, Cb, Co = 2, 44, 70, 64, 64, 128
-    xa = torch.randn(N, H, W, Ca, device="cuda", generator=g)
-    xb = torch.randn(N, H, W, Cb, device="cuda", generator=g)
-    w = torch.randn(Co, Ca + Cb, 3, 3, device="cuda", generator=g) * 0.05
-    r = torch.randn(N, H, W, Co, device="cuda", generator=g)
-    m = torch.randn(N, H, W, Co, device="cuda", generator=g)
-    b = torch.randn(Co, device="cuda", generator=g)
-    wp = ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, Co, Ca + Cb)
-    outs = []
-    for tile in (1, 3):
-        old, ops.WINO_TILE = ops.WINO_TILE, tile
-        olds, ops.WINO_SPLIT = ops.WINO_SPLIT, 0           # (split-K changes the summation order of the small 4-wave grid)
-        try:
-            out = torch.empty(N, H, W, Co, device="cuda")
-            ops.conv2d(xa, wp, out, kh=3, kw=3, pad=1, cout=Co, cout_pad=128, in_b=xb, bias=b, res=r, mask=m, slope_pre=0.1,
-                       slope_mask=0.2, algo=5)
-            outs.append(out)
-        finally:
-            ops.WINO_TILE, ops.WINO_SPLIT = old, olds
-    assert torch.equal(outs[0], outs[1])
+@pytest.mark.parametrize("terms", [0, 3])
+def test_wino6_fused_epilogues(terms):
+    kw = dict(algo=5, terms=terms)
+    run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04, **kw)
+    run_wino(1, 16, 32, 64, 0, 64, res=True, **kw)
+    run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0, **kw)
+    run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1, **kw)
+    run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True, **kw)
+    # the 32-output-channel form: decoder 2's trunk (main.0 two-source + LeakyReLU(.1), ReLU, + identity) and its
+    # input gradients (residual + activation mask), a ragged size with a partial channel tile
+    run_wino(1, 16, 32, 32, 32, 32, slope_pre=0.1, **kw)
+    run_wino(1, 16, 32, 32, 0, 32, slope_pre=0.0, **kw)
+    run_wino(1, 16, 32, 32, 0, 32, res=True, **kw)
+    run_wino(1, 8, 32, 32, 0, 32, bias=False, res=True, mask=True, **kw)
+    run_wino(1, 9, 37, 64, 0, 20, bias=False, res=True, mask=True, slope_post=0.0, **kw)
 
 
-@pytest.mark.parametrize("tile", [1, 3])
-def test_wino6_fused_epilogues(tile):
-    ops = _ops()
-    if tile == 3:
-        _need_experimental()
-    old, ops.WINO_TILE = ops.WINO_TILE, tile
-    try:
-        run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04, algo=5)
-        run_wino(1, 16, 32, 64, 0, 64, res=True, algo=5)
-        run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0, algo=5)
-        run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1, algo=5)
-        run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True, algo=5)
-        # the 32-output-channel form: decoder 2's trunk (main.0 two-source + LeakyReLU(.1), ReLU, + identity) and its
-        # input gradients (residual + activation mask), a ragged size with a partial channel tile
-        run_wino(1, 16, 32, 32, 32, 32, slope_pre=0.1, algo=5)
-        run_wino(1, 16, 32, 32, 0, 32, slope_pre=0.0, algo=5)
-        run_wino(1, 16, 32, 32, 0, 32, res=True, algo=5)
-        run_wino(1, 8, 32, 32, 0, 32, bias=False, res=True, mask=True, algo=5)
-        run_wino(1, 9, 37, 64, 0, 20, bias=False, res=True, mask=True, slope_post=0.0, algo=5)
-    finally:
-        ops.WINO_TILE = old
-
-
+@pytest.mark.parametrize("terms", [0, 3])
 @pytest.mark.parametrize("cfg", [(1, 16, 32, 64, 64), (1, 9, 24, 128, 64), (1, 8, 16, 256, 128), (1, 8, 8, 96, 40)])
-def test_wino6_dgrad(cfg):
+def test_wino6_dgrad(cfg, terms):
     ops = _ops()
     N, H, W, Ci, Co = cfg
     x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
     w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
     g = rnd(N, Co, H, W, seed=3)
     F.conv2d(x, w, None, 1, 1).backward(g)
-    wd = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_DGRAD, Co, Ci)
+    wd = ops.pack_conv_weights_wino6(w.float().cuda(), ops.ROLE_WINO_DGRAD, Co, Ci, f16=terms == 3)
     rp = -(-Ci // 64) * 64
     gd = nhwc(g)
     out = torch.empty(N, H, W, Ci, device="cuda")
-    ops.conv2d(gd, wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=rp, algo=5)
+    ops.conv2d(gd, wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=rp, algo=5, terms=terms)
     np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
     if Ci >= 128:       # row-range issue (two-source convs): second half of the rows
         half = Ci // 2
         o2 = torch.empty(N, H, W, half, device="cuda")
-        ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=rp, co_base=half, algo=5)
+        ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=rp, co_base=half, algo=5, terms=terms)
         np.testing.assert_allclose(nchw(o2).numpy(), x.grad[:, half:].numpy(), rtol=RTOL, atol=ATOL)
 
 
@@ -632,6 +592,63 @@ def test_wino6_accuracy_class_and_tiny_gradients():
     out = torch.empty(N, H, W, Co, device="cuda")
     ops.conv2d(nhwc(x * 1e-8), w6, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=64, algo=5)
     assert float((nchw(out) * 1e8 - ref).abs().max()) < 4e-6 * scale
+
+
+def test_wino_f16_accuracy_class_and_dynamic_range():
+    """Three fp16 products on two-plane operands (algo 5, mfma_terms 3; round 6).  The planes carry 22 bits and fp16's range is
+    bridged by exact power-of-two scales (U per packing, V per tile, online along K), so:
+    (a) O(1) data, K = 9 x 256: within 4e-6 of the output scale of the float64 convolution and within 2x the fp32 Winograd
+        tile's own deviation -- the six-product form's gate, unchanged;
+    (b) the same RELATIVE error for operands of magnitude 1e-8 and 1e+6, and for weights of magnitude 1e-6 / 1e+3 (no fixed
+        scale could do that inside fp16's 2^-14 .. 2^16);
+    (c) channels whose magnitude GROWS by 2^40 along K (every chunk 2^10 above the previous one: the accumulator rescale runs
+        at every chunk) and shrinks again: the error stays relative to the result;
+    (d) tiles of wildly different magnitude next to each other (per-tile scale), zero tiles and zero chunks."""
+    ops = _ops()
+    N, H, W, Ci, Co = 1, 32, 64, 256, 64
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, seed=2, scale=3.0 / np.sqrt(Ci * 9))
+
+    def run(xx, ww, terms=3, algo=5):
+        if algo == 5:
+            wp = ops.pack_conv_weights_wino6(ww.float().cuda(), ops.ROLE_WINO_FWD, Co, Ci, f16=terms == 3)
+        else:
+            wp = ops.pack_conv_weights(ww.float().cuda(), ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
+        out = torch.empty(N, H, W, Co, device="cuda")
+        ops.conv2d(nhwc(xx), wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=64, algo=algo, terms=terms if algo == 5 else 0)
+        return nchw(out)
+
+    ref = F.conv2d(x, w, None, 1, 1)
+    scale = float(ref.abs().max())
+    e3 = float((run(x, w) - ref).abs().max())
+    e6 = float((run(x, w, terms=0) - ref).abs().max())
+    e1 = float((run(x, w, algo=1) - ref).abs().max())
+    assert e3 < 4e-6 * scale and e3 < 2.0 * e1, (e3, e6, e1, scale)                       # (a)
+    for sx, sw in ((1e-8, 1.0), (1e6, 1.0), (1.0, 1e-6), (1.0, 1e3), (1e-8, 1e3)):          # (b)
+        xs, ws = (x * sx).float().double(), (w * sw).float().double()                       # (what the kernel is given)
+        r = F.conv2d(xs, ws, None, 1, 1)
+        assert float((run(xs, ws) - r).abs().max()) < 4e-6 * float(r.abs().max()), (sx, sw)
+    # (c) chunk c of the input channels scaled by 2^(10 c) for c < 5, falling again afterwards
+    ramp = torch.tensor([2.0 ** (10 * min(c, 9 - c)) if c < 10 else 1.0 for c in range(Ci // 16)], dtype=torch.float64)
+    xc = (x * ramp.repeat_interleave(16).view(1, Ci, 1, 1)).float().double()
+    r = F.conv2d(xc, w.float().double(), None, 1, 1)
+    assert float((run(xc, w) - r).abs().max()) < 4e-6 * float(r.abs().max())
+    # ... measured per output pixel too: a pixel whose window holds only the small channels' data is not drowned either
+    xz = xc.clone()
+    xz[:, 64:96] = 0.0                                       # the 2^40 chunks are zero chunks now
+    r = F.conv2d(xz, w.float().double(), None, 1, 1)
+    assert float((run(xz, w) - r).abs().max()) < 4e-6 * float(r.abs().max())
+    # (d) per-tile scales: image columns scaled by 2^(-20 .. +20), a zero band, compared PER COLUMN BAND
+    col = torch.tensor([2.0 ** (((c // 4) % 11 - 5) * 4) for c in range(W)], dtype=torch.float64)
+    col[20:28] = 0.0
+    xt = (x * col.view(1, 1, 1, W)).float().double()
+    r = F.conv2d(xt, w.float().double(), None, 1, 1)
+    got = run(xt, w)
+    for c0 in range(0, W, 4):
+        band = r[..., c0:c0 + 4].abs().max()
+        # (a band's window reaches one pixel into its neighbours: its error is relative to the largest of the three)
+        near = r[..., max(0, c0 - 4):c0 + 8].abs().max()
+        assert float((got[..., c0:c0 + 4] - r[..., c0:c0 + 4]).abs().max()) <= 4e-6 * float(near) + 1e-30, (c0, float(band))
 
 
 def test_wino6_rejects_bad_arguments():

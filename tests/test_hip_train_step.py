@@ -151,8 +151,14 @@ def test_save_and_resume_training_state(tmp_path):
     b2.save_training_state(0, 2, reference_layout=True)
     written = torch.load(os.path.join(ref_dir, "2.state"))
     plist = [torch.nn.Parameter(torch.zeros(arena.shapes[k])) for k in arena.offsets]
-    topt = torch.optim.AdamW(plist, lr=1e-4)
+    # (an optimizer built the way the reference builds it, twoImage_event_recurrent_model.py:88-90: two param groups, the
+    #  low-lr one -- 'module.offsets' / 'module.dcns' -- empty for this network; a one-group dict is refused by torch)
+    topt = torch.optim.AdamW([{"params": plist}, {"params": [], "lr": 1e-4 * 0.1}], lr=1e-4)
     topt.load_state_dict(written["optimizers"][0])                       # torch accepts it
+    assert len(written["optimizers"][0]["param_groups"]) == 2 and written["optimizers"][0]["param_groups"][1]["params"] == []
+    tsch = torch.optim.lr_scheduler.CosineAnnealingLR(topt, T_max=100, eta_min=1e-7)
+    tsch.load_state_dict(written["schedulers"][0])
+    assert len(tsch.base_lrs) == 2 and len(tsch._last_lr) == 2
     assert topt.state_dict()["param_groups"][0]["betas"] == tuple(opt["train"]["optim_g"]["betas"])
     assert torch.equal(topt.state[plist[3]]["exp_avg"], st[3]["exp_avg"]) and float(topt.state[plist[3]]["step"]) == 2.0
     e = TwoImageEventRecurrentRestorationModel(o2)

@@ -434,7 +434,7 @@ def test_streaming_weight_gradient_eligibility_mirrors_the_library():
     L = _lib.lib()
     for ci in (32, 48, 64, 96, 128, 256):                 # layer input channels = the GEMM's output rows
         for co in (8, 16, 24, 32, 64, 128):               # layer output channels: K = 4 co
-            for w_lo in (16, 32, 48, 64):
+            for w_lo in (8, 16, 24, 32, 48, 64):
                 d = _lib.WgradDesc()
                 d.g, d.in_a, d.dw, d.slabs = 4096, 8192, 12288, 16384          # (never dereferenced)
                 d.ld_g, d.c_o = ci, ci
@@ -444,8 +444,14 @@ def test_streaming_weight_gradient_eligibility_mirrors_the_library():
                 d.i_base, d.i_total, d.o_real, d.algo, d.phase = 0, co, ci, 8, 1
                 lib_ok = L.refid_wgrad_workspace_bytes(C.byref(d)) > 0
                 py_ok = ConvOp._pws_plan_ok(ci, 2 * co, 2 * co, 4 * co)
-                # (the library checks the row width at launch, the engine before choosing: a multiple of 32 pixels)
-                assert lib_ok == py_ok, (ci, co, w_lo, lib_ok, py_ok)
+                # (the row width must fill whole ring buffers of 16 or 32 pixels: the library's workspace query says so too --
+                #  it used to report a size for a geometry its launch then refused --, the engine asks for a multiple of 32)
+                if w_lo % 32 == 0:
+                    assert lib_ok == py_ok, (ci, co, w_lo, lib_ok, py_ok)
+                elif w_lo % 16:
+                    assert not lib_ok, (ci, co, w_lo)
+                else:
+                    assert not lib_ok or py_ok, (ci, co, w_lo)
 
 
 def test_cached_conv_descriptors_equal_the_validating_path_byte_for_byte(monkeypatch):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""fp32 Winograd tile (algo 1) vs Winograd x six bf16 products (algo 5) at the config-2 shapes (B=8): time, difference
-between the two, and -- on a small crop -- the largest deviation of each from the float64 convolution."""
+"""fp32 Winograd tile (algo 1) vs Winograd x six bf16 products (algo 5) vs Winograd x three fp16 products (algo 5, terms 3) at
+the config-2 shapes (B=8): time and -- on a small crop -- the largest deviation of each from the float64 convolution."""
 import os
 import sys
 
@@ -8,7 +8,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
 from refid_amd import ops
-from refid_amd._lib import lib
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_kernels import timeit, B
 
@@ -26,16 +25,13 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
               slope_mask=0.2 if mask else 1.0)
     w1 = ops.pack_conv_weights(w, ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
     w6 = ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, Co, Ci)
+    w3 = ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, Co, Ci, f16=True)
     o1 = torch.empty(B, H, H, Co, device="cuda")
     o6 = torch.empty(B, H, H, Co, device="cuda")
+    o3 = torch.empty(B, H, H, Co, device="cuda")
     t1 = timeit(lambda: ops.conv2d(a, w1, o1, algo=1, **kw))
-    ops.WINO_TILE = 1
-    t6n = timeit(lambda: ops.conv2d(a, w6, o6, algo=5, **kw))
-    o6n = o6.clone()
-    ops.WINO_TILE = 3 if lib().refid_experimental_tiles() else 4
     t6 = timeit(lambda: ops.conv2d(a, w6, o6, algo=5, **kw))
-    same = bool(torch.equal(o6, o6n))
-    diff = (o1 - o6).abs().max().item()
+    t3 = timeit(lambda: ops.conv2d(a, w3, o3, algo=5, terms=3, **kw))
     # float64 reference on a crop of sample 0 (rows 0..15: includes the top border)
     crop = 18
     xa = torch.cat([a[:1, :crop], b[:1, :crop]], 3) if b is not None else a[:1, :crop]
@@ -45,11 +41,9 @@ def one(name, H, Ca, Cb, Co, res=False, mask=False):
         ref = ref + r[:1, :crop - 2].double().cpu()
     if mask:
         ref = ref * torch.where(m[:1, :crop - 2].cpu() > 0, 1.0, 0.2)
-    e1 = (o1[:1, :crop - 2].double().cpu() - ref).abs().max().item()
-    e6 = (o6[:1, :crop - 2].double().cpu() - ref).abs().max().item()
-    wide = "wide 8-wave tile" if lib().refid_experimental_tiles() else "32-channel form"
-    print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us | x6 {t6n*1e6:7.1f} us {fl/t6n/1e12:6.1f} TF(eff) x{t1/t6n:4.2f} | x6 {wide} {t6*1e6:7.1f} us "
-          f"(same bits: {same}) | x6 vs fp32 {diff:.1e}  err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}", flush=True)
+    e1, e6, e3 = ((o[:1, :crop - 2].double().cpu() - ref).abs().max().item() for o in (o1, o6, o3))
+    print(f"{name:28s} wino fp32 {t1*1e6:7.1f} us | x6 bf16 {t6*1e6:7.1f} us | x3 fp16 {t3*1e6:7.1f} us {fl/t3/1e12:6.1f} TF(eff) "
+          f"x{t6/t3:4.2f} vs x6 | err vs fp64: fp32 {e1:.1e}  x6 {e6:.1e}  x3 {e3:.1e}", flush=True)
 
 
 if __name__ == "__main__":

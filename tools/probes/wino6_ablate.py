@@ -18,7 +18,8 @@ VARIANTS = {0: "product", 1: "U fragments cache resident", 2: "no three-plane sp
             4: "no res / mask loads, no stores", 5: "raw halo cache resident", 6: "no U loads in the K loop",
             7: "no raw loads / LDS stores in the K loop", 8: "neither (6 + 7)", 9: "odd-slot workgroup starts 4 us late",
             10: "no K loop, no epilogue traffic (3 + 4)", 11: "odd-slot workgroup starts 8 us late",
-            12: "U loads: same 16 bytes for every lane", 13: "half the U loads"}
+            12: "U loads: same 16 bytes for every lane", 13: "half the U loads",
+            14: "three products, two U planes", 15: "three products, two U planes, no split"}
 if os.environ.get("WINO6_ONLY"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["WINO6_ONLY"].split(",")}
 EXTRA = os.environ.get("WINO6_FLAGS", "").split()

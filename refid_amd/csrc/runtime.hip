@@ -388,7 +388,9 @@ __device__ __forceinline__ void pack_absmax_block(const PackArgs& p) {       // 
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < (int)(blockDim.x >> 6); ++k) m = fmaxf(m, part[k]);
-        *reinterpret_cast<int*>(p.dst) = wino3h_scale_exp(m);
+        int* hdr = reinterpret_cast<int*>(p.dst);            // the whole header is defined: eU, then zeros
+        hdr[0] = wino3h_scale_exp(m);
+        for (int k = 1; k < W3H_HEADER / 4; ++k) hdr[k] = 0;
     }
 }
 

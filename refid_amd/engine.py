@@ -241,7 +241,9 @@ WINO6 = os.environ.get("REFID_WINO6", "1") != "0"
 # thirds of the U bytes of the six-bf16-product form for a per-product error of ~2^-22 instead of ~2^-24 (still below the fp32
 # accumulation's own error; fp16's range is handled by exact power-of-two scales, csrc/conv_wino6.hip).  REFID_WINO_F16=0: the
 # six-product form (A/B switch).
-WINO_F16 = os.environ.get("REFID_WINO_F16", "1") != "0"
+_WF16 = os.environ.get("REFID_WINO_F16", "1")
+WINO_F16_FWD = _WF16 in ("1", "fwd")                  # ("fwd" / "dgrad": only the forward convs / only the input gradients)
+WINO_F16_DGRAD = _WF16 in ("1", "dgrad")
 WINO6_MIN_CO = int(os.environ.get("REFID_WINO6_MIN_CO", "32"))
 WINO6_THIN = os.environ.get("REFID_WINO6_THIN", "1") != "0"        # pred's forward (32 -> 3) on the 32-channel Winograd x six form
 # conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
@@ -456,15 +458,15 @@ class ConvOp:
         # ... and thin outputs (pred, 32 -> 3): the direct fp32 tile pads them to 32 GEMM columns and is bound by the fp32
         # matrix pipe (100 us per launch at B=8); on the 32-channel Winograd x six form the padding costs cheap bf16 MFMAs
         thin6 = WINO6_THIN and kind == "conv" and k == 3 and self.co <= 4 and self.ci % 16 == 0 and USE_WINOGRAD
-        self.w6_f16 = WINO_F16                 # the packing's form: two fp16 planes + header (terms 3) or three bf16 planes
-        self.w6_terms = 3 if self.w6_f16 else 0
+        # the packings' form: two fp16 planes + header (mfma_terms 3) or three bf16 planes (0)
+        self.w6_f16_f, self.w6_f16_d = WINO_F16_FWD, WINO_F16_DGRAD
         if WINO6 and not bf16 and ((self.f_algo == 1 and self.co >= WINO6_MIN_CO) or thin6) and self.ci % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci) < 2 ** 31 - 1:
-            self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci, self.w6_f16) // 2,
+            self.wp6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_FWD, self.co, self.ci, self.w6_f16_f) // 2,
                                    dtype=torch.bfloat16, device=dev)
         if WINO6 and not bf16 and need_dgrad and self.d_algo == 1 and self.ci >= WINO6_MIN_CO and self.co % 4 == 0 and \
                 ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci) < 2 ** 31 - 1:
-            self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci, self.w6_f16) // 2,
+            self.wd6 = torch.empty(ops.packed_weight_wino6_bytes(ops.ROLE_WINO_DGRAD, self.co, self.ci, self.w6_f16_d) // 2,
                                    dtype=torch.bfloat16, device=dev)
         # split-bf16 direct tile (algo 4): second packing next to the default one
         terms = 1 if bf16 else (split or ConvOp.default_split or MFMA_SPLIT)
@@ -532,9 +534,9 @@ class ConvOp:
         if self.wdp6 is not None:
             plan.add_split(self.w, ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, 3, self.wdp6, oscale=self.scale)
         if self.wp6 is not None:
-            plan.add_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, self.wp6, oscale=self.scale, f16=self.w6_f16)
+            plan.add_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, self.wp6, oscale=self.scale, f16=self.w6_f16_f)
         if self.wd6 is not None:
-            plan.add_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, self.wd6, oscale=self.scale, f16=self.w6_f16)
+            plan.add_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, self.wd6, oscale=self.scale, f16=self.w6_f16_d)
         if self.wps is not None:
             plan.add_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, self.s_planes, self.wps, oscale=self.scale)
         if self.wds is not None:
@@ -576,9 +578,9 @@ class ConvOp:
         if self.wdp6 is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_DGRAD, 32, 1, 1, self.co, self.ci, planes=3, out=self.wdp6, oscale=self.scale)
         if self.wp6 is not None:
-            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, out=self.wp6, oscale=self.scale, f16=self.w6_f16)
+            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_FWD, self.co, self.ci, out=self.wp6, oscale=self.scale, f16=self.w6_f16_f)
         if self.wd6 is not None:
-            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, out=self.wd6, oscale=self.scale, f16=self.w6_f16)
+            ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, out=self.wd6, oscale=self.scale, f16=self.w6_f16_d)
         if self.wps is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, planes=self.s_planes,
                                         out=self.wps, oscale=self.scale)
@@ -630,7 +632,7 @@ class ConvOp:
             return out if plus is None else (out, o2)
         if self.wp6 is not None and self.split == 0 and (b is None or a.shape[3] % 16 == 0):
             ops.conv2d(a, self.wp6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=self.f_rows, cout_pad=-(-self.f_rows // 64) * 64, in_b=b,
-                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5, terms=self.w6_terms, **two)
+                       bias=bv, res=res, slope_pre=slope_pre, slope_post=slope_post, algo=5, terms=3 if self.w6_f16_f else 0, **two)
             return out if plus is None else (out, o2)
         if self.wpp6 is not None and a.shape[3] % 16 == 0 and (b is None or b.shape[3] % 16 == 0):
             ops.conv2d(a, self.wpp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=self.f_rows, cout_pad=self.f_pad, in_b=b,
@@ -703,7 +705,7 @@ class ConvOp:
             return out if plus is None else (out, o2)
         if self.wd6 is not None and self.split == 0 and cnt >= WINO6_MIN_CO:
             ops.conv2d(g, self.wd6, out, kh=3, kw=3, stride=1, pad=1, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,
-                       res=res, mask=mask, slope_mask=slope_mask, algo=5, terms=self.w6_terms, **two)
+                       res=res, mask=mask, slope_mask=slope_mask, algo=5, terms=3 if self.w6_f16_d else 0, **two)
             return out if plus is None else (out, o2)
         if self.wdp6 is not None and cnt > 32 and g.shape[3] % 16 == 0:
             ops.conv2d(g, self.wdp6, out, kh=1, kw=1, stride=1, pad=0, mode=0, cout=cnt, cout_pad=self.d_pad, co_base=base,

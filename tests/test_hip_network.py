@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import refid_oracle as O
+from oracle import kink_tape as K
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-3, 1e-4
@@ -192,34 +193,70 @@ def test_bf16_compute_path_psnr_parity(golden_dir):
     assert int((gn == 0).sum()) == 13
 
 
+def _hip_activation_signs(net, x, ev, B, T):
+    """Run the HIP forward with every activation-carrying ConvOp.fwd call recorded: key (conv name, occurrence) -> bool NCHW
+    tensor "the positive branch was taken" (= the stored output is > 0: what BPTT's derivative masks test), in the oracle's
+    element order (the event head runs time-major here, batch-major there)."""
+    from refid_amd import engine
+    signs, count = {}, {}
+    real = engine.ConvOp.fwd
+
+    def fwd(self, a, b=None, res=None, slope_pre=1.0, slope_post=1.0, out=None, pw=None, bias=True, plus=None):
+        r = real(self, a, b, res, slope_pre, slope_post, out, pw, bias, plus)
+        if slope_pre != 1.0 or slope_post != 1.0:
+            o = r[0] if isinstance(r, tuple) else r
+            k = count.get(self.name, 0)
+            count[self.name] = k + 1
+            pos = (o > 0).permute(0, 3, 1, 2)
+            if self.name == "head.conv2d" and B > 1:                      # (T B, ...) time-major -> (B T, ...)
+                pos = pos.reshape(T, B, *pos.shape[1:]).transpose(0, 1).reshape(B * T, *pos.shape[1:])
+            signs[(self.name, k)] = pos.cpu()
+        return r
+
+    engine.ConvOp.fwd = fwd
+    try:
+        pred = net(x=x.cuda(), event=ev.cuda())
+    finally:
+        engine.ConvOp.fwd = real
+    return pred, signs
+
+
 @pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train", "full26_train"])
 def test_outputs_and_gradients_against_the_float64_oracle(golden_dir, name):
     """The tolerances above (2e-3 per gradient tensor) are set by the fp32 REFERENCE's own round-off, not by the HIP path:
-    against the same train step evaluated in float64 (the exact answer both approximate) the fp32 oracle is off by up to
-    1.7e-3 of a tensor's largest entry (head.conv2d.weight: a sum over all B*T*H*W pixels), the HIP path by < 1e-6 on every
-    tensor (tools/grad_error_report.py).  Bar here: 5e-6 of the tensor's largest entry for every gradient, 5e-6 absolute for
-    the outputs, 1e-6 relative for the loss."""
+    against the same train step evaluated in float64 (the exact answer both approximate) the HIP path is within 1e-6 on
+    every tensor (tools/grad_error_report.py).  Bar here: 5e-6 of the tensor's largest entry for every gradient, 5e-6
+    absolute for the outputs, 1e-6 relative for the loss -- against the float64 step GIVEN THE SAME ACTIVATION-SIGN DECISIONS
+    (oracle/kink_tape.py; round 6): ReLU / LeakyReLU have a kink at 0, the full-size fixture holds 44 float64
+    pre-activations within 1e-6 of their tensor's scale of it (the closest at 4e-8: below fp32's resolution of the sum), and
+    which branch an fp32-class arithmetic takes there is chance -- the reference's own fp32 path takes the other branch at
+    one of them and lands 5e-5 from the float64 gradient (tests/test_oracle_kinks.py shows it on CPU), the six-bf16-product
+    Winograd forward happened to take none, the three-fp16-product forward (per layer no less accurate: tools/bench_wino6.py)
+    takes one.  So: the signs the HIP path stored are compared with float64's; every differing element must lie within
+    2e-6 of its tensor's scale of zero, there may be at most 8 of them, and the float64 step is re-evaluated with exactly
+    those elements on the other branch before the unchanged 5e-6 comparison.  Without differing signs (both tiny fixtures)
+    this is the old test."""
     z, P, x, ev, gt, img_chn, base = load(golden_dir, name)
-    img_chn, base, B, T, H, W, seed = [int(v) for v in z["meta"]]
-    P64 = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, dtype=torch.float64)
-    x64, ev64, gt64 = O.make_inputs(B, T, H, W, img_chn, seed=seed, mode="hash", dtype=torch.float64)
-    out64 = O.forward(P64, x64, ev64)
-    loss64, _, g64, _ = O.train_step({k: v.clone() for k, v in P64.items()}, O.TrainState(P64), x64, ev64, gt64)
+    meta = [int(v) for v in z["meta"]]
+    img_chn, base, B, T, H, W, seed = meta
+    loss64, g64, out64, pre64 = K.run(*meta, dtype=torch.float64)
     net = build(img_chn, base, P)
-    pred = net(x=x.cuda(), event=ev.cuda())
+    pred, signs = _hip_activation_signs(net, x, ev, B, T)
     assert float((pred.detach().double().cpu() - out64).abs().max()) < 5e-6
     loss = torch.sqrt((pred - gt.cuda()) ** 2 + 1e-12).mean()
     loss.backward()
     np.testing.assert_allclose(loss.item(), float(loss64), rtol=1e-6)
-    worst = []
-    for k, p in net.named_parameters():
-        s = float(g64[k].abs().max())
-        if s == 0.0:
-            assert float(p.grad.abs().max()) == 0.0, k
-            continue
-        worst.append((float((p.grad.double().cpu() - g64[k]).abs().max()) / s, k))
-    worst.sort(reverse=True)
-    assert worst[0][0] < 5e-6, f"largest gradient deviations from the float64 oracle: {worst[:5]}"
+    # every activation the oracle applies after a conv is one recorded call here (the squeeze-excite MLP's ReLU on a (B, 32)
+    # vector is computed inside conv3's workgroups, not by a ConvOp: its keys exist on the oracle's side only)
+    missing = [k for k in pre64 if k not in signs and ".se_1." not in k[0]]
+    assert not missing and all(k in pre64 for k in signs), (missing[:3], [k for k in signs if k not in pre64][:3])
+    force, report = K.flips(pre64, signs)
+    assert len(report) <= 8 and all(r[0] < 2e-6 for r in report), f"activation signs that differ from float64: {report[:10]}"
+    if force:
+        _, g64, _, _ = K.run(*meta, dtype=torch.float64, force=force)
+    grads = {k: p.grad for k, p in net.named_parameters()}
+    worst, where = K.worst_deviation(grads, g64)
+    assert worst < 5e-6, f"largest gradient deviation from the float64 oracle ({len(report)} forced signs: {report}): {worst:.2e} at {where}"
 
 
 def test_bf16x3_compute_path_stays_inside_the_fp32_bar(golden_dir):

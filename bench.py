@@ -209,9 +209,9 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
     ach = executed / sec / 1e12
     bound, unit = "mfma", "TFLOP/s"
     if "wino6" in name:
-        # Winograd-domain products as six bf16 MFMAs each (exact three-plane operand split): issued FLOPs on the
-        # bf16 matrix pipe = direct x 16/36 x 6
-        executed = fl * (16.0 / 36.0) * 6.0
+        # Winograd-domain products as six bf16 MFMAs each (exact three-plane operand split), or -- "<.., true>", round 6 --
+        # three fp16 MFMAs each (two-plane operands): issued FLOPs on the bf16 / fp16 matrix pipe = direct x 16/36 x 6 (3)
+        executed = fl * (16.0 / 36.0) * (3.0 if "true" in name else 6.0)
         ach = executed / sec / 1e12
     if "split" in name:
         # split-bf16 tile: `terms` bf16 MFMAs per direct-conv multiply (+ 1/9 for the zero tenth tap of its tap pairs)
@@ -225,8 +225,22 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
         if gbs / 8000.0 > ach / peak:
             bound, unit, ach, peak = "hbm", "GB/s", gbs, 8000.0
     conv_fl = sum(v[0] for v in agg.values()); conv_t = sum(v[1] for v in agg.values())
+    # the comparable figures next to `frac` (which prices the FLOPs the kernel issues on the pipe it runs on):
+    #   frac_fp32_equiv  the multiplies the kernel's algorithm needs (Winograd: direct x 16/36; 2x4 tiles: x 12/36; direct
+    #                    tiles: all of them), each counted ONCE, against the fp32 matrix peak -- "what fp32 MFMA tile is this
+    #                    kernel worth" (above 1: faster than any fp32-pipe kernel of the same algorithm could be)
+    #   hbm_frac         ALGORITHMIC bytes per second against the HBM peak;   waste = PMC traffic / algorithmic bytes
+    mult = fl * (16.0 / 36.0) if "wino" in name else fl
+    if "wino24_down" in name:
+        mult = fl * (12.0 / 16.0)
+    elif "wino24" in name:
+        mult = fl * (12.0 / 36.0)
+    alg_bytes = nbytes / cnt
     return {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/)",
+            "frac_fp32_equiv": round(mult / sec / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "hbm_frac": round(nbytes / sec / 8e12, 4),
+            "waste": round(traffic / alg_bytes, 3) if traffic else None,
             "algorithmic_bytes_per_launch": round(nbytes / cnt), "kernel": name, "launches": cnt,
             "avg_launch_us": round(sec / cnt * 1e6, 2),
             "direct_conv_equivalent_tflops": round(fl / sec / 1e12, 2),
@@ -655,10 +669,15 @@ def main(argv=None, claim_stdout=False):
                                           "bf16": "bf16"}[args.dtype], "data": "synthetic",
             "rccl_ranks": world if (use_dist and args.backend == "nccl") else (0 if not use_dist else None),
             "arithmetic": {"fp32": "fp32 tensors, operands and accumulation; 3x3: Winograd F(2x2,3x3), transforms in fp32; its "
-                                   "transform-domain products (more than 32 output channels) and conv_down (4x4 stride 2) fwd/dgrad: "
-                                   "every fp32 operand split EXACTLY into three bf16 numbers, six bf16 MFMAs per product, fp32 "
-                                   "accumulation (same distance from float64 as the fp32 MFMA tiles: tests/test_hip_conv.py::"
-                                   "test_wino6_*, test_split_tile_conv_down_*; REFID_WINO6=0 / REFID_DOWN_SPLIT=0 turn them off); 3x3 "
+                                   "transform-domain products: every fp32 operand as TWO fp16 numbers h = rne16(v), l = rne16(v - h) "
+                                   "(22 significand bits), three fp16 MFMAs per product (hh + hl + lh, ~2^-22 per product, below the "
+                                   "fp32 accumulation's own error), fp32 accumulation; fp16's range is bridged by exact power-of-two "
+                                   "scales (weights per tensor, activations per Winograd tile and online along K), so any finite fp32 "
+                                   "magnitude keeps the same relative error (tests/test_hip_conv.py::test_wino_f16_accuracy_class_and_"
+                                   "dynamic_range: same distance from float64 as the fp32 MFMA tile; REFID_WINO_F16=0: six bf16 products "
+                                   "on exact three-plane operands, round 5's form; REFID_WINO6=0: fp32 MFMA); conv_down (4x4 stride 2) "
+                                   "fwd/dgrad: six bf16 MFMAs per product on exact three-bf16-plane operands (REFID_DOWN_SPLIT=0: fp32 "
+                                   "MFMA); 3x3 "
                                    "weight gradients: fp32 MFMA in the Winograd domain over 2x4 tiles of the output gradient (F(3,2) x "
                                    "F(3,4), transforms and accumulation fp32; 3e-6 .. 6e-6 of a tensor's scale from the float64 gradient, "
                                    "test_wgrad_f4_accuracy_class; REFID_WGRAD_F4=0: 2x2 tiles); conv_down's weight gradient: the same kernel on the "

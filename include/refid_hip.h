@@ -35,8 +35,9 @@ extern "C" {
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
-/* 1 when the library was built with REFID_EXPERIMENTAL_TILES=1 (tiles that were measured and are never selected by
- * default, e.g. refid_conv_desc.wino_tile = 2); the product build returns 0 and ignores such hints. */
+/* Always 0 since ABI 9: the tiles that were measured and lost (the persistent and the wide Winograd tiles, the six-product /
+ * LDS-DMA / F(3x3,4x4) weight gradients; REFID_EXPERIMENTAL_TILES=1 builds of ABI <= 8) are no longer in the tree.  Kept so that
+ * callers written against earlier versions still link. */
 int refid_experimental_tiles(void);
 
 /* Device facts used by the host-side scheduler (CU count etc.); -1 on failure. */
@@ -145,17 +146,12 @@ typedef struct refid_conv_desc {
                                                    per-sample geometry (a sample's bits do not depend on the batch
                                                    size); 2 = decided by the total grid size (best at 1-2 samples per
                                                    GPU).  Used by algo 1 / 5 and by algo 0's 4x4/s2 tiles (mode 0 and 2).  */
-    int wino_tile;                              /* experiments, honoured only by libraries built with
-                                                   REFID_EXPERIMENTAL_TILES=1 (same results bit for bit, measured slower):
-                                                   algo 5: 3 = the wide tile (8x32 px x 64 ch, 8 waves, weight fragments
-                                                   shared through an LDS ring); 
-                                                   algo 1: 0 / 1 = the 2-waves-per-SIMD tile (4x32 px x 64 ch
-                                                   workgroups; the default); 2 = the persistent one-wave-per-SIMD tile
-                                                   (8x32 px x 64 ch, one workgroup per CU walking the tiles) whenever the
-                                                   geometry allows -- ONLY in libraries built with
-                                                   REFID_EXPERIMENTAL_TILES=1 (refid_experimental_tiles()); the product
-                                                   build runs the default tile.  Same results bit for bit; 2 measured
-                                                   10-30 % slower.                                                    */
+    int wino_tile;                              /* algo 5: 0 = the library chooses between the 64- and the 32-output-channel
+                                                   workgroup tile; 1 = the 64-channel tile wherever cout > 32; 4 = the
+                                                   32-channel tile everywhere (an A/B switch: measured 9-35 % slower on the
+                                                   64-channel layers).  Same results whichever runs.  (2 / 3 selected tiles
+                                                   that were removed with ABI 9 -- a persistent and a wide one, both measured
+                                                   slower -- and are ignored.)                                          */
     const refid_pw_extras* pw;                  /* algo 3 only: fusions around the pointwise conv, or NULL               */
     int mfma_terms;                             /* algo 3: 0 = fp32 MFMA products; 6 = six bf16 products on exactly split
                                                    operands (w_packed from refid_pack_conv_weights_split with kh = kw = 1,
@@ -224,12 +220,8 @@ typedef struct refid_wgrad_desc {
                                                    2 = direct with bf16 MFMA operands (3x3 stride 1 pad 1, more than 32
                                                    output and input channels; fp32 accumulation / slabs / dw; slab
                                                    geometry and phases identical to algo 0);
-                                                   3 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured
-                                                   0.75x algo 1): Winograd with the transform-domain products as six
-                                                   bf16 MFMAs on exactly split operands, as refid_conv2d algo 5;
-                                                   4 = experiment (same builds; measured equal to algo 1 in the train step):
-                                                   algo 1's fp32 tile fed by LDS-DMA into two buffers, one barrier per K
-                                                   tile (pitches multiples of 4 floats, 16-byte aligned tensors);
+                                                   (3, 4, 6: experiments of ABI <= 8 -- six bf16 products, LDS-DMA staging,
+                                                   F(3x3,4x4) -- that did not beat algo 1 / 5: rejected with a message);
                                                    5 = Winograd over 2x4 tiles of g (3x3 stride 1): F(3,2) down the rows,
                                                    F(3,4) along them -- 24 instead of 32 fp32 MFMAs per 8 pixels, packed
                                                    transforms (wgrad_wino24.hip; slabs [split][24][o][i]; pitches / channel
@@ -244,10 +236,7 @@ typedef struct refid_wgrad_desc {
                                                    weight gradient (wgrad_pws.hip): K = (dy, dx, c) over the even / odd rows of
                                                    the source, which must have dense pixels (ld_a == c_a; one source, no db,
                                                    c_o >= 64 and a multiple of 32, c_a a multiple of 16, wo a multiple of 32);
-                                                   the reduction permutes the columns into dw's [o][c][dy][dx] layout;
-                                                   6 = experiment (REFID_EXPERIMENTAL_TILES builds only; measured no faster
-                                                   than algo 1): Winograd F(3x3,4x4), 36 MFMAs per 16 pixels, six-wave
-                                                   workgroups (experimental/wgrad_wino4.hip)                          */
+                                                   the reduction permutes the columns into dw's [o][c][dy][dx] layout  */
     int phase;                                  /* 0 = partial products + reduction in one call;
                                                    weights shared over the T recurrent steps can instead
                                                    keep accumulating in their own `slabs`:

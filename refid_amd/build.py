@@ -15,9 +15,9 @@ LIB = os.path.join(HERE, "librefid_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-pass-failed"]
-# Tiles that were measured and lost (csrc/experimental/: the persistent one-wave-per-SIMD Winograd tile) stay out of the
-# product library; REFID_EXPERIMENTAL_TILES=1 builds them in (tools/bench_wino2.py, the tile's own tests).
-EXPERIMENTAL = os.environ.get("REFID_EXPERIMENTAL_TILES", "0") == "1"
+# (the tiles that were measured and lost -- the persistent one-wave-per-SIMD Winograd tile, the wide Winograd x six tile, the
+#  F(3x3,4x4) weight gradient -- lived in csrc/experimental/ behind REFID_EXPERIMENTAL_TILES=1 until round 6; their numbers
+#  are in DESIGN.md section 7, their sources in the history)
 
 
 def _newer(src_list, target):
@@ -33,9 +33,6 @@ def build(verbose=False, force=False):
     # The flag set the objects and the library were built with is recorded AFTER a successful link (never before: a failed
     # compile must not leave a stamp that says "already built this way"); a different or missing record rebuilds everything.
     stamp = os.path.join(CSRC, ".buildflags")
-    if EXPERIMENTAL:
-        srcs += sorted(glob.glob(os.path.join(CSRC, "experimental", "*.hip")))
-        flags.append("-DREFID_EXPERIMENTAL_TILES")
     want = " ".join(flags)
     try:
         have = open(stamp).read()

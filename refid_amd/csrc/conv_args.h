@@ -37,17 +37,11 @@ struct ConvKArgs {
 size_t refid_wino3x3_workspace_bytes(const ConvKArgs& a, int split_mode);
 int refid_launch_wino3x3(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st);
 int refid_launch_splitk_finish(const ConvKArgs& f, const float* ws, int ldW, long long npix, hipStream_t st);
-// conv_wino2.hip: persistent one-wave-per-SIMD variant for problems with >= 2 tiles per CU
-bool refid_wino3x3_p_eligible(const ConvKArgs& a, int cus);
-int refid_launch_wino3x3_p(const ConvKArgs& a, int cus, hipStream_t st);
 // conv_wino6.hip: Winograd F(2x2,3x3) with six bf16 products per fp32 product (algo 5)
 bool refid_wino6_eligible(const ConvKArgs& a);
 size_t refid_wino6_workspace_bytes(const ConvKArgs& a, int split_mode);
 // terms: 0 / 6 = six bf16 products (three planes per operand), 3 = three fp16 products (two planes, scaled operands)
 int refid_launch_wino6(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, int terms, hipStream_t st);
-// conv_wino6w.hip: the same arithmetic on 8-wave workgroups (8x32 pixels) that share the weight fragments through LDS
-int refid_wino6w_workgroups(const ConvKArgs& a);
-int refid_launch_wino6w(const ConvKArgs& a, int ks, hipStream_t st);
 // conv_split.hip: direct 3x3 tile with split-bf16 operands (algo 4); terms = 6 (fp32-class products) or 3
 bool refid_split3x3_eligible(const ConvKArgs& a);
 int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipStream_t st);

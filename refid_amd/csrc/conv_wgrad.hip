@@ -828,11 +828,6 @@ int refid_wgrad_wino_launch(const refid_wgrad_desc* d, hipStream_t st);
 // wgrad_wino24.hip: Winograd over 2x4 tiles, F(3,2) x F(3,4) (algo 5)
 size_t refid_wgrad_wino24_workspace_bytes(const refid_wgrad_desc* d);
 int refid_wgrad_wino24_launch(const refid_wgrad_desc* d, hipStream_t st);
-#ifdef REFID_EXPERIMENTAL_TILES
-// experimental/wgrad_wino4.hip: Winograd F(3x3,4x4) (algo 6)
-size_t refid_wgrad_wino4_workspace_bytes(const refid_wgrad_desc* d);
-int refid_wgrad_wino4_launch(const refid_wgrad_desc* d, hipStream_t st);
-#endif
 
 // algo 8: the weight gradient of a 2x2 stride-2 conv over NON-overlapping patches (ConvTranspose2d(2,2) with the roles swapped,
 // refid_hip.h) as ONE streaming 1x1 weight gradient: an output pixel's patch is two contiguous runs of 2 c_a floats (rows 2y and
@@ -870,9 +865,6 @@ extern "C" size_t refid_wgrad_workspace_bytes(const refid_wgrad_desc* d) {
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino_workspace_bytes(d) : 0;
     if (d->algo == 5) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
     if (d->algo == 7) return (d->kh == 4 && d->kw == 4 && d->stride == 2) ? refid_wgrad_wino24_workspace_bytes(d) : 0;
-#ifdef REFID_EXPERIMENTAL_TILES
-    if (d->algo == 6) return (d->kh == 3 && d->kw == 3 && d->stride == 1) ? refid_wgrad_wino4_workspace_bytes(d) : 0;
-#endif
     if (thin_ok(d)) return (size_t)thin_nsplit(d) * 4 * (WT_MAXG * 1024 + 32) * sizeof(float);
     const Plan p = plan_of(d->kh, d->kw, d->stride, d->c_o, d->phase != 0 ? d->i_total - d->i_base : d->c_a + d->c_b);
     if (!p.ok) return 0;
@@ -943,12 +935,8 @@ static int conv2d_wgrad_impl(const refid_wgrad_desc* d, hipStream_t st) {
                 "wgrad: algo 2 (bf16 operands) needs more than 32 output and input channels and pad 1");
     if (d->algo == 1 || d->algo == 3 || d->algo == 4) return refid_wgrad_wino_launch(d, st);
     if (d->algo == 5 || d->algo == 7) return refid_wgrad_wino24_launch(d, st);
-#ifdef REFID_EXPERIMENTAL_TILES
-    if (d->algo == 6) return refid_wgrad_wino4_launch(d, st);
-#else
-    REFID_CHECK(d->algo != 6, "wgrad: algo 6 (Winograd F(3x3,4x4)) is an experiment that did not beat algo 5; build with "
-                              "REFID_EXPERIMENTAL_TILES=1 to run it");
-#endif
+    REFID_CHECK(d->algo != 6, "wgrad: algo 6 (Winograd F(3x3,4x4)) was an experiment that did not beat algo 5 (round 5, "
+                              "DESIGN.md section 7); it is no longer built");
     if (thin_ok(d)) {
         REFID_CHECK(d->phase >= 0 && d->phase <= 3, "wgrad: bad phase %d", d->phase);
         const int ns = thin_nsplit(d), nslab = ns * 4;

@@ -473,18 +473,9 @@ int device_cus() {
 
 int refid_launch_wino3x3(const ConvKArgs& ka, float* ws, size_t ws_bytes, int split_mode, int tile_hint, hipStream_t st) {
     ConvKArgs a = ka;
-    // tile_hint (refid_conv_desc.wino_tile): 0 / 1 = the 2-waves-per-SIMD tile; 2 = the persistent one-wave-per-SIMD
-    // tile (conv_wino2.hip) whenever the geometry allows it.  Same bits.  The persistent tile is opt-in: measured 10-30 %
-    // slower at every config-2 shape (a lone wave per SIMD pays ~130 cycles per buffer-load issue and every LDS /
-    // barrier stall itself; two co-resident workgroups hide exactly that -- DESIGN.md, profiles/r02_wino_*).
-    // Built only with REFID_EXPERIMENTAL_TILES=1 (csrc/experimental/conv_wino2.hip); the product library always runs the
-    // two-wave tile (same bits).
-#ifdef REFID_EXPERIMENTAL_TILES
-    if (tile_hint == 2 && a.vecOK && a.Cout % 4 == 0 && a.out2 == nullptr) {
-        const int cus = device_cus();
-        if (cus > 0 && refid_wino3x3_p_eligible(a, 0)) return refid_launch_wino3x3_p(a, cus, st);
-    }
-#endif
+    // (tile_hint 2 once selected a persistent one-wave-per-SIMD tile: measured 10-30 % slower at every config-2 shape -- a
+    //  lone wave per SIMD pays ~130 cycles per buffer-load issue and every LDS / barrier stall itself; two co-resident
+    //  workgroups hide exactly that, DESIGN.md section 7, profiles/r02_wino_* -- and was removed in round 6)
     // no workspace from the caller = no split (still correct, one K loop per workgroup)
     const WinoPlan pl = wino_plan(a, ws ? split_mode : 0);
     const bool narrow = a.Cout <= 32;

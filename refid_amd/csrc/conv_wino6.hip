@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     // 7 = no raw loads / LDS stores in the K loop, 8 = 6 + 7, 9 / 11 = the workgroup in the odd wave slot of its SIMD starts
     // 4 / 8 us late (anti-phased pair per CU), 10 = 3 + 4, 12 = every lane of a U load reads the same 16 bytes (same
     // instruction count, no bandwidth), 13 = half the U loads (column tile 1 reuses tile 0's fragments), 14 = three products on
-    // two planes (the MFMA / U-byte count of a two-plane fp16 form), 15 = 14 without the split.  Never in the product.
+    // two planes (the MFMA / U-byte count of a two-plane fp16 form), 15 = 14 without the split; fp16 form (WINO6_TERMS=3):
+    // 16 = no max / rescale / scale, 17 = a one-instruction max, 18 = no split.  Never in the product.
     auto load_raw = [&](int ch, f32x4 (&dst)[R_ITEMS]) {
         const int c0 = (REFID_WINO6_ABLATE == 5 ? 0 : ch) * KC;   // chunk-uniform source: Ca % 16 == 0 for two sources
         const bool fromA = c0 < a.Ca;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
         for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
             for (int b = 0; b < 4; ++b) t[qq][b] = r[qq * PLANE + offP + BOFF[b]] + r[qq * PLANE + offM + BOFF[b]] * sgn;
-        if constexpr (F16) {
+        if constexpr (F16 && REFID_WINO6_ABLATE != 16) {
             // largest |t| of this lane's tile in this chunk (both K halves: lanes l and l ^ 32 hold the same tile)
             float m = 0.f;
 #pragma unroll
@@ -272,6 +273,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     m = fmaxf(fmaxf(m, fmaxf(fabsf(t[qq][b][0]), fabsf(t[qq][b][1]))), fmaxf(fabsf(t[qq][b][2]), fabsf(t[qq][b][3])));
+            if (REFID_WINO6_ABLATE == 17) m = fabsf(t[0][0][0]);            // (a one-instruction "max": prices the max tree)
             const unsigned mb = __float_as_uint(m);
             const auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
             const int eb = (int)(max(sw[0], sw[1]) >> 23);
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
                 v[qq] = (j == 0) ? t[qq][0] - t[qq][2] : (j == 1) ? t[qq][1] + t[qq][2]
                       : (j == 2) ? t[qq][2] - t[qq][1] : t[qq][1] - t[qq][3];
             if (REFID_WINO6_ABLATE == 2 || REFID_WINO6_ABLATE == 15) { pl[0] = v[0]; pl[1] = v[1]; pl[2] = t[0][j]; }
+            else if (F16 && REFID_WINO6_ABLATE == 18) { pl[0] = v[0]; pl[1] = v[1]; }
             else if constexpr (F16) split8h(v[0], v[1], pl);
             else split8(v[0], v[1], pl);
 #pragma unroll
@@ -542,12 +545,8 @@ int refid_launch_wino6(const ConvKArgs& ka, float* ws, size_t ws_bytes, int spli
     REFID_CHECK(refid_wino6_eligible(a),
                 "conv2d: the Winograd six-product tile needs input-channel counts that are multiples "
                 "of 4 (two sources: c_a a multiple of 16) and tensors below 2 GiB");
-    // Wide tile (experimental/conv_wino6w.hip: 8x32 pixels, 8 waves, weight fragments shared through an LDS ring, same
-    // bits): measured 0-10 % slower, only in libraries built with REFID_EXPERIMENTAL_TILES=1 and only on request
-    // (refid_conv_desc.wino_tile = 3)
-#ifdef REFID_EXPERIMENTAL_TILES
-    if (tile_hint == 3 && a.Cout > 32 && a.out2 == nullptr && !f16) return refid_launch_wino6w(a, 1, st);   // (no second output there)
-#endif
+    // (a wide tile -- 8x32 pixels, 8 waves, weight fragments shared through an LDS ring, same bits -- measured 0-10 % slower
+    //  and was removed in round 6: DESIGN.md section 7)
     const Wino6Plan pl = wino6_plan(a, ws ? split_mode : 0, tile_hint);
     dim3 grid = pl.grid;
     const int ks = pl.ks;

@@ -15,11 +15,7 @@ void refid_set_error(const char* fmt, ...) {
 extern "C" const char* refid_last_error(void) { return g_err; }
 extern "C" int refid_abi_version(void) { return REFID_ABI_VERSION; }
 extern "C" int refid_experimental_tiles(void) {
-#ifdef REFID_EXPERIMENTAL_TILES
-    return 1;
-#else
     return 0;
-#endif
 }
 
 extern "C" int refid_device_cu_count(void) {

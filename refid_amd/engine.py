@@ -274,10 +274,6 @@ WGRAD_GROUP_SMALL = max(1, min(24, int(_WG_ENV))) if _WG_ENV else 24
 # time step.  Engine._set_wgrad_groups shrinks the group when that would not fit into half of the HBM still free when BPTT
 # starts (a larger crop / T / batch then runs in smaller groups instead of running out of memory).
 WGRAD_KEEP_BYTES_PER_PIXEL_STEP = 4900
-# Experiment (REFID_EXPERIMENTAL_TILES builds only): Winograd weight gradient with six exact-split bf16 products per fp32
-# product (refid_wgrad_desc.algo = 3) instead of the fp32-MFMA Winograd tile (algo 1).  Measured 0.75x: both operands
-# are transformed and split on the fly, ~19 VALU per MFMA.  Off.
-WGRAD_WINO6 = os.environ.get("REFID_WGRAD_WINO6", "0") == "1"
 # Round 5: 3x3 weight gradients on the Winograd 2x4-tile form (refid_wgrad_desc.algo = 5: F(3,2) x F(3,4), 24 instead of 32
 # fp32 MFMAs per 8 output pixels, packed transforms) wherever the 2x2-tile form (algo 1) was used and the output has at
 # least WGRAD_F4_MIN_HW rows and columns (below that a 4 x 16-pixel K tile is mostly zero padding and the 2x2 form's smaller
@@ -778,8 +774,6 @@ class ConvOp:
                 (b is None or b.shape[3] % 32 == 0) and a.shape[1] % 2 == 0 and a.shape[2] % 2 == 0 and \
                 min(g.shape[1], g.shape[2]) >= WGRAD_F4_MIN_HW and g.shape[3] % 4 == 0:
             algo = 7          # the 2x4-tile Winograd kernel on the four parity phases of the input
-        if algo == 1 and WGRAD_WINO6 and not self.bf16:
-            algo = 3          # the same transform-domain GEMMs as six bf16 MFMAs per fp32 product
         if self.bf16 and self.kind == "conv" and self.k == 3 and self.co > 32 and self.ci > 32:
             algo = 2          # bf16 matrix-core operands, fp32 accumulation (compute_dtype: bf16)
         return self._wgrad_issue(g, a, b, bias, algo)

@@ -19,7 +19,8 @@ ROLE_FWD, ROLE_DGRAD, ROLE_CONVT, ROLE_CONVT_DGRAD, ROLE_DOWN_DGRAD, ROLE_WINO_F
 # sample (by per-sample geometry: a sample's bits do not depend on the batch it is in) | 0 (never)
 WINO_SPLIT = {"0": 0, "s": 1}.get(os.environ.get("REFID_SPLITK", os.environ.get("REFID_WINO_SPLITK", "auto"))[:1], 2)
 
-# Winograd tile selection (refid_conv_desc.wino_tile): 0 = by problem size, 1 = 2-waves tile, 2 = persistent tile
+# Winograd x six / x three tile selection (refid_conv_desc.wino_tile): 0 = by problem size, 1 = the 64-channel tile wherever
+# cout > 32, 4 = the 32-channel tile everywhere (A/B switches)
 WINO_TILE = int(os.environ.get("REFID_WINO_TILE", "0"))
 
 # bench.py's roofline leg: when PROFILE is a list, conv2d()/conv2d_wgrad() bracket each launch with

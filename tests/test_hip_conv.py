@@ -16,12 +16,6 @@ def _ops():
     return ops
 
 
-def _need_experimental():
-    from refid_amd._lib import lib
-    if not lib().refid_experimental_tiles():
-        pytest.skip("product library: built without REFID_EXPERIMENTAL_TILES=1")
-
-
 def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().float().cuda()
 
@@ -688,15 +682,10 @@ def test_winograd_dgrad(cfg):
     (2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 256, 256, 256), (1, 5, 3, 64, 0, 128),
     (1, 7, 33, 32, 0, 96), (1, 16, 32, 32, 32, 32), (1, 8, 32, 32, 0, 3),
 ])
-@pytest.mark.parametrize("algo", [1, 3, 4, 5, 6])
+@pytest.mark.parametrize("algo", [1, 5])
 def test_winograd_wgrad(cfg, algo):
-    """algo 1: fp32 MFMA, 2x2 tiles; algo 5: fp32 MFMA, 2x4 tiles (wgrad_wino24.hip); experimental builds: algo 3 = six
-    exact-split bf16 products per fp32 product, algo 4 = the fp32 tile fed by LDS-DMA into two buffers, algo 6 = 4x4 tiles."""
+    """algo 1: fp32 MFMA, 2x2 tiles; algo 5: fp32 MFMA, 2x4 tiles (wgrad_wino24.hip)."""
     ops = _ops()
-    if algo in (3, 4, 6):
-        _need_experimental()
-    if algo == 4 and cfg[5] % 4:
-        pytest.skip("the LDS-DMA kernel moves 16-byte pieces")
     N, H, W, Ca, Cb, Co = cfg
     x = rnd(N, Ca + Cb, H, W, seed=1)
     w = rnd(Co, Ca + Cb, 3, 3, seed=2).requires_grad_(True)
@@ -1061,93 +1050,6 @@ def test_winograd_splitk_two_streams_have_private_workspaces():
     np.testing.assert_allclose(nosplit.cpu().numpy(), serial[0].cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
-# ---- persistent one-wave-per-SIMD Winograd tile (csrc/experimental/conv_wino2.hip; refid_conv_desc.wino_tile = 2) ----
-# An experiment that lost (10-30 % slower): only in libraries built with REFID_EXPERIMENTAL_TILES=1; these tests skip on
-# the product library.
-@pytest.fixture
-def persistent_tile():
-    ops = _ops()
-    _need_experimental()
-    old, ops.WINO_TILE = ops.WINO_TILE, 2
-    yield ops
-    ops.WINO_TILE = old
-
-
-@pytest.mark.parametrize("cfg", [
-    (2, 16, 32, 32, 0, 64), (1, 24, 40, 64, 64, 64), (1, 8, 8, 128, 128, 128), (1, 12, 20, 64, 0, 256),
-    (2, 16, 16, 32, 32, 32), (1, 5, 3, 64, 0, 64), (1, 7, 33, 32, 0, 96), (3, 40, 72, 64, 0, 64), (2, 36, 64, 32, 0, 32),
-    (1, 19, 70, 32, 32, 32),
-])
-def test_persistent_winograd_forward_geometries(persistent_tile, cfg):
-    """Same cases as the 2-waves tile (odd sizes, two sources, ragged channel tiles) + multi-tile walks per workgroup
-    (the grid is min(#CUs, #tiles): 3x40x72 gives every workgroup a tile seam to cross only on a small grid, so the
-    seam logic is exercised by the full-size test below as well)."""
-    run_wino(*cfg)
-
-
-def test_persistent_winograd_fused_epilogues(persistent_tile):
-    run_wino(1, 16, 32, 64, 0, 64, slope_pre=0.04)
-    run_wino(1, 16, 32, 64, 0, 64, res=True)
-    run_wino(1, 8, 32, 128, 0, 128, res=True, slope_post=0.0)
-    run_wino(1, 8, 32, 64, 64, 64, slope_pre=0.1)
-    run_wino(1, 8, 32, 64, 0, 64, bias=False, res=True, mask=True)
-    run_wino(2, 24, 64, 32, 0, 32, bias=True, res=True, mask=True, slope_pre=0.1)
-
-
-def test_persistent_tile_is_bit_identical_to_the_two_wave_tile_at_size():
-    """Config-2 level-0 shape (B=8, 256x256, 64 -> 64, residual + mask): 2048 tiles over 256 persistent workgroups (8
-    tile seams each, next-tile prefetch across the epilogue).  Both tiles add the K chunks in the same order with the
-    same transforms: equal bits -- which is also what keeps a sample's result independent of the batch size."""
-    _need_experimental()
-    ops = _ops()
-    g = torch.Generator(device="cuda").manual_seed(3)
-    N, H, W = 8, 256, 256
-    for Ca, Cb, Co in ((64, 0, 64), (64, 64, 64), (32, 0, 32), (128, 0, 128)):
-        Hh = H if Co <= 64 else H // 2
-        Ci = Ca + Cb
-        xa = torch.randn(N, Hh, Hh, Ca, device="cuda", generator=g)
-        xb = torch.randn(N, Hh, Hh, Cb, device="cuda", generator=g) if Cb else None
-        res = torch.randn(N, Hh, Hh, Co, device="cuda", generator=g)
-        msk = torch.randn(N, Hh, Hh, Co, device="cuda", generator=g)
-        w = torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) * 0.05
-        b = torch.randn(Co, device="cuda", generator=g)
-        wp = ops.pack_conv_weights(w, ops.ROLE_WINO_FWD, 64, 8, 3, 3, Co, Ci)
-        outs = []
-        for tile in (1, 2):
-            old, ops.WINO_TILE = ops.WINO_TILE, tile
-            try:
-                out = torch.empty(N, Hh, Hh, Co, device="cuda")
-                ops.conv2d(xa, wp, out, kh=3, kw=3, stride=1, pad=1, cout=Co, cout_pad=-(-Co // 64) * 64, algo=1, in_b=xb,
-                           bias=b, res=res, mask=msk, slope_pre=0.1, slope_mask=0.2)
-                outs.append(out)
-            finally:
-                ops.WINO_TILE = old
-        assert torch.equal(outs[0], outs[1]), (Ca, Cb, Co)
-        # and against torch on one sample
-        ref = F.leaky_relu(F.conv2d(torch.cat([xa[:1], xb[:1]], 3).permute(0, 3, 1, 2) if Cb else xa[:1].permute(0, 3, 1, 2),
-                                    w, b, 1, 1), 0.1) + res[:1].permute(0, 3, 1, 2)
-        ref = ref * torch.where(msk[:1].permute(0, 3, 1, 2) > 0, 1.0, 0.2)
-        np.testing.assert_allclose(outs[1][:1].permute(0, 3, 1, 2).cpu().numpy(), ref.cpu().numpy(), rtol=RTOL, atol=ATOL)
-
-
-def test_persistent_winograd_dgrad_row_ranges(persistent_tile):
-    ops = persistent_tile
-    N, H, W, Ci, Co = 2, 24, 64, 128, 64
-    x = rnd(N, Ci, H, W, seed=1).requires_grad_(True)
-    w = rnd(Co, Ci, 3, 3, seed=2, scale=0.1)
-    g = rnd(N, Co, H, W, seed=3)
-    F.conv2d(x, w, None, 1, 1).backward(g)
-    wd = ops.pack_conv_weights(w.float().cuda(), ops.ROLE_WINO_DGRAD, 64, 8, 3, 3, Co, Ci)
-    gd = nhwc(g)
-    out = torch.empty(N, H, W, Ci, device="cuda")
-    ops.conv2d(gd, wd, out, kh=3, kw=3, stride=1, pad=1, cout=Ci, cout_pad=128, algo=1)
-    np.testing.assert_allclose(nchw(out).numpy(), x.grad.numpy(), rtol=RTOL, atol=ATOL)
-    half = Ci // 2
-    o2 = torch.empty(N, H, W, half, device="cuda")
-    ops.conv2d(gd, wd, o2, kh=3, kw=3, stride=1, pad=1, cout=half, cout_pad=128, co_base=half, algo=1)
-    np.testing.assert_allclose(nchw(o2).numpy(), x.grad[:, half:].numpy(), rtol=RTOL, atol=ATOL)
-
-
 @pytest.mark.parametrize("kind", ["down_fwd", "down_dgrad"])
 def test_direct_tile_splitk_small_grids(kind):
     """The 4x4 / stride-2 tiles (conv_down forward, its input gradient) are long-K, few-tile launches at small batch
@@ -1235,13 +1137,11 @@ def test_bf16_weight_gradient_tile(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 16, 32, 64, 0, 64), (1, 24, 40, 64, 64, 64), (1, 9, 33, 64, 64, 128)])
-@pytest.mark.parametrize("algo", [1, 3, 4, 5, 6])
+@pytest.mark.parametrize("algo", [1, 5])
 def test_winograd_wgrad_grouped_time_steps(cfg, algo):
     """refid_wgrad_desc.groups: the Winograd weight gradients of several time steps of one conv in ONE launch (the weights
     are shared over T) == the same calls one by one -- persistent-slab phases included."""
     ops = _ops()
-    if algo in (3, 4, 6):
-        _need_experimental()
     N, H, W, Ca, Cb, Co = cfg
     steps = []
     for t in range(4):

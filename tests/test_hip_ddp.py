@@ -32,13 +32,14 @@ def _opt(img_chn, base):
 def _worker(rank, world, port, ret, backend="gloo", graph=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
+    dev = rank if (backend == "nccl" and world > 1) else 0      # real RCCL ranks: one device each (RCCL refuses two on one)
     if backend == "nccl":
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(dev)
         os.environ["REFID_FORCE_GRADSYNC"] = "1"       # run the collectives in a 1-rank group
     dist.init_process_group(backend, rank=rank, world_size=world)
     from refid_amd.train import TwoImageEventRecurrentRestorationModel
     from refid_amd.dist import shard_batch
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(dev)
     model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
     P = O.make_params(26, base_num_channels=8, mode="hash", seed=5 + rank)     # ranks start DIFFERENT ...
     model.net_g.load_state_dict(P)
@@ -242,6 +243,66 @@ def test_early_all_reduce_is_enqueued_before_the_backward_sweep_bptt():
     assert order[1][2] == n_early                  # ... still un-waited when backward_late starts
     assert order[2][2] == 0                        # the late call waits for all of them
     assert all(g >= 0.0 for g in gaps)             # compute-stream events in the same order
+
+
+needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL takes one rank per device")
+
+
+def _single_rank_reference():
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    model = TwoImageEventRecurrentRestorationModel(_opt(26, 8))
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    model.net_g.load_state_dict(P)
+    x, ev, gt = O.make_inputs(2, 3, 32, 32, 26, seed=21, mode="hash")
+    for it in (1, 2):
+        model.update_learning_rate(it)
+        model.feed_data({"lq": x, "voxel": ev, "gt": gt})
+        model.optimize_parameters(it)
+    return model, P
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("graph", [False, True])
+def test_two_real_rccl_ranks_equal_one_rank_on_the_full_batch(graph):
+    """The gloo test's body with backend 'nccl' on two devices (skips on one-GPU boxes): two RCCL ranks x B=1 == one rank x
+    B=2 -- eager, and with the step replayed from its three hipGraphs with the early / late all-reduces issued between them
+    (the form bench.py's small-batch default uses)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    mp.spawn(_worker, args=(2, port, ret, "nccl", graph), nprocs=2, join=True)
+    assert set(ret.keys()) == {0, 1}
+    loss0, gn0, sd0 = ret[0]
+    loss1, gn1, sd1 = ret[1]
+    assert loss0 == loss1 and gn0 == gn1
+    for k in sd0:
+        assert torch.equal(sd0[k], sd1[k]), k                  # replicas stay bit-identical
+    model, P = _single_rank_reference()
+    assert abs(model.get_current_log()["l_pix"] - loss0) < 1e-6
+    assert abs(model.grad_norm() - gn0) < 1e-3 * gn0
+    sd = model.net_g.state_dict()
+    for k in sd:
+        a, b = sd[k].double().cpu(), sd0[k].double()
+        disp = (a - P[k].double()).abs().max().item()
+        assert (a - b).abs().max().item() <= 0.02 * disp + 1e-9, k
+
+
+@needs_two_gpus
+def test_bench_two_gpus_reports_two_rccl_ranks_and_a_strong_leg():
+    """`python bench.py --gpus 2 --steps 3` on a box with two devices: self-launched RCCL ranks, rccl_ranks = 2, the weak line
+    (B=8 per GPU) and the strong leg (global batch 8 sharded)."""
+    import gc, json, subprocess, sys
+    gc.collect()
+    torch.cuda.empty_cache()
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline", "--no-roofline"],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 16 and line["value"] > 0
+    assert line["strong"]["global_batch"] == 8 and line["strong"]["per_gpu_batch"] == 4 and line["strong"]["value"] > 0
 
 
 def test_forced_gradsync_bench_costs_under_one_percent():

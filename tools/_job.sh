@@ -1,4 +1,3 @@
-set -x
 mkdir -p gpurun_out/r06
-timeout 1500 python -m pytest tests/test_hip_network.py tests/test_hip_train_step.py -q > gpurun_out/r06/t_net.txt 2>&1
-tail -25 gpurun_out/r06/t_net.txt
+timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/r06/t_all.txt 2>&1
+tail -15 gpurun_out/r06/t_all.txt

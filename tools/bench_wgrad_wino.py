@@ -1,8 +1,6 @@
 #!/usr/bin/env python3
 """fp32 Winograd weight gradient at the config-2 shapes, 8 grouped time steps per launch as in the train step: the F(2x2,3x3)
-tile (algo 1, "regs") against the 2x4-tile form (algo 5, "f24"; default) or, with OTHER=f4 / OTHER=dma, the F(3x3,4x4) tile
-(algo 6) / the LDS-DMA double-buffered F(2x2) experiment (algo 4), both in libraries built with REFID_EXPERIMENTAL_TILES=1.  Not bit-equal: the largest relative difference is
-printed."""
+tile (algo 1, "regs") against the 2x4-tile form (algo 5, "f24").  Not bit-equal: the largest relative difference is printed."""
 import os
 import subprocess
 import sys
@@ -55,9 +53,9 @@ def run(tag, algo):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        run(sys.argv[1], {"regs": 1, "dma": 4, "f24": 5, "f4": 6}[sys.argv[1]])
+        run(sys.argv[1], {"regs": 1, "f24": 5}[sys.argv[1]])
     else:
-        other = os.environ.get("OTHER", "f24")                # "f4" / "dma": experimental builds (F(3x3,4x4), LDS-DMA F(2x2))
+        other = "f24"
         for tag in ("regs", other):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), tag])
         import torch

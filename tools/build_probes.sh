@@ -11,8 +11,7 @@ set -euo pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
 python tools/probes/wino6_ablate.py --build
-python tools/probes/wgrad_wino_ablate.py --build          # (builds with REFID_EXPERIMENTAL_TILES=1: its algo 4 lives there)
-python -m refid_amd.build > /dev/null                      # product objects again: the 2x4 weight-gradient variants link them
+python tools/probes/wgrad_wino_ablate.py --build
 python tools/probes/w24_ablate.py --build
 python -m refid_amd.build > /dev/null                      # back to the product library
 mkdir -p tools/probes/bin

@@ -15,9 +15,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 BIN = os.path.join(ROOT, "tools", "probes", "bin")
 VARIANTS = {0: "product tile (algo 1)", 1: "tiles not re-staged (no ds_write pass, no 2nd barrier)", 2: "no global tile loads",
-            3: "no loads, stores, barriers (NOT a bound: LDS reads hoisted)", 4: "3 + operands from registers",
-            100: "LDS-DMA tile (algo 4)", 5: "LDS-DMA: no DMA in the K loop", 6: "LDS-DMA: no wait / barrier",
-            11: "LDS-DMA: every request dead (no memory traffic)", 12: "LDS-DMA: the LDS-fed loop by itself (no DMA, no sync)"}
+            3: "no loads, stores, barriers (NOT a bound: LDS reads hoisted)", 4: "3 + operands from registers"}
+# (variants 100 / 5 / 6 / 11 / 12 priced the LDS-DMA form of this tile, refid_wgrad_desc.algo 4: removed with csrc/experimental/
+#  in round 6; its numbers: profiles/r03_*)
 if os.environ.get("WW_ONLY"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["WW_ONLY"].split(",")}
 
@@ -38,14 +38,10 @@ def check_fresh(path):
 
 
 def build():
-    os.environ["REFID_EXPERIMENTAL_TILES"] = "1"          # algo 4 lives in experimental builds
     from refid_amd.build import FLAGS, HIPCC, build as build_main
     build_main()
-    FLAGS = FLAGS + ["-DREFID_EXPERIMENTAL_TILES"]
     os.makedirs(BIN, exist_ok=True)
-    objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "refid_amd", "csrc", "*.o")) +
-                            glob.glob(os.path.join(ROOT, "refid_amd", "csrc", "experimental", "*.o")))
-            if os.path.basename(o) != "wgrad_wino.o"]
+    objs = [o for o in sorted(glob.glob(os.path.join(ROOT, "refid_amd", "csrc", "*.o"))) if os.path.basename(o) != "wgrad_wino.o"]
     for v in VARIANTS:
         obj = os.path.join(BIN, f"wgrad_wino_abl{v}.o")
         subprocess.check_call([HIPCC] + FLAGS + [f"-DREFID_WW_ABLATE={v % 100}", "-I", os.path.join(ROOT, "refid_amd", "csrc"),

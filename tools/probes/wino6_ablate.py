@@ -19,7 +19,9 @@ VARIANTS = {0: "product", 1: "U fragments cache resident", 2: "no three-plane sp
             7: "no raw loads / LDS stores in the K loop", 8: "neither (6 + 7)", 9: "odd-slot workgroup starts 4 us late",
             10: "no K loop, no epilogue traffic (3 + 4)", 11: "odd-slot workgroup starts 8 us late",
             12: "U loads: same 16 bytes for every lane", 13: "half the U loads",
-            14: "three products, two U planes", 15: "three products, two U planes, no split"}
+            14: "three products, two U planes", 15: "three products, two U planes, no split",
+            16: "fp16 form: no max / rescale / scale", 17: "fp16 form: one-instruction max", 18: "fp16 form: no split"}
+TERMS = int(os.environ.get("WINO6_TERMS", "0"))          # 3: time the three-fp16-product form (variants 0, 16-18)
 if os.environ.get("WINO6_ONLY"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["WINO6_ONLY"].split(",")}
 EXTRA = os.environ.get("WINO6_FLAGS", "").split()
@@ -76,11 +78,11 @@ def run(v):
         r = torch.randn(B, H, H, Co, device="cuda") if rm else None
         m = torch.randn(B, H, H, Co, device="cuda") if rm else None
         bias = torch.randn(Co, device="cuda")
-        w6 = ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, Co, Ci)
+        w6 = ops.pack_conv_weights_wino6(w, ops.ROLE_WINO_FWD, Co, Ci, f16=TERMS == 3)
         t = timeit(lambda: ops.conv2d(a, w6, out, kh=3, kw=3, pad=1, cout=Co, cout_pad=-(-Co // 64) * 64, in_b=b, bias=bias,
-                                      res=r, mask=m, slope_mask=0.2, slope_pre=0.1, algo=5))
+                                      res=r, mask=m, slope_mask=0.2, slope_pre=0.1, algo=5, terms=TERMS))
         row.append(f"{name} {t * 1e6:7.1f}")
-    print(f"[{v}{TAG}] {VARIANTS[v]:32s} " + " | ".join(row), flush=True)
+    print(f"[{v}{TAG}{' fp16x3' if TERMS == 3 else ''}] {VARIANTS[v]:32s} " + " | ".join(row), flush=True)
 
 
 if __name__ == "__main__":

@@ -411,7 +411,7 @@ def parse_args(argv=None):
                     help="--mode infer --config 5: tiles per forward call (val.max_minibatch)")
     ap.add_argument("--no-strong-leg", action="store_true", help="N>1 weak runs: skip the extra strong-scaling timing")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the step from captured hipGraphs (auto = off: measured slower than eager launches)")
+                    help="replay the step from captured hipGraphs (auto: while B*H*W <= 2*256*256 per GPU)")
     ap.add_argument("--dtype", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="fp32 = BASELINE configs[1] (headline); bf16 = config-3 style compute (bf16 MFMA operands)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="gloo: --dry-run only")
@@ -585,9 +585,10 @@ def main(argv=None, claim_stdout=False):
             else:
                 x, ev, gt = synthetic_batch(per_gpu_batch, args.T, args.size, args.size, args.img_chn, 100 + rank, dev)
                 model.feed_data({"lq": x, "voxel": ev, "gt": gt})
-            use_graph = args.graph == "on"      # auto: eager (measured r02: replay 164 -> 171 ms at B=1; the GPU is the limiter)
+            # auto (default): replayed from hipGraphs while B H W <= 2 x 256 x 256 per GPU (round 6: B=1 83.1 vs 85.9-87.5 ms
+            # eager; the 8-GPU strong-scaling shard), eager launches above (B=8: the GPU is the limiter)
             if hasattr(model, "set_graph_mode"):
-                model.set_graph_mode(use_graph)
+                model.set_graph_mode({"on": True, "off": False, "auto": "auto"}[args.graph])
 
         def one():
             nonlocal it
@@ -620,6 +621,7 @@ def main(argv=None, claim_stdout=False):
 
     per_gpu = args.batch if args.scaling == "weak" else args.batch // world
     dt = timed(per_gpu, args.steps, args.warmup)
+    replayed = bool(getattr(model, "graph_on", False))          # did the timed steps run from hipGraphs? (--graph auto / on)
     loss = model.get_current_log()["l_pix"]
 
     roof = None
@@ -693,6 +695,7 @@ def main(argv=None, claim_stdout=False):
                        "global_batch": gbatch, "parallelism": f"dp{world}", "loss": round(loss, 6)},
         }
         if not args.dry_run:
+            out["launch"] = "hipGraph replay" if replayed else "eager launches"
             out["h2d"] = ("prefetched, in timed region (pinned host batch -> HBM on a side stream during the previous step; "
                           "feed_data inside the loop)") if args.h2d == "prefetch" else "resident (fed once before the timed region)"
             out["h2d_ms_exposed"] = h2d["exposed_ms"]

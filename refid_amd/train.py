@@ -106,6 +106,8 @@ class TwoImageEventRecurrentRestorationModel:
             raise NotImplementedError(f"Scheduler {self.sched_type} is not implemented yet. (supported: {SCHEDULERS})")
         self.sched_cfg = sch
         self.total_iter = train_opt.get("total_iter")
+        # train.graph_replay: "off" (default: eager launches, as every earlier round), "on", or "auto" (small batches only)
+        self._graph_opt = train_opt.get("graph_replay", "off")
         self.use_grad_clip = train_opt.get("use_grad_clip", True)
         eng = self.net_g.engine
         self.exp_avg = torch.zeros_like(eng.arena.flat_p)
@@ -123,6 +125,8 @@ class TwoImageEventRecurrentRestorationModel:
         self.dist_on = self.world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized()
                                           and os.environ.get("REFID_FORCE_GRADSYNC") == "1")
         self.grad_sync = GradSync(eng.arena.flat_g, eng.arena.offsets) if self.dist_on else None
+        if self._graph_opt in ("on", "auto", True):
+            self.set_graph_mode("auto" if self._graph_opt == "auto" else True)
         if self.dist_on:            # DDP's parameter broadcast from rank 0 (base_model.py:66-72)
             torch.distributed.broadcast(eng.arena.flat_p, src=0)
             eng.mark_params_changed()
@@ -158,6 +162,11 @@ class TwoImageEventRecurrentRestorationModel:
         replay it afterwards -- one graph on a single GPU; three graphs (forward + forward-sweep BPTT | backward-sweep
         BPTT | clip + AdamW) with the two RCCL all-reduce phases issued eagerly in between when data-parallel.  The
         captured step is re-captured when the input shapes change.  off: eager launches (the default)."""
+        if on == "auto":                           # decided per batch geometry at the next optimize_parameters()
+            self._graph_auto = hasattr(self.net_g.engine, "backward_early")
+            on = False
+        else:
+            self._graph_auto = False
         on = bool(on)
         if on and not hasattr(self.net_g.engine, "backward_early"):
             raise NotImplementedError("graph mode is implemented for FinalBidirectionAttenfusion's engine only")
@@ -245,9 +254,12 @@ class TwoImageEventRecurrentRestorationModel:
         if g["hyper_evt"][slot] is not None:
             g["hyper_evt"][slot].synchronize()
         h = g["hyper_host"][slot]
+        # the bias corrections exactly as refid_clip_adamw forms them (float betas, double pow, one rounding to float): the
+        # replayed step then equals the eager step bit for bit
+        b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)
         h[0] = self.cur_lr
-        h[1] = 1.0 - self.betas[0] ** self.step_count
-        h[2] = math.sqrt(1.0 - self.betas[1] ** self.step_count)
+        h[1] = 1.0 - b1 ** self.step_count
+        h[2] = math.sqrt(1.0 - b2 ** self.step_count)
         g["hyper"].copy_(h, non_blocking=True)
         g["hyper_evt"][slot] = torch.cuda.Event()
         g["hyper_evt"][slot].record()
@@ -280,8 +292,19 @@ class TwoImageEventRecurrentRestorationModel:
         self._step_done = torch.cuda.Event()
         self._step_done.record()
 
+    # "auto": replay the step from hipGraphs while the per-GPU batch is small -- B H W <= GRAPH_AUTO_MAX_PIX (two samples at
+    # 256 x 256): there a step is ~4800 launches of ~17 us of GPU time each and the Python / ctypes enqueue is part of what the
+    # step waits for (round 6, B=1: 83.1 replayed vs 85.9-87.5 ms eager on one box); at B=8 the GPU is the limiter and the
+    # replay buys nothing.  Same results as eager launches (tests/test_hip_ddp.py, test_hip_train_step.py).
+    GRAPH_AUTO_MAX_PIX = 2 * 256 * 256
+
     def optimize_parameters(self, current_iter):
         self._bound_run_ahead()
+        if getattr(self, "_graph_auto", False):
+            small = self.lq.shape[0] * self.lq.shape[-2] * self.lq.shape[-1] <= self.GRAPH_AUTO_MAX_PIX
+            if small != getattr(self, "graph_on", False):
+                self.set_graph_mode(small)
+                self._graph_auto = True
         if getattr(self, "graph_on", False):
             self._step_graph()
             return self._mark_step_end()

@@ -245,6 +245,26 @@ def test_early_all_reduce_is_enqueued_before_the_backward_sweep_bptt():
     assert all(g >= 0.0 for g in gaps)             # compute-stream events in the same order
 
 
+def test_graph_replay_with_a_one_rank_rccl_group_equals_eager_bit_for_bit():
+    """The three-graph form of the step (forward + forward-sweep BPTT | backward-sweep BPTT | clip + AdamW) with REAL RCCL
+    all-reduces issued between the replays -- a 1-rank 'nccl' group, what a one-GPU box can run -- gives the bits of the
+    eager step with the same collectives: graph replay is the default for small per-GPU batches (bench.py --graph auto,
+    train.graph_replay: auto), i.e. for the 8-GPU strong-scaling shard."""
+    rets = []
+    for graph in (False, True):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        ret = ctx.Manager().dict()
+        mp.spawn(_worker, args=(1, port, ret, "nccl", graph), nprocs=1, join=True)
+        rets.append(ret[0])
+    (le, ge, sde), (lg, gg, sdg) = rets
+    nbits = sum(int(not torch.equal(sde[k], sdg[k])) for k in sde)
+    print(f"graph vs eager with a 1-rank RCCL group: loss {le!r} / {lg!r}, grad norm {ge!r} / {gg!r}, {nbits} of {len(sde)} tensors differ in some bit")
+    assert le == lg and ge == gg
+    for k in sde:
+        assert torch.equal(sde[k], sdg[k]), k
+
+
 needs_two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL takes one rank per device")
 
 

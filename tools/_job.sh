@@ -1,3 +1,1 @@
-mkdir -p gpurun_out/r06
-timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/r06/t_all.txt 2>&1
-tail -15 gpurun_out/r06/t_all.txt
+timeout 1200 python -m pytest tests/test_hip_ddp.py -x -q -s -k "graph_replay_with" 2>&1 | grep -v amdgpu.ids | tail -8

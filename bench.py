@@ -190,7 +190,7 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
         if name.startswith("conv_split_kernel<"):
             # the event timing groups the split tile by its product count; rocprof names the template instances
             # <MT, NT, planes, KS, mode>: launch-weighted mean over the instances with that many planes
-            planes = {"1": 1, "3": 2, "6": 3}[name[len("conv_split_kernel<"):-1]]
+            planes = {"1": 1, "3": 2, "6": 3}[name[len("conv_split_kernel<"):-1].split(",")[0]]
             rows = [v for k, v in table.items() if k.startswith("conv_split_kernel<") and
                     int(k[len("conv_split_kernel<"):-1].split(",")[2]) == planes]
             if rows:
@@ -215,7 +215,8 @@ def roofline_from_profile(prof, step_seconds, dtype, unit_note, traffic_lookup=T
         ach = executed / sec / 1e12
     if "split" in name:
         # split-bf16 tile: `terms` bf16 MFMAs per direct-conv multiply (+ 1/9 for the zero tenth tap of its tap pairs)
-        executed = fl * int(name.split("<")[1].split(">")[0]) * 10.0 / 9.0
+        # ("<3, fp16>": three fp16 products on two-plane operands; the stride-2 modes it serves have no zero tap)
+        executed = fl * int(name.split("<")[1].split(">")[0].split(",")[0]) * (1.0 if "fp16" in name else 10.0 / 9.0)
         ach = executed / sec / 1e12
     if "bf16" in name or "split" in name or "wino6" in name:
         # bf16 matrix-core operands: the dense bf16 MFMA peak is 2.5 PFLOP/s (MI355X_MICROARCH.md); such a

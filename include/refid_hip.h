@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define REFID_ABI_VERSION 9     /* 9: refid_conv_desc.algo 5 with mfma_terms 3 (Winograd x three fp16 products), refid_pack_conv_weights_wino3h, pack-table kind 5 + refid_pack_batch_prepass; 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8, refid_rows_sum_defer / _flush; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
+#define REFID_ABI_VERSION 9     /* 9: refid_conv_desc.algo 5 with mfma_terms 3 (Winograd x three fp16 products) / algo 4 with mfma_terms 19 (conv_down on three fp16 products), refid_pack_conv_weights_wino3h / _split_f16, pack-table kinds 5 / 6 + refid_pack_batch_prepass; 8: refid_wgrad_desc.phase 4 + refid_wgrad_finish_flush (batched slab reductions), refid_*_tb layout conversions, REFID_ROLE_CONVT_DGRAD_PW, refid_wgrad_desc.algo 8, refid_rows_sum_defer / _flush; 7: refid_wgrad_desc.algo 5 (2x4 Winograd tiles) / 6; thin-output 3x3 weight gradient */
 
 const char* refid_last_error(void);
 int refid_abi_version(void);
@@ -159,7 +159,11 @@ typedef struct refid_conv_desc {
                                                    algo 4: 0 / 6 = three bf16 planes per operand, six products
                                                    (error <= 2^-23 per product: fp32 class, closer to the fp64 result
                                                    than the fp32 Winograd tile); 3 = two planes, three products
-                                                   (2^-16 per product: explicit opt-in, still finer than TF32).
+                                                   (2^-16 per product: explicit opt-in, still finer than TF32); 19 (16 + 3;
+                                                   4x4 stride 2 forward / input gradient only) = three fp16 products on
+                                                   two-plane operands scaled by exact powers of two (w_packed from
+                                                   refid_pack_conv_weights_split_f16): ~2^-22 per product, the fp32 class
+                                                   at half of 6's MFMAs.
                                                    algo 5: 0 / 6 = six bf16 products on three-plane operands; 3 = three
                                                    fp16 products on two-plane operands h = rne16(v), l = rne16(v - h)
                                                    (~2^-22 per product, below the fp32 accumulation's own error at
@@ -307,6 +311,12 @@ int refid_pack_conv_weights_bf16(const float* w, const float* oscale, void* pack
  *                                                 (t < 4) or 8 + 4h + (t - 4)
  * refid_packed_weight_split_bytes gives the buffer size. */
 size_t refid_packed_weight_split_bytes(int role, int o, int i, int kh, int kw, int bn, int planes);
+/* The 3x3 / 4x4 layouts above with TWO fp16 planes h = rne16(w 2^eW), l = rne16(w 2^eW - h) behind a 64-byte header (int eW at
+ * byte 0: max |w| 2^eW in [2^12, 2^13), found by a reduction over the tensor that the call launches first), for refid_conv2d
+ * algo 4 with mfma_terms = 19.  `packed` must be 16-byte aligned. */
+size_t refid_packed_weight_split_f16_bytes(int role, int o, int i, int kh, int kw, int bn);
+int refid_pack_conv_weights_split_f16(const float* w, const float* oscale, void* packed, int role, int o, int i,
+                                      int kh, int kw, int bn, void* stream);
 int refid_pack_conv_weights_split(const float* w, const float* oscale, void* packed, int role, int o, int i,
                                   int kh, int kw, int bn, int planes, void* stream);
 /* Winograd-domain weights U = G g G^T (times oscale[row] when given) for refid_conv2d algo 5: computed in fp32 like
@@ -325,9 +335,10 @@ int refid_pack_conv_weights_wino3h(const float* w, const float* oscale, void* pa
 /* All packings of a model in ONE launch.  The caller builds a table of refid_pack_entry_bytes()-sized records in host
  * memory with refid_pack_entry_fill (kind 0: refid_pack_conv_weights[_scaled / _bf16] -- `planes` = 1 selects bf16 output;
  * 1: refid_pack_conv_weights_split, 3x3 / 4x4; 2: the same, 1x1; 3: refid_pack_conv_weights_wino6; 4: dst[e] = w[e] *
- * oscale[e] for e < o (refid_mul_vec); 5: refid_pack_conv_weights_wino3h), copies it to device memory once, and calls
+ * oscale[e] for e < o (refid_mul_vec); 5: refid_pack_conv_weights_wino3h; 6: refid_pack_conv_weights_split_f16), copies it to
+ * device memory once, and calls
  * refid_pack_batch whenever the weights have changed -- after refid_pack_batch_prepass on the same stream when the table holds
- * kind-5 records (their scale exponents: one workgroup per record, a no-op for the other kinds).  `blk0` = the sum of the values returned for the records before this one (each call returns its record's
+ * kind-5 / kind-6 records (their scale exponents: one workgroup per record, a no-op for the other kinds).  `blk0` = the sum of the values returned for the records before this one (each call returns its record's
  * workgroup count >= 1, -1 on error -- the same argument checks as the one-by-one entry points); nblocks = the sum over
  * all records.  refid_pack_table_check walks a finished HOST table (every record filled, first blocks consecutive from 0:
  * the kernel finds a workgroup's record by binary search over them) and returns that sum, -1 on error.  Same bits as the

@@ -136,6 +136,9 @@ def _bind_extra(L):
     L.refid_packed_weight_wino3h_bytes.restype = C.c_size_t
     L.refid_pack_conv_weights_wino3h.argtypes = [vp, vp, vp] + [i] * 4 + [vp]
     L.refid_pack_batch_prepass.argtypes = [vp, i, vp]
+    L.refid_packed_weight_split_f16_bytes.argtypes = [i] * 6
+    L.refid_packed_weight_split_f16_bytes.restype = C.c_size_t
+    L.refid_pack_conv_weights_split_f16.argtypes = [vp, vp, vp] + [i] * 6 + [vp]
     L.refid_mul_vec.argtypes = [vp, vp, vp, i, vp]
     L.refid_pack_entry_bytes.restype = C.c_size_t
     L.refid_pack_entry_bytes.argtypes = []

@@ -18,7 +18,16 @@
 //     tests/test_hip_conv.py::test_split_tile_accuracy_classes) -- an experiment switch for 3x3;
 //   * TERMS = 3 keeps the first three products (two planes per operand, 2^-16 relative: finer than TF32, which is
 //     what the reference's own GPU path multiplies with by default): 1.4-1.55x faster than the Winograd tile, an
-//     explicit opt-in (compute_dtype bf16x3);  TERMS = 1 is plain bf16 operands (compute_dtype bf16).
+//     explicit opt-in (compute_dtype bf16x3);  TERMS = 1 is plain bf16 operands (compute_dtype bf16);
+//   * F16 (round 6, mfma_terms 19; conv_down forward / input gradient): TWO fp16 planes h = rne16(v), l = rne16(v - h) carry 22
+//     bits, three v_mfma_f32_32x32x16_f16 (hh + hl + lh) give the product to ~2^-22 -- half the MFMAs of the six-bf16-product
+//     form at the fp32 class's accuracy.  fp16's range (2^-14 .. 2^16) is bridged by exact power-of-two scales: the weights by
+//     2^eW per packing (refid_pack_conv_weights_split_f16: exponent in the packing's header), the activations per WORKGROUP
+//     and online along K -- a staged halo pixel feeds several output pixels and all four waves, so the scale is the
+//     workgroup's: every stage's largest |x| (thread max -> wave max -> four LDS slots read after the stage's barrier) is
+//     compared with the reference exponent; a stage more than 2^6 above it multiplies the accumulators by 2^(E - E') first
+//     (exact), the output epilogue undoes 2^(8 - E + eW) with v_ldexp.  (conv_wino6.hip's fp16 form scales per tile: there a
+//     lane's operand column is its own.)
 //
 // Mapping (one workgroup = 256 threads = 4 waves, one per SIMD; two workgroups per CU cover each other's staging,
 // barriers, prologue and epilogue -- the regime the trace of the Winograd tile showed to work on this chip):
@@ -44,6 +53,13 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int F16_TGT = 8;              // a freshly scaled stage's largest |x| lands in [2^8, 2^9)
+constexpr int F16_SLACK = 6;            // binades a later stage may exceed the reference before the accumulators are rescaled
+constexpr int F16_E0 = F16_TGT + 1;     // initial (biased) reference exponent: any real data is larger
+constexpr int F16_HEADER = 64;          // bytes in front of the fp16 planes: int eW (runtime.hip)
 constexpr int TW = 32;                  // output pixels per tile row
 constexpr int KC = 8;                   // input channels per chunk (x 2 taps = K of one bf16 MFMA)
 constexpr int NTH = 256;
@@ -78,10 +94,11 @@ __device__ int g_split_ktrace_wg = -1;
 //         arithmetic in the loader.
 // MODE 2: input gradient of conv_down: four output-parity classes (blockIdx.y), each a 2x2-tap stride-1 conv over the
 //         output gradient with its own weights; output pixels (2y+py, 2x+px).
-template <int MT_, int NT_, int PL_, int KS_, int MODE_>
+template <int MT_, int NT_, int PL_, int KS_, int MODE_, bool F16_ = false>
 struct SCfg {
     static constexpr int MT = MT_, NT = NT_, PL = PL_, KS = KS_;   // KS: 8-channel sub-chunks per LDS stage (barrier pair)
     static constexpr int MODE = MODE_;
+    static constexpr bool F16 = F16_;                       // two fp16 planes + scales instead of PL bf16 planes
     static constexpr int TH = 4 * MT, BN = 32 * NT;
     static constexpr int HWD = (MODE == 1) ? TW + 1 : TW + 2;
     static constexpr int NTAP = (MODE == 0) ? 10 : 4;        // taps per sub-chunk in LDS / packed weights
@@ -93,7 +110,7 @@ struct SCfg {
     static constexpr int B_ITEMS = (PL * B_SLOTS + NTH - 1) / NTH;
     static constexpr int C4 = BN / 4;                       // float4 per output pixel
     static constexpr int XS = C4 + 1;                       // padded pixel pitch of the epilogue strip
-    static constexpr int LDS_LOOP = KS * PL * (A_SLOTS + B_SLOTS) * 16;
+    static constexpr int LDS_LOOP = KS * PL * (A_SLOTS + B_SLOTS) * 16 + (F16 ? 16 : 0);   // (+ the four wave maxima)
     static constexpr int LDS_EPI = 4 * 32 * XS * 16;
     static constexpr int LDS_BYTES = LDS_LOOP > LDS_EPI ? LDS_LOOP : LDS_EPI;
 };
@@ -119,14 +136,32 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, f32x4 (
     if constexpr (PL == 3) pl[2] = __builtin_bit_cast(f32x4, p2);
 }
 
-template <int MT, int NT, int PL, int KS, int MODE>
+// v (8 fp32 channels, scaled into fp16's range) -> two fp16 planes, h + l = v to 22 bits
+__device__ __forceinline__ void split8h(const f32x4& v0, const f32x4& v1, f32x4 (&pl)[2]) {
+    f16x8 h, l;
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        const f32x2 ab = {k < 4 ? v0[k] : v1[k - 4], k < 4 ? v0[k + 1] : v1[k - 3]};
+        const f16x2 hh = __builtin_convertvector(ab, f16x2);
+        const f32x2 r = ab - __builtin_convertvector(hh, f32x2);
+        const f16x2 ll = __builtin_convertvector(r, f16x2);
+        h[k] = hh[0]; h[k + 1] = hh[1];
+        l[k] = ll[0]; l[k + 1] = ll[1];
+    }
+    pl[0] = __builtin_bit_cast(f32x4, h);
+    pl[1] = __builtin_bit_cast(f32x4, l);
+}
+
+template <int MT, int NT, int PL, int KS, int MODE, bool F16 = false>
 __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
-    using C = SCfg<MT, NT, PL, KS, MODE>;
+    using C = SCfg<MT, NT, PL, KS, MODE, F16>;
+    static_assert(!F16 || PL == 2, "the fp16 form has two planes");
     constexpr int HP = C::HP, BN = C::BN, HWD = C::HWD, NTAP = C::NTAP, NSTEP = C::NSTEP;
     static_assert(MODE != 1 || KS == 2, "MODE 1: a stage = the two column positions of a block");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* sA = reinterpret_cast<f32x4*>(smem);              // [KS][PL][HP]
     f32x4* sB = sA + KS * PL * C::A_SLOTS;                   // [KS][PL][10][BN]
+    float* sM = reinterpret_cast<float*>(sB + KS * PL * C::B_SLOTS);   // F16: the waves' largest |x| of the stage being staged
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -160,8 +195,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     const int cls = (MODE == 2) ? blockIdx.y : 0;            // MODE 2: output parity class (py, px)
     const int py = cls >> 1, px = cls & 1;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(const_cast<float*>(a.w)) + (long long)cls * nsub * wChunk, 0,
+        reinterpret_cast<char*>(const_cast<float*>(a.w)) + (F16 ? F16_HEADER : 0) + (long long)cls * nsub * wChunk, 0,
         (int)min((long long)nsub * wChunk, 0x7fffffffLL), 0x00020000);
+    const int eW = F16 ? *reinterpret_cast<const int*>(a.w) : 0;       // the weights travel as w 2^eW
+    int eRef = F16_E0;                                       // F16: the workgroup's reference exponent (biased)
     // MODE 0 / 2: voA / voB[it] = the halo pixel of item `it` in source A / B.  MODE 1: voA[it] / voB[it] = the pixel at
     // ROW position sy = 0 / 1 of halo block `it`, column position 0; vo1x[sy][it] = column position 1 (validity differs)
     int voA[C::A_ITEMS], voB[C::A_ITEMS], vo1x[2][MODE == 1 ? C::A_ITEMS : 1];
@@ -237,14 +274,49 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
         }
     };
     auto load_chunk = [&](int ch) { load_part(ch, -1); };
-    auto store_chunk = [&]() {
+    // F16: this thread's / wave's largest |x| of the stage in `ra` -> the wave's LDS slot (read by everybody after the barrier)
+    auto post_max = [&]() {
+        float tm = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < KS; ++sub)
+#pragma unroll
+            for (int it = 0; it < C::A_ITEMS; ++it)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const f32x4 v = ra[sub][it][h];
+                    tm = fmaxf(fmaxf(tm, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tm = fmaxf(tm, __shfl_xor(tm, o));
+        if (lane == 0) sM[wave] = tm;
+    };
+    f32x16 acc[MT][NT];
+    // after the barrier: the stage's scale 2^(TGT - (eRef - 127)); the accumulators follow when the data outgrow the reference
+    auto stage_scale = [&]() -> float {
+        const f32x4 m4 = *reinterpret_cast<const f32x4*>(sM);
+        const int eb = (int)(__float_as_uint(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]))) >> 23);
+        if (eb > eRef + F16_SLACK) {                         // workgroup-uniform, rare
+            const int fe = 127 + eRef - eb;
+            const float f = fe >= 1 ? __uint_as_float((unsigned)fe << 23) : 0.f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][nn][r] *= f;
+            eRef = eb;
+        }
+        return __uint_as_float((unsigned)(F16_TGT + 254 - eRef) << 23);
+    };
+    auto store_chunk = [&](float sc = 1.f) {
 #pragma unroll
         for (int sub = 0; sub < KS; ++sub) {
 #pragma unroll
             for (int it = 0; it < C::A_ITEMS; ++it) {
                 const int hp = tid + it * NTH;
                 f32x4 pl[PL];
-                split8<PL>(ra[sub][it][0], ra[sub][it][1], pl);
+                if constexpr (F16) split8h(ra[sub][it][0] * sc, ra[sub][it][1] * sc, pl);
+                else split8<PL>(ra[sub][it][0], ra[sub][it][1], pl);
                 if (hp < HP) {
 #pragma unroll
                     for (int p = 0; p < PL; ++p) sA[(sub * PL + p) * HP + hp] = pl[p];
@@ -258,7 +330,6 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
         }
     };
 
-    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -289,7 +360,13 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     const f32x4* pB = sB + kh * BN + li;
 
     load_chunk(0);
-    store_chunk();
+    if constexpr (F16) {
+        post_max();
+        __syncthreads();
+        store_chunk(stage_scale());
+    } else {
+        store_chunk();
+    }
     __syncthreads();
     SPLIT_STAMP(1);
 
@@ -314,13 +391,22 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int nn = 0; nn < NT; ++nn)      // consecutive MFMAs hit different accumulators
-                        acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                            __builtin_bit_cast(bf16x8, bf[TB[e]][nn]), __builtin_bit_cast(bf16x8, af[TA[e]][m]),
-                            acc[m][nn], 0, 0, 0);
+                    for (int nn = 0; nn < NT; ++nn) {    // consecutive MFMAs hit different accumulators
+                        if constexpr (F16)
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                __builtin_bit_cast(f16x8, bf[TB[e]][nn]), __builtin_bit_cast(f16x8, af[TA[e]][m]),
+                                acc[m][nn], 0, 0, 0);
+                        else
+                            acc[m][nn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                                __builtin_bit_cast(bf16x8, bf[TB[e]][nn]), __builtin_bit_cast(bf16x8, af[TA[e]][m]),
+                                acc[m][nn], 0, 0, 0);
+                    }
             __builtin_amdgcn_sched_barrier(0);           // keep the step's loads with the step
         }
         SPLIT_KSTAMP(ch, 2);
+        if constexpr (F16) {
+            if (more) post_max();                    // (the next stage's loads have been in flight since this stage's first step)
+        }
         __syncthreads();
         SPLIT_KSTAMP(ch, 3);
 #ifdef REFID_SPLIT_TRACE
@@ -328,7 +414,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
 #endif
         SPLIT_KSTAMP(ch, 4);
         if (more) {
-            store_chunk();
+            if constexpr (F16) store_chunk(stage_scale());
+            else store_chunk();
             SPLIT_KSTAMP(ch, 5);
             __syncthreads();
         }
@@ -373,7 +460,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = acc[m][nn][4 * g + k];
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = acc[m][nn][4 * g + k];
+                    if constexpr (F16) v[k] = ldexpf(v[k], eRef - 127 - F16_TGT - eW);   // undo both scales: exact
+                }
                 ex[li * XS + nn * 8 + 2 * g + kh] = v;
             }
 #pragma unroll
@@ -421,11 +511,11 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     SPLIT_STAMP(3);
 }
 
-template <int MT, int NT, int PL, int KS, int MODE>
+template <int MT, int NT, int PL, int KS, int MODE, bool F16 = false>
 int launch_split(const ConvKArgs& ka, hipStream_t st) {
-    using C = SCfg<MT, NT, PL, KS, MODE>;
+    using C = SCfg<MT, NT, PL, KS, MODE, F16>;
     static std::atomic<unsigned long long> attr_done{0};
-    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL, KS, MODE>, C::LDS_BYTES, "conv_split")) return rc;
+    if (int rc = refid_lds_attr_once(attr_done, &conv_split_kernel<MT, NT, PL, KS, MODE, F16>, C::LDS_BYTES, "conv_split")) return rc;
     ConvKArgs a = ka;
     a.tilesX = cdiv(a.Wo, TW);
     a.tilesY = cdiv(a.Ho, C::TH);
@@ -433,7 +523,7 @@ int launch_split(const ConvKArgs& ka, hipStream_t st) {
     a.ncot = cdiv(a.Cout, C::BN);
     const int tiles = a.tilesX * a.tilesY * a.N;
     dim3 grid(cdiv(tiles, 8) * 8 * a.ncot, MODE == 2 ? 4 : 1);
-    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL, KS, MODE>), grid, dim3(NTH), C::LDS_BYTES, st, a);
+    hipLaunchKernelGGL((conv_split_kernel<MT, NT, PL, KS, MODE, F16>), grid, dim3(NTH), C::LDS_BYTES, st, a);
     REFID_LAUNCH_CHECK("conv_split");
     return 0;
 }
@@ -441,11 +531,11 @@ int launch_split(const ConvKArgs& ka, hipStream_t st) {
 // stage depth of the 3x3 tile KS = 1: deeper stages (2 sub-chunks for two planes, 4 for one: fewer barriers, same LDS as
 // three planes) measured 4-8 % SLOWER on every shape -- the barrier pair is not what the short stages wait for.  The
 // 2x2-tap modes have two MFMA steps per sub-chunk and always stage two.
-template <int PL, int MODE>
+template <int PL, int MODE, bool F16 = false>
 int launch_split_pl(const ConvKArgs& a, bool wide, bool tall, hipStream_t st) {
     constexpr int KS = (MODE == 0) ? 1 : 2;
-    if (wide) return tall ? launch_split<2, 2, PL, KS, MODE>(a, st) : launch_split<1, 2, PL, KS, MODE>(a, st);
-    return tall ? launch_split<2, 1, PL, KS, MODE>(a, st) : launch_split<1, 1, PL, KS, MODE>(a, st);
+    if (wide) return tall ? launch_split<2, 2, PL, KS, MODE, F16>(a, st) : launch_split<1, 2, PL, KS, MODE, F16>(a, st);
+    return tall ? launch_split<2, 1, PL, KS, MODE, F16>(a, st) : launch_split<1, 1, PL, KS, MODE, F16>(a, st);
 }
 
 }  // namespace
@@ -465,15 +555,19 @@ bool refid_split3x3_eligible(const ConvKArgs& a) {
            a.ldA % 4 == 0 && (!a.inB || a.ldB % 4 == 0);
 }
 
-// terms: 6 (three planes per operand: fp32-class products), 3 (two planes: 2^-16 relative) or 1 (plain bf16 operands)
+// terms: 6 (three planes per operand: fp32-class products), 3 (two planes: 2^-16 relative), 1 (plain bf16 operands) or 19 (two
+// fp16 planes, three products on scaled operands: the fp32 class at half of 6's MFMAs; the stride-2 modes only)
 // mode: 0 = 3x3 stride 1; 1 = 4x4 stride 2 pad 1 forward; 2 = its input gradient (a.Ho / a.Wo = the gradient's grid)
 int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipStream_t st) {
-    REFID_CHECK(terms == 1 || terms == 3 || terms == 6, "conv2d: split tile takes 1, 3 or 6 product terms (got %d)", terms);
+    REFID_CHECK(terms == 1 || terms == 3 || terms == 6 || (terms == 19 && mode != 0),
+                "conv2d: split tile takes 1, 3 or 6 product terms, or 19 (three fp16 products; 4x4 stride 2 and its input "
+                "gradient only) (got %d)", terms);
+    REFID_CHECK(terms != 19 || (reinterpret_cast<uintptr_t>(a.w) & 15) == 0, "conv2d: the fp16 split packing must be 16-byte aligned");
     REFID_CHECK(refid_split3x3_eligible(a) && (mode == 0 || a.inB == nullptr),
                 "conv2d: split tile needs channel counts that are multiples of 8, tensors below 2 GiB and, for the stride-2 "
                 "modes, a single source");
     {   // the weight fragments are fetched with 32-bit buffer offsets as well
-        const long long planes = terms == 6 ? 3 : (terms == 3 ? 2 : 1);
+        const long long planes = terms == 6 ? 3 : ((terms == 3 || terms == 19) ? 2 : 1);
         const long long wbytes = (long long)cdiv(a.Ctot, KC) * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? 10 : 4) * a.CoutPad * 16;
         REFID_CHECK(wbytes < 0x7fffffffLL, "conv2d: packed weights too large for the split tile's 32-bit offsets");
     }
@@ -484,6 +578,7 @@ int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipS
 #define SPLIT_DISPATCH(PLN)                                                          \
     (mode == 0 ? launch_split_pl<PLN, 0>(a, wide, tall, st)                          \
                : (mode == 1 ? launch_split_pl<PLN, 1>(a, wide, tall, st) : launch_split_pl<PLN, 2>(a, wide, tall, st)))
+    if (terms == 19) return mode == 1 ? launch_split_pl<2, 1, true>(a, wide, tall, st) : launch_split_pl<2, 2, true>(a, wide, tall, st);
     if (terms == 6) return SPLIT_DISPATCH(3);
     if (terms == 3) return SPLIT_DISPATCH(2);
     return SPLIT_DISPATCH(1);

@@ -262,6 +262,39 @@ __device__ __forceinline__ void pack_split_elem(const PackArgs& p, int planes, i
     }
 }
 
+// The same layouts with TWO fp16 planes h = rne16(v 2^eW), l = rne16(v 2^eW - h) behind a 64-byte header (int eW at byte 0, as
+// the Winograd x three packing below): conv_split.hip's three-fp16-product form (refid_conv2d algo 4, mfma_terms 19).
+template <class IDX>
+__device__ __forceinline__ void pack_split_f16_elem(const PackArgs& p, int mode, IDX e) {
+    const int ntp = mode == 0 ? p.ntaps + 1 : 4;
+    const int nsub = mode == 1 ? 4 : 1;
+    const int eW = *reinterpret_cast<const int*>(p.dst);
+    _Float16* dst = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(p.dst) + 64);
+    IDX r = e;
+    const int k8 = r % 8; r /= 8;
+    const int row = r % p.rowsPad; r /= p.rowsPad;
+    const int tap = r % ntp; r /= ntp;
+    const int plane = r % 2; r /= 2;
+    const int sub = r % nsub; r /= nsub;
+    const int chunk = r % p.nchunks;
+    const int cls = r / p.nchunks;
+    const int k = chunk * 8 + k8;
+    float v = 0.f;
+    if (row < p.rows && k < p.K) {
+        if (mode == 0) { if (tap < p.ntaps) v = pack_fetch(p, 0, tap, row, k); }
+        else if (mode == 1) v = pack_fetch(p, 0, (2 * (tap >> 1) + (sub >> 1)) * 4 + 2 * (tap & 1) + (sub & 1), row, k);
+        else v = pack_fetch(p, cls, tap, row, k);
+    }
+    v = ldexpf(v, eW);
+    const _Float16 h = (_Float16)v;
+    dst[e] = plane == 0 ? h : (_Float16)(v - (float)h);
+}
+
+__global__ __launch_bounds__(256) void pack_split_f16_kernel(const PackArgs p, int mode) {
+    const long long total = (long long)p.ncls * p.nchunks * (mode == 1 ? 4 : 1) * 2 * (mode == 0 ? p.ntaps + 1 : 4) * p.rowsPad * 8;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_split_f16_elem<long long>(p, mode, e);
+}
+
 __global__ __launch_bounds__(256) void pack_split_kernel(const PackArgs p, int planes, int mode) {
     const long long total = (long long)p.ncls * p.nchunks * (mode == 1 ? 4 : 1) * planes * (mode == 0 ? p.ntaps + 1 : 4) * p.rowsPad * 8;
     for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) pack_split_elem<long long>(p, planes, mode, e);
@@ -365,8 +398,8 @@ __device__ __forceinline__ int wino3h_scale_exp(float maxabs) {
 
 __device__ __forceinline__ void pack_absmax_block(const PackArgs& p) {       // one workgroup (any size that is a multiple of 64)
     __shared__ float part[16];
-    const long long total = (long long)p.O * p.I * 9;
-    const int per_o = p.I * 9;
+    const long long total = (long long)p.O * p.I * p.KH * p.KW;
+    const int per_o = p.I * p.KH * p.KW;
     float m = 0.f;
     if (p.oscale == nullptr && total % 4 == 0 && (reinterpret_cast<uintptr_t>(p.w) & 15) == 0) {
         const f32x4* w4 = reinterpret_cast<const f32x4*>(p.w);
@@ -443,7 +476,8 @@ __global__ __launch_bounds__(256) void pack_wino3h_kernel(const PackArgs p) {
 struct PackEntry {
     PackArgs p;
     int kind;                  // 0 pack_kernel (fp32 / bf16), 1 split (modes 0-2), 2 1x1 split, 3 Winograd x six, 4 out = a * b (vectors),
-                               // 5 Winograd x three fp16 products (needs refid_pack_batch_prepass before the batch)
+                               // 5 Winograd x three fp16 products, 6 split tile with two fp16 planes (modes 0-2): both need
+                               // refid_pack_batch_prepass before the batch (their scale exponents)
     int planes, mode;
     int blk0, nblk;            // this entry's workgroups: [blk0, blk0 + nblk)
     long long total;           // elements
@@ -464,6 +498,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __rest
         for (unsigned f = (unsigned)e0; f < (unsigned)total; f += (unsigned)stride) pack_wino6_weight(p, f);
     } else if (kind == 5) {
         for (unsigned f = (unsigned)e0; f < (unsigned)total; f += (unsigned)stride) pack_wino3h_weight(p, f);
+    } else if (kind == 6) {
+        for (long long e = e0; e < total; e += stride) pack_split_f16_elem<long long>(p, mode, e);
     } else if (total < 0x7fffffffLL) {
         for (unsigned e = (unsigned)e0; e < (unsigned)total; e += (unsigned)stride) {
             switch (kind) {
@@ -488,7 +524,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackEntry* __rest
 // the scale exponents of every kind-5 record of a table (one workgroup per record; the others leave at once)
 __global__ __launch_bounds__(1024) void pack_prepass_kernel(const PackEntry* __restrict__ table, int n) {
     const PackEntry& en = table[blockIdx.x];
-    if (en.kind != 5) return;
+    if (en.kind != 5 && en.kind != 6) return;
     const PackArgs p = en.p;
     pack_absmax_block(p);
 }
@@ -581,6 +617,31 @@ extern "C" int refid_pack_conv_weights_split(const float* w, const float* oscale
     if (mode == 3) hipLaunchKernelGGL(pack_pw6_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes);
     else hipLaunchKernelGGL(pack_split_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, planes, mode);
     REFID_LAUNCH_CHECK("pack_conv_weights_split");
+    return 0;
+}
+
+extern "C" size_t refid_packed_weight_split_f16_bytes(int role, int o, int i, int kh, int kw, int bn) {
+    PackArgs p;
+    const int mode = split_pack_mode(role, kh, kw);
+    if (mode < 0 || mode == 3) return 0;
+    if (pack_geometry(role, o, i, kh, kw, 8, bn, &p)) return 0;
+    return 64 + (size_t)split_pack_elems(p, 2, mode) * 2;
+}
+
+extern "C" int refid_pack_conv_weights_split_f16(const float* w, const float* oscale, void* packed, int role, int o, int i,
+                                                 int kh, int kw, int bn, void* stream) {
+    PackArgs p;
+    REFID_CHECK(w && packed, "pack_split_f16: null pointer");
+    REFID_CHECK((reinterpret_cast<uintptr_t>(packed) & 15) == 0, "pack_split_f16: the packing must be 16-byte aligned");
+    const int mode = split_pack_mode(role, kh, kw);
+    REFID_CHECK(mode >= 0 && mode != 3, "pack_split_f16: FWD / DGRAD of a 3x3 kernel, FWD / DOWN_DGRAD of a 4x4 (stride 2) kernel");
+    REFID_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_split_f16: unknown role %d", role);
+    p.w = w; p.dst = reinterpret_cast<float*>(packed); p.oscale = oscale; p.bf16 = 1;
+    const long long total = split_pack_elems(p, 2, mode);
+    hipLaunchKernelGGL(pack_absmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+    REFID_LAUNCH_CHECK("pack_conv_weights_split_f16/absmax");
+    hipLaunchKernelGGL(pack_split_f16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p, mode);
+    REFID_LAUNCH_CHECK("pack_conv_weights_split_f16");
     return 0;
 }
 
@@ -680,6 +741,14 @@ extern "C" int refid_pack_entry_fill(void* entry_host, int kind, const float* w,
         p.bf16 = 1;
         en.total = (long long)p.nchunks * p.rowsPad * 16;    // WEIGHTS (one thread each writes its 48 plane entries)
         REFID_FILL_CHECK(en.total * 48 < 0x7fffffffLL, "pack_entry_fill: Winograd x six packing exceeds the 32-bit index range");
+    } else if (kind == 6) {
+        const int mode = split_pack_mode(role, kh, kw);
+        REFID_FILL_CHECK(mode >= 0 && mode != 3, "pack_entry_fill: bad split geometry for the fp16 planes");
+        REFID_FILL_CHECK((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "pack_entry_fill: the fp16 split packing must be 16-byte aligned");
+        REFID_FILL_CHECK(pack_geometry(role, o, i, kh, kw, 8, bn, &p) == 0, "pack_entry_fill: unknown role %d", role);
+        p.bf16 = 1;
+        en.mode = mode;
+        en.total = split_pack_elems(p, 2, mode);
     } else if (kind == 5) {
         REFID_FILL_CHECK((role == REFID_ROLE_WINO_FWD || role == REFID_ROLE_WINO_DGRAD) && kh == 3 && kw == 3, "pack_entry_fill: Winograd roles, 3x3");
         REFID_FILL_CHECK((reinterpret_cast<uintptr_t>(dst) & 15) == 0, "pack_entry_fill: the fp16 Winograd packing must be 16-byte aligned");
@@ -705,7 +774,7 @@ extern "C" int refid_pack_table_check(const void* table_host, int n) {
     const PackEntry* t = reinterpret_cast<const PackEntry*>(table_host);
     long long blk = 0;
     for (int k = 0; k < n; ++k) {
-        REFID_FILL_CHECK(t[k].kind >= 0 && t[k].kind <= 5 && t[k].total > 0 && t[k].nblk >= 1,
+        REFID_FILL_CHECK(t[k].kind >= 0 && t[k].kind <= 6 && t[k].total > 0 && t[k].nblk >= 1,
                          "pack_table_check: record %d was never filled (kind %d, total %lld)", k, t[k].kind, t[k].total);
         REFID_FILL_CHECK(t[k].blk0 == blk, "pack_table_check: record %d starts at block %d, expected %lld", k, t[k].blk0, blk);
         blk += t[k].nblk;

@@ -249,7 +249,10 @@ WINO6_THIN = os.environ.get("REFID_WINO6_THIN", "1") != "0"        # pred's forw
 # conv_down (4x4 / stride 2) and its input gradient have no Winograd form; on the split tile with six bf16 products per
 # fp32 product they run 1.6-2x faster than on the fp32 MFMA tile at the same distance from the float64 result (the operand
 # split is exact: tests/test_hip_conv.py::test_split_tile_conv_down_*).  0 = keep them on the fp32 MFMA tile.
-DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "6"))
+# (round 6: 19 = THREE fp16 products on two-plane operands scaled by exact powers of two -- the weights per tensor, the
+#  activations per workgroup and online along K, csrc/conv_split.hip --: half of 6's MFMAs in the same error class; the default.
+#  6 = six bf16 products on exact three-plane operands, round 2-5's form.)
+DOWN_SPLIT = int(os.environ.get("REFID_DOWN_SPLIT", "19"))
 # 1x1 convolutions on the pointwise tile's six-product form (refid_conv2d algo 3, mfma_terms 6).  Measured
 # (tools/bench_pw6.py, profiles/r03_pw6_bench.txt): 1.03-1.26x the fp32-MFMA form when the launch is repeated on warm
 # operands, NO gain inside the train step (676 launches: 39.8 vs 39.2 ms; the squeeze-excite fused conv3 is slower, 116
@@ -347,6 +350,7 @@ class ConvOp:
         self.arena, self.name, self.kind = arena, name, kind
         self.bf16 = bf16
         self.split = 0                        # product terms of the split-bf16 tile (algo 4) this conv may use
+        self.s_f16 = False                    # ... as three fp16 products (terms 19: the packings hold two fp16 planes)
         self.w = arena.p(name + ".weight")
         self.gw = arena.g(name + ".weight")
         self.has_bias = (name + ".bias") in arena.shapes
@@ -484,17 +488,18 @@ class ConvOp:
                                        dtype=torch.bfloat16, device=dev)
         if kind == "down" and self.ci % 8 == 0 and self.co % 8 == 0 and (bf16 or DOWN_SPLIT or ConvOp.default_split):
             self.split = terms = 1 if bf16 else (ConvOp.default_split or DOWN_SPLIT)
-            self.s_planes = planes = {1: 1, 3: 2, 6: 3}[terms]
+            self.s_planes = planes = {1: 1, 3: 2, 6: 3, ops.TERMS_F16X3: 2}[terms]
+            self.s_f16 = f16 = terms == ops.TERMS_F16X3
             if not bf16:                      # (plain bf16 operands: the LDS-staged tile is as fast on the forward conv)
                 self.sf_bn = ops.conv_bn(4, 4, 2, 0, self.co)
                 self.sf_pad = -(-self.co // self.sf_bn) * self.sf_bn
-                self.wps = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, self.sf_bn, 4, 4, self.co, self.ci, planes) // 2,
+                self.wps = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_FWD, self.sf_bn, 4, 4, self.co, self.ci, planes, f16) // 2,
                                        dtype=torch.bfloat16, device=dev)
             if need_dgrad:
                 self.sd_bn = ops.conv_bn(4, 4, 2, 2, self.ci)
                 self.sd_pad = -(-self.ci // self.sd_bn) * self.sd_bn
                 self.wds = torch.empty(ops.packed_weight_split_bytes(ops.ROLE_DOWN_DGRAD, self.sd_bn, 4, 4, self.co, self.ci,
-                                                                     planes) // 2, dtype=torch.bfloat16, device=dev)
+                                                                     planes, f16) // 2, dtype=torch.bfloat16, device=dev)
         self.b_eff = self.b
         if self.scale is not None and self.has_bias:
             self.b_eff = torch.empty_like(self.b)
@@ -534,10 +539,10 @@ class ConvOp:
         if self.wd6 is not None:
             plan.add_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, self.wd6, oscale=self.scale, f16=self.w6_f16_d)
         if self.wps is not None:
-            plan.add_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, self.s_planes, self.wps, oscale=self.scale)
+            plan.add_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, self.s_planes, self.wps, oscale=self.scale, f16=self.s_f16)
         if self.wds is not None:
             plan.add_split(self.w, ops.ROLE_DOWN_DGRAD if self.kind == "down" else ops.ROLE_DGRAD, self.sd_bn, k, k, self.co,
-                           self.ci, self.s_planes, self.wds, oscale=self.scale)
+                           self.ci, self.s_planes, self.wds, oscale=self.scale, f16=self.s_f16)
         if self.scale is not None and self.has_bias:
             plan.add_mul_vec(self.b, self.scale, self.b_eff)
 
@@ -579,10 +584,10 @@ class ConvOp:
             ops.pack_conv_weights_wino6(self.w, ops.ROLE_WINO_DGRAD, self.co, self.ci, out=self.wd6, oscale=self.scale, f16=self.w6_f16_d)
         if self.wps is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_FWD, self.sf_bn, k, k, self.co, self.ci, planes=self.s_planes,
-                                        out=self.wps, oscale=self.scale)
+                                        out=self.wps, oscale=self.scale, f16=self.s_f16)
         if self.wds is not None:
             ops.pack_conv_weights_split(self.w, ops.ROLE_DOWN_DGRAD if self.kind == "down" else ops.ROLE_DGRAD, self.sd_bn,
-                                        k, k, self.co, self.ci, planes=self.s_planes, out=self.wds, oscale=self.scale)
+                                        k, k, self.co, self.ci, planes=self.s_planes, out=self.wds, oscale=self.scale, f16=self.s_f16)
         if self.scale is not None and self.has_bias:
             ops.mul_vec(self.b, self.scale, out=self.b_eff)
 

@@ -102,14 +102,21 @@ def pack_conv_weights_bf16(w, role, bn, kc, kh, kw, o, i, out=None, oscale=None)
     return out
 
 
-def packed_weight_split_bytes(role, bn, kh, kw, o, i, planes):
+TERMS_F16X3 = 19          # refid_conv_desc.mfma_terms of the split tile's three-fp16-product form (16 + 3)
+
+
+def packed_weight_split_bytes(role, bn, kh, kw, o, i, planes, f16=False):
+    """f16: two fp16 planes behind a 64-byte header (conv2d algo 4 with terms = TERMS_F16X3); `planes` is then ignored."""
+    if f16:
+        return lib().refid_packed_weight_split_f16_bytes(role, o, i, kh, kw, bn)
     return lib().refid_packed_weight_split_bytes(role, o, i, kh, kw, bn, planes)
 
 
-def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscale=None):
-    """Split-bf16 packed weights for conv2d(algo=4): `planes` bf16 numbers per weight (3 = exact, 2 = 2^-17)."""
+def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscale=None, f16=False):
+    """Split-bf16 packed weights for conv2d(algo=4): `planes` bf16 numbers per weight (3 = exact, 2 = 2^-17); f16: two fp16
+    planes of w 2^eW (22 bits), the scale exponent found by a reduction over the tensor and kept in the packing's header."""
     L = lib()
-    nb = L.refid_packed_weight_split_bytes(role, o, i, kh, kw, bn, planes)
+    nb = packed_weight_split_bytes(role, bn, kh, kw, o, i, planes, f16)
     if nb == 0:
         raise _lib.RefidHipError("pack_conv_weights_split: bad geometry")
     if not w.is_contiguous():
@@ -118,6 +125,11 @@ def pack_conv_weights_split(w, role, bn, kh, kw, o, i, planes=3, out=None, oscal
         out = torch.empty(nb // 2, dtype=torch.bfloat16, device=w.device)
     elif out.numel() * out.element_size() != nb:
         raise _lib.RefidHipError("pack_conv_weights_split: out has the wrong size")
+    if f16:
+        check(L.refid_pack_conv_weights_split_f16(w.data_ptr(), oscale.data_ptr() if oscale is not None else None,
+                                                  out.data_ptr(), role, o, i, kh, kw, bn, _stream()),
+              "refid_pack_conv_weights_split_f16")
+        return out
     check(L.refid_pack_conv_weights_split(w.data_ptr(), oscale.data_ptr() if oscale is not None else None,
                                           out.data_ptr(), role, o, i, kh, kw, bn, planes, _stream()),
           "refid_pack_conv_weights_split")
@@ -255,7 +267,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
         if terms == 3:
             name = name[:-1] + ", true>"                                           # three fp16 products
     if algo == 4:
-        name = "conv_split_kernel<%d>" % (terms or 6)
+        name = "conv_split_kernel<%s>" % ("3, fp16" if terms == TERMS_F16X3 else (terms or 6))
     if algo == 3:
         name = "conv_pw_kernel<1, 8>" if cout <= 32 else ("conv_pw_kernel<2, 4, six>" if terms == 6 else "conv_pw_kernel<2, 4>")
     opix = d.n * out.shape[1] * out.shape[2]
@@ -739,8 +751,11 @@ class PackPlan:
     def add_pack(self, w, role, bn, kc, kh, kw, o, i, out, oscale=None, bf16=False):
         self._add(0, w, oscale, out, role, o, i, kh, kw, kc, bn, 1 if bf16 else 0)
 
-    def add_split(self, w, role, bn, kh, kw, o, i, planes, out, oscale=None):
-        self._add(2 if kh == 1 and kw == 1 else 1, w, oscale, out, role, o, i, kh, kw, 8, bn, planes)
+    def add_split(self, w, role, bn, kh, kw, o, i, planes, out, oscale=None, f16=False):
+        if f16:
+            self._add(6, w, oscale, out, role, o, i, kh, kw, 8, bn, 2)
+        else:
+            self._add(2 if kh == 1 and kw == 1 else 1, w, oscale, out, role, o, i, kh, kw, 8, bn, planes)
 
     def add_wino6(self, w, role, o, i, out, oscale=None, f16=False):
         self._add(5 if f16 else 3, w, oscale, out, role, o, i, 3, 3, 16, 64, 2 if f16 else 3)
@@ -767,7 +782,7 @@ class PackPlan:
         return self
 
     def run(self):
-        if any(it[0] == 5 for it in self.items):            # the fp16 Winograd packings' scale exponents (max |w| per tensor) first
+        if any(it[0] in (5, 6) for it in self.items):       # the fp16 packings' scale exponents (max |w| per tensor) first
             check(lib().refid_pack_batch_prepass(self.table.data_ptr(), len(self.items), _stream()), "refid_pack_batch_prepass")
         check(lib().refid_pack_batch(self.table.data_ptr(), len(self.items), self.nblocks, _stream()), "refid_pack_batch")
 

@@ -1338,12 +1338,14 @@ def test_split_tile_rejects_bad_arguments():
         ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=64, cout_pad=64, algo=4)
     x = torch.randn(1, 8, 32, 32, device="cuda")
     with pytest.raises(RefidHipError, match="1, 3 or 6"):
+        ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=64, cout_pad=64, algo=4, terms=19)     # (the fp16 form: stride-2 modes only)
+    with pytest.raises(RefidHipError, match="1, 3 or 6"):
         ops.conv2d(x, wp, out, kh=3, kw=3, stride=1, pad=1, cout=64, cout_pad=64, algo=4, terms=4)
     with pytest.raises(RefidHipError):
         ops.pack_conv_weights_split(torch.randn(64, 32, 5, 5, device="cuda"), ops.ROLE_FWD, 64, 5, 5, 64, 32, planes=3)
 
 
-@pytest.mark.parametrize("terms", [6, 3, 1])
+@pytest.mark.parametrize("terms", [6, 3, 1, 19])
 @pytest.mark.parametrize("cfg", [(2, 16, 64, 64, 64), (1, 24, 40, 128, 128), (1, 8, 8, 256, 256), (1, 18, 66, 32, 48), (3, 64, 64, 64, 64),
                                  (1, 10, 6, 16, 16)])
 def test_split_tile_conv_down_forward(cfg, terms):
@@ -1359,7 +1361,8 @@ def test_split_tile_conv_down_forward(cfg, terms):
     r = rnd(*y.shape, seed=4)
     ref = y + r
     bn = ops.conv_bn(4, 4, 2, 0, Co)
-    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_FWD, bn, 4, 4, Co, Ci, planes={6: 3, 3: 2, 1: 1}[terms])
+    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_FWD, bn, 4, 4, Co, Ci, planes={6: 3, 3: 2, 1: 1, 19: 2}[terms],
+                                     f16=terms == 19)
     out = torch.full((N, H // 2, W // 2, Co), 7.0, device="cuda")
     ops.conv2d(nhwc(x), wp, out, kh=4, kw=4, stride=2, pad=1, cout=Co, cout_pad=-(-Co // bn) * bn, bias=b.float().cuda(),
                res=nhwc(r), slope_pre=0.2, algo=4, terms=terms)
@@ -1367,7 +1370,7 @@ def test_split_tile_conv_down_forward(cfg, terms):
     np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=rtol, atol=atol)
 
 
-@pytest.mark.parametrize("terms", [6, 3, 1])
+@pytest.mark.parametrize("terms", [6, 3, 1, 19])
 @pytest.mark.parametrize("cfg", [(2, 16, 32, 64), (1, 24, 40, 128), (1, 8, 8, 256), (1, 36, 68, 32), (2, 64, 64, 64),
                                  (1, 16, 32, 24), (1, 8, 16, 40)])       # 24 / 40 channels: K % 16 == 8, half-empty last stage
 def test_split_tile_conv_down_dgrad(cfg, terms):
@@ -1384,12 +1387,62 @@ def test_split_tile_conv_down_dgrad(cfg, terms):
     m = rnd(N, C, H, W, seed=5)
     ref = (x.grad + r) * torch.where(m > 0, 1.0, 0.3)
     bn = ops.conv_bn(4, 4, 2, 2, C)
-    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_DOWN_DGRAD, bn, 4, 4, C, C, planes={6: 3, 3: 2, 1: 1}[terms])
+    wp = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_DOWN_DGRAD, bn, 4, 4, C, C, planes={6: 3, 3: 2, 1: 1, 19: 2}[terms],
+                                     f16=terms == 19)
     out = torch.empty(N, H, W, C, device="cuda")
     ops.conv2d(nhwc(g), wp, out, kh=4, kw=4, stride=2, pad=1, mode=2, cout=C, cout_pad=-(-C // bn) * bn, res=nhwc(r), mask=nhwc(m),
                slope_mask=0.3, algo=4, terms=terms)
     rtol, atol = (RTOL, ATOL) if terms != 3 else (2e-4, 2e-4)
     np.testing.assert_allclose(nchw(out).numpy(), ref.numpy(), rtol=rtol, atol=atol)
+
+
+def test_split_tile_f16_accuracy_class_and_dynamic_range():
+    """conv_down on three fp16 products (mfma_terms 19): two fp16 planes carry 22 bits; fp16's range is bridged by exact
+    power-of-two scales -- the weights per packing, the activations per workgroup and online along K.  (a) O(1) data, K = 16 x
+    256: within the six-bf16-product form's distance from float64 (both ~1e-6 of scale), forward and input gradient; (b) the
+    same relative error at magnitudes 1e-8 / 1e+6 and for weights of 1e-6 / 1e+3; (c) channels that GROW by 2^40 along K (a
+    rescale of the accumulators at every stage) and fall again; (d) image regions of different magnitude in different
+    workgroups (the scale is per workgroup: 8 x 32 output pixels) keep the error relative to their own scale."""
+    ops = _ops()
+    N, H, W, C = 1, 64, 128, 256
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(C, C, 4, 4, seed=2, scale=3.0 / np.sqrt(C * 16))
+    bn = ops.conv_bn(4, 4, 2, 0, C)
+    bnd = ops.conv_bn(4, 4, 2, 2, C)
+
+    def fwd(xx, ww, terms):
+        wp = ops.pack_conv_weights_split(ww.float().cuda(), ops.ROLE_FWD, bn, 4, 4, C, C, planes=3 if terms == 6 else 2, f16=terms == 19)
+        out = torch.empty(N, H // 2, W // 2, C, device="cuda")
+        ops.conv2d(nhwc(xx), wp, out, kh=4, kw=4, stride=2, pad=1, cout=C, cout_pad=-(-C // bn) * bn, algo=4, terms=terms)
+        return nchw(out)
+
+    ref = F.conv2d(x, w, None, 2, 1)
+    scale = float(ref.abs().max())
+    e19 = float((fwd(x, w, 19) - ref).abs().max())
+    e6 = float((fwd(x, w, 6) - ref).abs().max())
+    assert e19 < 4e-6 * scale and e19 < 2.0 * e6 + 1e-7 * scale, (e19, e6, scale)                     # (a)
+    g = rnd(N, C, H // 2, W // 2, seed=3)
+    xg = x.clone().requires_grad_(True)
+    F.conv2d(xg, w, None, 2, 1).backward(g)
+    wd = ops.pack_conv_weights_split(w.float().cuda(), ops.ROLE_DOWN_DGRAD, bnd, 4, 4, C, C, planes=2, f16=True)
+    od = torch.empty(N, H, W, C, device="cuda")
+    ops.conv2d(nhwc(g), wd, od, kh=4, kw=4, stride=2, pad=1, mode=2, cout=C, cout_pad=-(-C // bnd) * bnd, algo=4, terms=19)
+    assert float((nchw(od) - xg.grad).abs().max()) < 4e-6 * float(xg.grad.abs().max())
+    for sx, sw in ((1e-8, 1.0), (1e6, 1.0), (1.0, 1e-6), (1.0, 1e3)):                                   # (b)
+        xs, ws = (x * sx).float().double(), (w * sw).float().double()
+        r = F.conv2d(xs, ws, None, 2, 1)
+        assert float((fwd(xs, ws, 19) - r).abs().max()) < 4e-6 * float(r.abs().max()), (sx, sw)
+    ramp = torch.tensor([2.0 ** (10 * min(c, 9 - c)) if c < 10 else 1.0 for c in range(C // 16)], dtype=torch.float64)   # (c)
+    xc = (x * ramp.repeat_interleave(16).view(1, C, 1, 1)).float().double()
+    r = F.conv2d(xc, w.float().double(), None, 2, 1)
+    assert float((fwd(xc, w, 19) - r).abs().max()) < 4e-6 * float(r.abs().max())
+    row = torch.tensor([2.0 ** (((y // 16) - 2) * 10) for y in range(H)], dtype=torch.float64)          # (d): bands of 16 rows
+    xt = (x * row.view(1, 1, H, 1)).float().double()
+    r = F.conv2d(xt, w.float().double(), None, 2, 1)
+    got = fwd(xt, w, 19)
+    for y0 in range(0, H // 2, 8):                             # a workgroup's 8 output rows = 16 input rows = one band (+ a halo row)
+        near = r[:, :, max(0, y0 - 8):y0 + 16].abs().max()
+        assert float((got[:, :, y0:y0 + 8] - r[:, :, y0:y0 + 8]).abs().max()) <= 4e-6 * float(near), y0
 
 
 @pytest.mark.parametrize("case", [

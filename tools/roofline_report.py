@@ -10,7 +10,9 @@ Inputs (all produced on the GPU box by tools/profile_round.sh):
             SQ_LDS_IDX_ACTIVE, GRBM_GUI_ACTIVE ...), any number of files
 Roofs (/opt/skills/guides/MI355X_MICROARCH.md): HBM 8000 GB/s, fp32 MFMA 157.3 TFLOP/s, dense bf16 MFMA 2500 TFLOP/s.
 A kernel is priced against the matrix roof with the FLOPs it ISSUES (Winograd: direct x 16/36; six-product tiles: x 6
-bf16 MFMAs per multiply, direct split tile + 1/9 for its zero tap) and against HBM with its measured PMC bytes."""
+bf16 MFMAs per multiply, three-fp16-product tiles -- rocprof names "<.., true>" -- x 3, direct split tile + 1/9 for its zero tap)
+and against HBM with its measured PMC bytes.  Round 6: every row also carries `frac_algorithmic` = ALGORITHMIC
+bytes per second / 8 TB/s (over-fetch is not achievement) and `waste` = PMC bytes / algorithmic bytes."""
 import argparse
 import collections
 import csv
@@ -29,7 +31,10 @@ def norm(name):
 
 def algo_key(k):
     """rocprof kernel name -> name used by refid_amd.ops.PROFILE (tools/profile_step.py)."""
-    if k.startswith("conv_wino6_kernel"): return k if "<" in k else "conv_wino6_kernel<2>"
+    if k.startswith("conv_wino6_kernel"):
+        m = re.match(r"conv_wino6_kernel<(\d+)(?:, (true|false))?>", k)           # <NT, F16>: ops.PROFILE names "<NT>" / "<NT, true>"
+        if not m: return "conv_wino6_kernel<2>"
+        return f"conv_wino6_kernel<{m.group(1)}, true>" if m.group(2) == "true" else f"conv_wino6_kernel<{m.group(1)}>"
     if k.startswith("conv_wino_kernel"): return k
     if k.startswith("wgrad_wino_kernel"): return "wgrad_wino_kernel"
     if k.startswith("wgrad_wino24_kernel") and "true" in k: return "wgrad_wino24_down_kernel"
@@ -37,7 +42,8 @@ def algo_key(k):
     if k.startswith("conv_pw_kernel"):
         m = re.match(r"conv_pw_kernel<(\d+), (\d+)", k)
         return f"conv_pw_kernel<{m.group(1)}, {m.group(2)}>"
-    if k.startswith("conv_split_kernel"): return "conv_split_kernel<6>"
+    if k.startswith("conv_split_kernel"):                                          # <MT, NT, PL, KS, MODE, F16>
+        return "conv_split_kernel<3, fp16>" if k.rstrip(">").endswith("true") else "conv_split_kernel<6>"
     m = re.match(r"wgrad_kernel<WCfg<(\d+), (\d+), (\d+)", k)
     if m: return f"wgrad_kernel<{m.group(1)}x{m.group(2)}s{m.group(3)}>"
     if k.startswith("wgrad_pw_kernel") or k.startswith("wgrad_pws_kernel"): return "wgrad_kernel<1x1s1>"
@@ -81,11 +87,13 @@ def main():
             fl_per_s = al["flops"] / (al["ms"] * 1e-3)                  # direct-conv FLOP/s over that family
             alg_bytes = al["bytes"] / al["launches"]
             mult, peak, bound = 1.0, FP32, "mfma-fp32"
-            if "wino6" in k: mult, peak, bound = 16.0 / 36.0 * 6.0, BF16, "mfma-bf16"
+            if "wino6" in k and "true" in k: mult, peak, bound = 16.0 / 36.0 * 3.0, BF16, "mfma-fp16"
+            elif "wino6" in k: mult, peak, bound = 16.0 / 36.0 * 6.0, BF16, "mfma-bf16"
             elif "wino24" in k and "true" in k: mult = 12.0 / 16.0
             elif "wino24" in k: mult = 12.0 / 36.0
             elif "wino" in k: mult = 16.0 / 36.0
-            elif "split" in k: mult, peak, bound = 6.0 * 10.0 / 9.0 if "3, 2, 0>" in k else 6.0, BF16, "mfma-bf16"
+            elif "split" in k and k.rstrip(">").endswith("true"): mult, peak, bound = 3.0, BF16, "mfma-fp16"
+            elif "split" in k: mult, peak, bound = 6.0 * 10.0 / 9.0 if "3, 2, 0" in k else 6.0, BF16, "mfma-bf16"
             issued = fl_per_s * mult / 1e12
             rate, unit, frac = issued, "TFLOP/s issued", issued / peak
             if pmc_bytes and pmc_bytes / (avg * 1e-9) / 1e9 / HBM > frac:
@@ -103,6 +111,8 @@ def main():
                          share=round(tot / total_ns, 4), avg_us=round(avg / 1e3, 1), bound=bound,
                          rate=None if rate is None else round(rate, 1), unit=unit, frac=None if frac is None else round(frac, 3),
                          pmc_hbm_bytes_per_launch=pmc_bytes, algorithmic_bytes_per_launch=None if alg_bytes is None else round(alg_bytes),
+                         frac_algorithmic=None if alg_bytes is None else round(alg_bytes / (avg * 1e-9) / 1e9 / HBM, 3),
+                         waste=None if not (alg_bytes and pmc_bytes) else round(pmc_bytes / alg_bytes, 2),
                          mfma_busy_over_busy=None if mfma_util is None else round(mfma_util, 3),
                          lds_conflict_share=None if not (ldsc is not None and ldsa) else round(ldsc / ldsa, 3)))
     rows.sort(key=lambda r: -r["ms_per_step"])
@@ -122,7 +132,8 @@ def main():
                     f.write(f"    {n:32s} {v[0] / v[1]:18.1f}  (n={v[1]})\n")
     print(f"{len(rows)} kernels >= 0.3 ms/step -> {a.out}")
     for r in rows[:14]:
-        print(f"  {r['kernel'][:58]:58s} {r['ms_per_step']:7.2f} ms  {str(r['bound']):10s} frac {r['frac']}  mfma {r['mfma_busy_over_busy']}")
+        print(f"  {r['kernel'][:58]:58s} {r['ms_per_step']:7.2f} ms  {str(r['bound']):10s} frac {r['frac']}  hbm(alg) {r['frac_algorithmic']}  "
+              f"waste {r['waste']}  mfma {r['mfma_busy_over_busy']}")
 
 
 if __name__ == "__main__":

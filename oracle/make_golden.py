@@ -54,19 +54,19 @@ def import_reference():
     return arch, losses
 
 
-def build_ref(arch, img_chn, base):
+def build_ref(arch, img_chn, base, num_block=1):
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):      # the ctor prints
         net = arch.FinalBidirectionAttenfusion(img_chn=img_chn, ev_chn=2, num_encoders=3,
-                                               base_num_channels=base, num_block=1,
+                                               base_num_channels=base, num_block=num_block,
                                                num_residual_blocks=2)
     return net
 
 
 def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wanted, out_dir,
-             store_output="full"):
-    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)
-    net = build_ref(arch, img_chn, base)
+             store_output="full", num_block=1):
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, num_block=num_block)
+    net = build_ref(arch, img_chn, base, num_block)
     sd = net.state_dict()
     assert list(sd.keys()) == list(P.keys()), "state-dict key order/naming mismatch"
     for k in sd:
@@ -176,7 +176,7 @@ def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wa
         out["tap/egaca_out"] = rec["_last_egaca_out"].numpy()
         out["tap/egaca_se"] = rec["_last_egaca_se"].numpy()
         out["tap/bottleneck_tlast"] = rec["_last_bottleneck"].numpy()
-    out["meta"] = np.array([img_chn, base, B, T, H, W, seed], dtype=np.int64)
+    out["meta"] = np.array([img_chn, base, B, T, H, W, seed] + ([num_block] if num_block != 1 else []), dtype=np.int64)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB), "
@@ -344,6 +344,9 @@ def main():
     if os.environ.get("ONLY") == "metrics":
         run_metrics(out_dir)
         return
+    if os.environ.get("ONLY") == "nb2":
+        run_case(arch, losses, "tiny26_nb2_train", 26, 8, 2, 3, 32, 32, 7, True, True, out_dir, num_block=2)
+        return
     if os.environ.get("ONLY") != "refid":
         run_evhinet(losses, "evhinet_tiny_train", 8, 2, 32, 32, 1, True, out_dir)
         run_evhinet(losses, "evhinet_odd_train", 16, 1, 40, 24, 2, True, out_dir)
@@ -357,6 +360,8 @@ def main():
     run_case(arch, losses, "odd26_fwd", 26, 8, 1, 2, 40, 24, 3, False, False, out_dir)
     # full-width network end to end with a train step
     run_case(arch, losses, "full26_train", 26, 32, 1, 5, 64, 64, 4, True, False, out_dir)
+    # two ResidualBlockNoBN per trunk (num_block=2; the YAMLs use 1, the reference ctor's default is 3): round 6
+    run_case(arch, losses, "tiny26_nb2_train", 26, 8, 2, 3, 32, 32, 7, True, True, out_dir, num_block=2)
     # BASELINE config 1: img_chn=3, 128x128, 5-bin voxel -> T=4, forward only
     run_case(arch, losses, "config1_fwd", 3, 32, 1, 4, 128, 128, 5, False, False, out_dir,
              store_output=4)

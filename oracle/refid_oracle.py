@@ -49,7 +49,7 @@ def param_shapes(img_chn: int, ev_chn: int = 2, out_chn: int = 3, num_encoders: 
     ``head``, per-level ``encoders_backward``/``encoders_forward`` modules,
     ``head_img``, ``img_encoders``, then resblocks / decoders / pred).
     """
-    assert num_block == 1, "shipped configs use num_block=1 (one ResidualBlockNoBN per trunk)"
+    assert num_block >= 1, "ConvResidualBlocks: at least one ResidualBlockNoBN per trunk (rsm:719-726, make_layer :760-773)"
     b = base_num_channels
     sh: "OrderedDict[str, tuple]" = OrderedDict()
 
@@ -83,8 +83,9 @@ def param_shapes(img_chn: int, ev_chn: int = 2, out_chn: int = 3, num_encoders: 
                 sh[f"{a}.{n}.weight"] = (c,); sh[f"{a}.{n}.bias"] = (c,)
         t = prefix + ".recurrent_block.forward_trunk.main"
         conv(t + ".0", co, 2 * co, 3)
-        conv(t + ".2.0.conv1", co, co, 3)
-        conv(t + ".2.0.conv2", co, co, 3)
+        for k in range(num_block):                                          # make_layer(ResidualBlockNoBN, num_block)
+            conv(t + f".2.{k}.conv1", co, co, 3)
+            conv(t + f".2.{k}.conv2", co, co, 3)
         if fuse:
             conv(prefix + ".fuse_two_dir.conv2d", co, 2 * co, 1)
         sh[prefix + ".down.weight"] = (co, co, 4, 4)
@@ -111,8 +112,8 @@ def param_shapes(img_chn: int, ev_chn: int = 2, out_chn: int = 3, num_encoders: 
         sh[p + ".transposed_conv2d.bias"] = (ci // 2,)
         t = p + ".forward_trunk.main"
         conv(t + ".0", ci // 2, ci, 3)
-        conv(t + ".2.0.conv1", ci // 2, ci // 2, 3)
-        conv(t + ".2.0.conv2", ci // 2, ci // 2, 3)
+        conv(t + ".2.0.conv1", ci // 2, ci // 2, 3)          # (the decoders' trunks always hold ONE block: rsm:375-384 does not
+        conv(t + ".2.0.conv2", ci // 2, ci // 2, 3)          #  pass num_block on)
     conv("pred.conv2d", out_chn, b, 3)                                     # arch:75-77
     return sh
 
@@ -166,7 +167,7 @@ def make_params(img_chn: int, base_num_channels: int = 32, mode: str = "hash", s
                 t = torch.ones(s) if k.endswith(".weight") else torch.zeros(s)
             elif k.endswith((".beta", ".gamma")):
                 t = torch.zeros(s)
-            elif ".main.2.0.conv" in k:                                    # rsm:752-753,776-800
+            elif ".main.2." in k and ".conv" in k:                         # rsm:752-753,776-800 (every ResidualBlockNoBN)
                 if k.endswith(".weight"):
                     std = math.sqrt(2.0 / (s[1] * s[2] * s[3]))
                     t = torch.randn(s, generator=g) * std * 0.1
@@ -286,8 +287,11 @@ def trunk(P, name, u, h):
     if h is None:
         h = torch.zeros_like(u)
     v = F.leaky_relu(_conv(P, name + ".0", torch.cat([u, h], dim=1), 1, 1), 0.1)
-    r = _conv(P, name + ".2.0.conv2", F.relu(_conv(P, name + ".2.0.conv1", v, 1, 1)), 1, 1)
-    return v + r
+    k = 0
+    while f"{name}.2.{k}.conv1.weight" in P:                               # num_block ResidualBlockNoBN (rsm:760-773)
+        v = v + _conv(P, f"{name}.2.{k}.conv2", F.relu(_conv(P, f"{name}.2.{k}.conv1", v, 1, 1)), 1, 1)
+        k += 1
+    return v
 
 
 def evr_level(P, name, level: int, x, y, prev_state, bi_state, taps=None):

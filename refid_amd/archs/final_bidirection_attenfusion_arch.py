@@ -42,8 +42,8 @@ class FinalBidirectionAttenfusion(nn.Module):
         unsupported = []
         if num_encoders != 3:
             unsupported.append(f"num_encoders={num_encoders} (shipped configs: 3)")
-        if num_block != 1:
-            unsupported.append(f"num_block={num_block} (shipped configs: 1)")
+        if num_block < 1:
+            unsupported.append(f"num_block={num_block} (at least one ResidualBlockNoBN per trunk)")
         if skip_type != 'sum':
             unsupported.append(f"skip_type={skip_type!r}")
         if norm is not None:
@@ -54,12 +54,14 @@ class FinalBidirectionAttenfusion(nn.Module):
             unsupported.append("num_residual_blocks<1")
         if unsupported:
             raise NotImplementedError("FinalBidirectionAttenfusion (HIP): unsupported options: " + ", ".join(unsupported)
-                                      + " -- every options/*.yml of the reference uses num_encoders=3, num_block=1")
+                                      + " -- every options/*.yml of the reference uses num_encoders=3 (num_block: any >= 1; the "
+                                      "YAMLs use 1, the reference ctor's default is 3)")
         # recurrent_block_type / activation / use_first_dcn / use_reversed_voxel are accepted and
         # ignored, exactly like the reference (arch:59,92; rsm:251-257)
         self.img_chn, self.ev_chn, self.out_chn = img_chn, ev_chn, out_chn
         self.base_num_channels, self.num_residual_blocks = base_num_channels, num_residual_blocks
-        self._shapes = param_shapes(img_chn, ev_chn, out_chn, base_num_channels, num_residual_blocks)
+        self.num_block = num_block
+        self._shapes = param_shapes(img_chn, ev_chn, out_chn, base_num_channels, num_residual_blocks, num_block)
         self._engine = None
         self._grad_sync = None                 # optional callable(phase) run inside BPTT (refid_amd.dist.GradSync)
         self._params = {}
@@ -86,7 +88,7 @@ class FinalBidirectionAttenfusion(nn.Module):
                 p.fill_(1.0 if k.endswith("weight") else 0.0)
             elif k.endswith((".beta", ".gamma")):
                 p.zero_()
-            elif ".main.2.0.conv" in k:
+            elif ".main.2." in k and ".conv" in k:          # every ResidualBlockNoBN of a trunk (rsm:752-753)
                 if k.endswith("weight"):
                     nn.init.kaiming_normal_(p)
                     p.mul_(0.1)
@@ -118,7 +120,7 @@ class FinalBidirectionAttenfusion(nn.Module):
                 all(p.data_ptr() == self._engine.arena.p(k).data_ptr() for k, p in self._params.items()):
             return
         eng = Engine(self.img_chn, self.ev_chn, self.out_chn, self.base_num_channels, self.num_residual_blocks,
-                     device=dev, compute_dtype=self.compute_dtype)
+                     device=dev, compute_dtype=self.compute_dtype, num_block=self.num_block)
         with torch.no_grad():
             for k, p in self._params.items():
                 if p.dtype != torch.float32:

@@ -33,7 +33,7 @@ from . import ops
 from ._lib import RefidHipError
 
 
-def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2):
+def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, num_block=1):
     """State-dict inventory (names, shapes, registration order) of the reference network:
     XXNet_final_attenfusion_arch.py:90-128 + the sub-module ctors it calls."""
     b = base
@@ -68,8 +68,9 @@ def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2):
                 sh[f"{a}.{n}.weight"] = (ci,); sh[f"{a}.{n}.bias"] = (ci,)
         t = prefix + ".recurrent_block.forward_trunk.main"
         conv(t + ".0", co, 2 * co, 3)
-        conv(t + ".2.0.conv1", co, co, 3)
-        conv(t + ".2.0.conv2", co, co, 3)
+        for k in range(num_block):                      # make_layer(ResidualBlockNoBN, num_block): rsm:719-726,760-773
+            conv(t + f".2.{k}.conv1", co, co, 3)
+            conv(t + f".2.{k}.conv2", co, co, 3)
         if fuse:
             conv(prefix + ".fuse_two_dir.conv2d", co, 2 * co, 1)
         sh[prefix + ".down.weight"] = (co, co, 4, 4)
@@ -95,8 +96,8 @@ def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2):
         sh[p + ".transposed_conv2d.bias"] = (ci // 2,)
         t = p + ".forward_trunk.main"
         conv(t + ".0", ci // 2, ci, 3)
-        conv(t + ".2.0.conv1", ci // 2, ci // 2, 3)
-        conv(t + ".2.0.conv2", ci // 2, ci // 2, 3)
+        conv(t + ".2.0.conv1", ci // 2, ci // 2, 3)      # (the decoders' trunks always hold ONE block: rsm:375-384 does not pass
+        conv(t + ".2.0.conv2", ci // 2, ci // 2, 3)      #  num_block on)
     conv("pred.conv2d", out_chn, b, 3)
     return sh
 
@@ -886,14 +887,21 @@ def finish_wgrads(op_list):
 
 
 class _Trunk:
+    """ConvResidualBlocks (rsm:719-726): conv3x3 + LeakyReLU(.1), then num_block ResidualBlockNoBN (rsm:755-758; every shipped
+    YAML: one)."""
+
     def __init__(self, arena, prefix, bf16=False):
         self.c0 = ConvOp(arena, prefix + ".0", bf16=bf16)
-        self.c1 = ConvOp(arena, prefix + ".2.0.conv1", bf16=bf16)
-        self.c2 = ConvOp(arena, prefix + ".2.0.conv2", bf16=bf16)
+        self.blocks = []
+        k = 0
+        while f"{prefix}.2.{k}.conv1.weight" in arena.shapes:
+            self.blocks.append((ConvOp(arena, f"{prefix}.2.{k}.conv1", bf16=bf16), ConvOp(arena, f"{prefix}.2.{k}.conv2", bf16=bf16)))
+            k += 1
+        self.c1, self.c2 = self.blocks[0]
         self.C = self.c0.co
 
     def ops(self):
-        return [self.c0, self.c1, self.c2]
+        return [self.c0] + [c for blk in self.blocks for c in blk]
 
 
 class _Egaca:
@@ -959,7 +967,7 @@ class Engine:
     """Forward + BPTT backward of FinalBidirectionAttenfusion on one GPU."""
 
     def __init__(self, img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, device="cuda",
-                 compute_dtype="fp32"):
+                 compute_dtype="fp32", num_block=1):
         if base not in (8, 16, 32, 64):
             # EGACA's LayerNorm / depthwise / squeeze-excite kernels take 2*base in {16, 32, 64, 128} channels; every
             # options/*.yml of the reference uses 32
@@ -977,7 +985,7 @@ class Engine:
         self.img_chn, self.ev_chn, self.out_chn, self.base = img_chn, ev_chn, out_chn, base
         self.nres = num_residual_blocks
         self.device = torch.device(device)
-        self.shapes = param_shapes(img_chn, ev_chn, out_chn, base, num_residual_blocks)
+        self.shapes = param_shapes(img_chn, ev_chn, out_chn, base, num_residual_blocks, num_block)
         self.arena = A = ParamArena(self.shapes, self.device)
         self.head_ev = ConvOp(A, "head.conv2d", need_dgrad=False, bf16=bf)
         self.head_img = ConvOp(A, "head_img.conv2d", need_dgrad=False, bf16=bf)
@@ -1204,23 +1212,30 @@ class Engine:
     def _trunk_fwd(T, u, h, st, plus=None):
         """plus: also returns s + plus (the next decoder's input sum, written by the last conv's tile)."""
         v = T.c0.fwd(u, h, slope_pre=0.1)
-        r = T.c1.fwd(v, slope_pre=0.0)
-        s = T.c2.fwd(r, res=v, plus=plus)
-        sp = None
-        if plus is not None:
-            s, sp = s
+        xs, rs, x = [], [], v                            # block k: x_{k+1} = x_k + conv2(relu(conv1(x_k))), x_0 = v
+        for k, (c1, c2) in enumerate(T.blocks):
+            r = c1.fwd(x, slope_pre=0.0)
+            xs.append(x); rs.append(r)
+            x = c2.fwd(r, res=x, plus=plus if k == len(T.blocks) - 1 else None)
+        s, sp = x if plus is not None else (x, None)
         if st is not None:
-            st.update(u=u, h=h, v=v, r=r, s=s)
+            st.update(u=u, h=h, v=v, r=rs[0], xs=xs, rs=rs, s=s)
         return s if plus is None else (s, sp)
 
     @staticmethod
     def _trunk_bwd(T, g_s, st, mask_u=None, slope_u=1.0):
-        u, h, v, r = st["u"], st["h"], st["v"], st["r"]
+        u, h, v = st["u"], st["h"], st["v"]
         C = T.C
-        T.c2.wgrad(g_s, r)
-        g_r = T.c2.dgrad(g_s, mask=r, slope_mask=0.0)
-        T.c1.wgrad(g_r, v)
-        g_v = T.c1.dgrad(g_r, res=g_s, mask=v, slope_mask=0.1)
+        g = g_s
+        for k in range(len(T.blocks) - 1, -1, -1):       # x_{k+1} = x_k + conv2(relu(conv1(x_k)))
+            c1, c2 = T.blocks[k]
+            x, r = st["xs"][k], st["rs"][k]
+            c2.wgrad(g, r)
+            g_r = c2.dgrad(g, mask=r, slope_mask=0.0)
+            c1.wgrad(g_r, x)
+            # x_0 = v is LeakyReLU(.1) of main.0's output: its derivative mask rides on the last tile; x_k (k > 0) is linear
+            g = c1.dgrad(g_r, res=g, mask=v, slope_mask=0.1) if k == 0 else c1.dgrad(g_r, res=g)
+        g_v = g
         T.c0.wgrad(g_v, u, h)
         g_u = T.c0.dgrad(g_v, rows=(0, C), mask=mask_u, slope_mask=slope_u)
         g_h = T.c0.dgrad(g_v, rows=(C, C)) if h is not None else None

@@ -78,10 +78,17 @@ def test_state_dict_keys_shapes_and_counts(img_chn, count):
 def test_unsupported_options_fail_loudly():
     from refid_amd.archs import define_network
     base = dict(type="FinalBidirectionAttenfusion", img_chn=6, ev_chn=2, num_encoders=3, num_block=1)
-    for bad in (dict(num_encoders=4), dict(num_block=3), dict(skip_type="concat"), dict(norm="BN"),
+    for bad in (dict(num_encoders=4), dict(num_block=0), dict(skip_type="concat"), dict(norm="BN"),
                 dict(use_recurrent_upsample_conv=False)):
         with pytest.raises(NotImplementedError):
             define_network({**base, **bad})
+    # num_block (ResidualBlockNoBN per encoder trunk; the YAMLs use 1, the reference ctor's default is 3): any >= 1 builds, with
+    # the reference's state-dict keys -- the decoders' trunks keep their single block (rsm:375-384 does not pass num_block on)
+    net3 = define_network({**base, "num_block": 3, "base_num_channels": 8})
+    keys = list(net3.state_dict().keys())
+    assert len(keys) == 183 + 2 * 6 * 4 and "encoders_forward.2.recurrent_block.forward_trunk.main.2.2.conv2.bias" in keys
+    assert "decoders.0.forward_trunk.main.2.1.conv1.weight" not in keys
+    assert keys == list(O.param_shapes(6, base_num_channels=8, num_block=3).keys())
     with pytest.raises(AssertionError):
         define_network({**base, "img_chn": 0})
     # ignored-by-the-reference keywords are accepted

@@ -13,8 +13,9 @@ RTOL, ATOL = 1e-4, 1e-5     # oracle vs reference: same torch ops, only graph st
 
 def _load(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
-    img_chn, base, B, T, H, W, seed = [int(v) for v in z["meta"]]
-    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed)
+    img_chn, base, B, T, H, W, seed = [int(v) for v in z["meta"][:7]]
+    nb = int(z["meta"][7]) if len(z["meta"]) > 7 else 1                   # num_block (fixtures of round 6 on)
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, num_block=nb)
     x, ev, gt = O.make_inputs(B, T, H, W, img_chn, seed=seed, mode="hash")
     return z, P, x, ev, gt, base
 
@@ -27,7 +28,7 @@ def test_param_inventory_matches_reference_counts():
         assert sum(int(np.prod(s)) for s in sh.values()) == n
 
 
-@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train"])
+@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train", "tiny26_nb2_train"])
 def test_forward_taps_and_train_step(golden_dir, name):
     z, P, x, ev, gt, base = _load(golden_dir, name)
     taps = {}

@@ -44,7 +44,8 @@ size_t refid_wino6_workspace_bytes(const ConvKArgs& a, int split_mode);
 int refid_launch_wino6(const ConvKArgs& a, float* ws, size_t ws_bytes, int split_mode, int tile_hint, int terms, hipStream_t st);
 // conv_split.hip: direct 3x3 tile with split-bf16 operands (algo 4); terms = 6 (fp32-class products) or 3
 bool refid_split3x3_eligible(const ConvKArgs& a);
-int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipStream_t st);
+// split_mode (refid_conv_desc.split_k): 1 = tile choice from the per-sample geometry (batch-independent bits)
+int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, int split_mode, hipStream_t st);
 // conv_pw.hip
 // Fusions around a pointwise conv (refid_pw_extras in refid_hip.h): EGACA's LayerNorm2d prologue, the squeeze-excite
 // vector computed in the kernel and applied to the operand, second residual, GELU second output.

@@ -565,7 +565,7 @@ extern "C" int refid_conv2d(const refid_conv_desc* d, void* stream) {
         if (cus == 0) cus = refid_device_cu_count();
         REFID_CHECK(d->pad == 1, "conv2d: the split tile's geometries all have pad 1");
         return refid_launch_split3x3(a, d->mfma_terms ? d->mfma_terms : 6, f == F_3x3 ? 0 : (f == F_4x4s2 ? 1 : 2),
-                                     cus > 0 ? cus : 256, st);
+                                     cus > 0 ? cus : 256, d->split_k, st);
     }
     if (d->algo == 5) return refid_launch_wino6(a, d->ws, d->ws_bytes, d->split_k, d->wino_tile, d->mfma_terms, st);
     if (d->algo == 1) {

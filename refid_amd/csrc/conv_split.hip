@@ -558,7 +558,7 @@ bool refid_split3x3_eligible(const ConvKArgs& a) {
 // terms: 6 (three planes per operand: fp32-class products), 3 (two planes: 2^-16 relative), 1 (plain bf16 operands) or 19 (two
 // fp16 planes, three products on scaled operands: the fp32 class at half of 6's MFMAs; the stride-2 modes only)
 // mode: 0 = 3x3 stride 1; 1 = 4x4 stride 2 pad 1 forward; 2 = its input gradient (a.Ho / a.Wo = the gradient's grid)
-int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipStream_t st) {
+int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, int split_mode, hipStream_t st) {
     REFID_CHECK(terms == 1 || terms == 3 || terms == 6 || (terms == 19 && mode != 0),
                 "conv2d: split tile takes 1, 3 or 6 product terms, or 19 (three fp16 products; 4x4 stride 2 and its input "
                 "gradient only) (got %d)", terms);
@@ -573,7 +573,10 @@ int refid_launch_split3x3(const ConvKArgs& a, int terms, int mode, int cus, hipS
     }
     const bool wide = a.Cout > 32;
     // 8-row tiles when they still give every CU its two workgroups, 4-row tiles otherwise
-    const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * a.N * cdiv(a.Cout, wide ? 64 : 32) * (mode == 2 ? 4 : 1);
+    // (split policy 1, "sample": decided as if the batch held 8 samples, so that a sample's bits do not depend on the batch it
+    //  is in -- with the fp16 form the workgroup's tile decides its scale, and the scale the rounding of values whose low plane
+    //  is subnormal; the exact-split bf16 forms give the same bits on either tile)
+    const int wg8 = cdiv(a.Wo, TW) * cdiv(a.Ho, 8) * (split_mode == 1 ? 8 : a.N) * cdiv(a.Cout, wide ? 64 : 32) * (mode == 2 ? 4 : 1);
     const bool tall = wg8 >= 2 * cus;
 #define SPLIT_DISPATCH(PLN)                                                          \
     (mode == 0 ? launch_split_pl<PLN, 0>(a, wide, tall, st)                          \

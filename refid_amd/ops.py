@@ -243,7 +243,7 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     d.mask_mode = mask_mode
     d.algo = algo
     d.wino_tile = WINO_TILE
-    if WINO_SPLIT and algo in (0, 1, 2, 5):
+    if WINO_SPLIT and algo in (0, 1, 2, 4, 5):          # (algo 4: no workspace; the policy decides its tile shape)
         d.split_k = WINO_SPLIT
         need = lib().refid_conv_workspace_bytes(C.byref(d))
         if need:

@@ -126,6 +126,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kh = lane >> 5;
     const int ti = wave;                                   // transform row i owned by this wave (xi = 4i .. 4i+3)
+    if (REFID_WINO6_ABLATE == 20 && a.N > 0) return;       // (every workgroup leaves at once, registers / LDS as the product: dispatch only)
+    if (REFID_WINO6_ABLATE == 21 && a.N > 0) { __syncthreads(); if (tid == 12345) a.out[0] = 1.f; return; }   // + one barrier
 
 #if defined(REFID_WINO6_ABLATE) && (REFID_WINO6_ABLATE == 9 || REFID_WINO6_ABLATE == 11)
     {
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     // 4 / 8 us late (anti-phased pair per CU), 10 = 3 + 4, 12 = every lane of a U load reads the same 16 bytes (same
     // instruction count, no bandwidth), 13 = half the U loads (column tile 1 reuses tile 0's fragments), 14 = three products on
     // two planes (the MFMA / U-byte count of a two-plane fp16 form), 15 = 14 without the split; fp16 form (WINO6_TERMS=3):
-    // 16 = no max / rescale / scale, 17 = a one-instruction max, 18 = no split.  Never in the product.
+    // 16 = no max / rescale / scale, 17 = a one-instruction max, 18 = no split, 19 = the prologue's halo loads from a cache-resident
+    // tile, 20 = every workgroup returns at once (dispatch cost of the grid), 21 = 20 + one barrier.  Never in the product.
     auto load_raw = [&](int ch, f32x4 (&dst)[R_ITEMS]) {
         const int c0 = (REFID_WINO6_ABLATE == 5 ? 0 : ch) * KC;   // chunk-uniform source: Ca % 16 == 0 for two sources
         const bool fromA = c0 < a.Ca;
@@ -331,8 +334,22 @@ __global__ __launch_bounds__(256, NT == 2 ? 2 : 3) void conv_wino6_kernel(const 
     // prologue: raw(kc0) -> LDS; raw(kc0+1) and U(kc0, column 0) in flight
     {
         f32x4 rr0[R_ITEMS];
+#if REFID_WINO6_ABLATE == 19
+        int keep[R_ITEMS];                                 // the prologue's two halo chunks from ONE cache-resident tile (tile 0 of
+#pragma unroll                                             // sample 0): prices the HBM latency a workgroup's start waits for
+        for (int it = 0; it < R_ITEMS; ++it) {
+            keep[it] = pixo[it];
+            const int hp = (tid >> 2) + it * 64;
+            const int row = hp / HWD, col = hp % HWD;
+            pixo[it] = (hp < HP && row >= a.pad && col >= a.pad) ? (row - a.pad) * a.W + (col - a.pad) : OOB;
+        }
+#endif
         load_raw(kc0, rr0);
         load_raw(kc0 + 1, rr);
+#if REFID_WINO6_ABLATE == 19
+#pragma unroll
+        for (int it = 0; it < R_ITEMS; ++it) pixo[it] = keep[it];
+#endif
         load_u(kc0, 0, uA);
         if (REFID_WINO6_ABLATE == 6 || REFID_WINO6_ABLATE == 8) load_u(kc0, 1, uB);
         store_raw(0, rr0);

@@ -273,6 +273,12 @@ def conv2d(in_a, w_packed, out, *, kh, kw, stride=1, pad=0, mode=0, cout, cout_p
     opix = d.n * out.shape[1] * out.shape[2]
     nbytes = 4.0 * (d.n * d.h * d.w * (d.c_a + d.c_b) + opix * out.shape[3] * (1 + (res is not None) + (mask is not None))
                     + cout * (d.c_a + d.c_b) * taps)
+    if out2 is not None:                                   # the second output and its addend are algorithmic bytes too
+        nbytes += 8.0 * opix * out.shape[3]
+    if pw is not None:                                     # the pointwise tile's fused side outputs / second residual (EGACA)
+        for k in ("ln_out", "xs_out", "out2", "res2"):
+            if pw.get(k) is not None:
+                nbytes += 4.0 * pw[k].numel()
     PROFILE.append((name, flops, e0, e1,
                     (d.n, d.h, d.w, d.c_a, d.c_b, cout, int(res is not None), int(mask is not None), int(bias is not None)),
                     nbytes))

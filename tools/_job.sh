@@ -1,1 +1,3 @@
-timeout 2400 python -m pytest tests/test_hip_io.py tests/test_hip_at_size.py tests/test_hip_streams.py tests/test_hip_train_step.py tests/test_hip_ddp.py tests/test_hip_evhinet.py tests/test_hip_egaca.py -q -x 2>&1 | tail -6
+mkdir -p gpurun_out/r06
+WINO6_TERMS=3 WINO6_ONLY=20,21 WINO6_TAG=h python tools/probes/wino6_ablate.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06/wino6_abl_f16_dispatch.txt
+cat gpurun_out/r06/wino6_abl_f16_dispatch.txt

@@ -20,7 +20,8 @@ VARIANTS = {0: "product", 1: "U fragments cache resident", 2: "no three-plane sp
             10: "no K loop, no epilogue traffic (3 + 4)", 11: "odd-slot workgroup starts 8 us late",
             12: "U loads: same 16 bytes for every lane", 13: "half the U loads",
             14: "three products, two U planes", 15: "three products, two U planes, no split",
-            16: "fp16 form: no max / rescale / scale", 17: "fp16 form: one-instruction max", 18: "fp16 form: no split"}
+            16: "fp16 form: no max / rescale / scale", 17: "fp16 form: one-instruction max", 18: "fp16 form: no split",
+            19: "prologue halo loads cache resident", 20: "workgroups return at once (dispatch only)", 21: "20 + one barrier", 3: "no K loop", 10: "no K loop, no epilogue traffic (3 + 4)"}
 TERMS = int(os.environ.get("WINO6_TERMS", "0"))          # 3: time the three-fp16-product form (variants 0, 16-18)
 if os.environ.get("WINO6_ONLY"):
     VARIANTS = {int(v): VARIANTS[int(v)] for v in os.environ["WINO6_ONLY"].split(",")}

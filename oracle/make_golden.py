@@ -54,19 +54,20 @@ def import_reference():
     return arch, losses
 
 
-def build_ref(arch, img_chn, base, num_block=1):
+def build_ref(arch, img_chn, base, num_block=1, num_encoders=3):
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):      # the ctor prints
-        net = arch.FinalBidirectionAttenfusion(img_chn=img_chn, ev_chn=2, num_encoders=3,
+        net = arch.FinalBidirectionAttenfusion(img_chn=img_chn, ev_chn=2, num_encoders=num_encoders,
                                                base_num_channels=base, num_block=num_block,
                                                num_residual_blocks=2)
     return net
 
 
 def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wanted, out_dir,
-             store_output="full", num_block=1):
-    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, num_block=num_block)
-    net = build_ref(arch, img_chn, base, num_block)
+             store_output="full", num_block=1, num_encoders=3):
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, num_block=num_block, num_encoders=num_encoders)
+    net = build_ref(arch, img_chn, base, num_block, num_encoders)
+    assert not taps_wanted or num_encoders == 3, "the tap hooks below are written for three levels"
     sd = net.state_dict()
     assert list(sd.keys()) == list(P.keys()), "state-dict key order/naming mismatch"
     for k in sd:
@@ -136,6 +137,8 @@ def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wa
                 "encoders_forward.1.conv.conv2d.weight", "encoders_backward.2.down.weight",
                 "encoders_forward.1.atten_fuse.se_2.1.bias"]
         for k in pick:
+            if k not in named:                               # (a level that this num_encoders does not have)
+                continue
             g = named[k].grad.detach() / coef                # undo the in-place clip
             if g.numel() > 50000:                            # keep fixtures small
                 out["gradsub7/" + k] = g.flatten()[::7].numpy().astype(np.float32)
@@ -176,7 +179,8 @@ def run_case(arch, losses, name, img_chn, base, B, T, H, W, seed, train, taps_wa
         out["tap/egaca_out"] = rec["_last_egaca_out"].numpy()
         out["tap/egaca_se"] = rec["_last_egaca_se"].numpy()
         out["tap/bottleneck_tlast"] = rec["_last_bottleneck"].numpy()
-    out["meta"] = np.array([img_chn, base, B, T, H, W, seed] + ([num_block] if num_block != 1 else []), dtype=np.int64)
+    out["meta"] = np.array([img_chn, base, B, T, H, W, seed] + ([num_block] if (num_block, num_encoders) != (1, 3) else []) +
+                           ([num_encoders] if num_encoders != 3 else []), dtype=np.int64)
     path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
     print(f"{name}: wrote {path} ({os.path.getsize(path)/1024:.0f} KiB), "
@@ -347,6 +351,10 @@ def main():
     if os.environ.get("ONLY") == "nb2":
         run_case(arch, losses, "tiny26_nb2_train", 26, 8, 2, 3, 32, 32, 7, True, True, out_dir, num_block=2)
         return
+    if os.environ.get("ONLY") == "ne":
+        run_case(arch, losses, "tiny26_default_ctor_train", 26, 8, 2, 3, 32, 32, 8, True, False, out_dir, num_block=3, num_encoders=4)
+        run_case(arch, losses, "tiny6_ne2_train", 6, 8, 1, 3, 24, 40, 9, True, False, out_dir, num_encoders=2)
+        return
     if os.environ.get("ONLY") != "refid":
         run_evhinet(losses, "evhinet_tiny_train", 8, 2, 32, 32, 1, True, out_dir)
         run_evhinet(losses, "evhinet_odd_train", 16, 1, 40, 24, 2, True, out_dir)
@@ -362,6 +370,9 @@ def main():
     run_case(arch, losses, "full26_train", 26, 32, 1, 5, 64, 64, 4, True, False, out_dir)
     # two ResidualBlockNoBN per trunk (num_block=2; the YAMLs use 1, the reference ctor's default is 3): round 6
     run_case(arch, losses, "tiny26_nb2_train", 26, 8, 2, 3, 32, 32, 7, True, True, out_dir, num_block=2)
+    # the reference ctor's own defaults (num_encoders=4, num_block=3: arch:90-92) and the smallest net (two levels): round 6
+    run_case(arch, losses, "tiny26_default_ctor_train", 26, 8, 2, 3, 32, 32, 8, True, False, out_dir, num_block=3, num_encoders=4)
+    run_case(arch, losses, "tiny6_ne2_train", 6, 8, 1, 3, 24, 40, 9, True, False, out_dir, num_encoders=2)
     # BASELINE config 1: img_chn=3, 128x128, 5-bin voxel -> T=4, forward only
     run_case(arch, losses, "config1_fwd", 3, 32, 1, 4, 128, 128, 5, False, False, out_dir,
              store_output=4)

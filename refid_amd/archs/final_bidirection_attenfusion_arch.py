@@ -40,8 +40,9 @@ class FinalBidirectionAttenfusion(nn.Module):
         self.compute_dtype = compute_dtype
         assert ev_chn > 0 and img_chn > 0 and out_chn > 0                      # arch:45-47
         unsupported = []
-        if num_encoders != 3:
-            unsupported.append(f"num_encoders={num_encoders} (shipped configs: 3)")
+        if num_encoders not in (2, 3, 4):
+            unsupported.append(f"num_encoders={num_encoders} (2, 3 or 4: level 1 is the attention-fusion level; the YAMLs use 3, "
+                               "the reference ctor's default is 4)")
         if num_block < 1:
             unsupported.append(f"num_block={num_block} (at least one ResidualBlockNoBN per trunk)")
         if skip_type != 'sum':
@@ -54,14 +55,14 @@ class FinalBidirectionAttenfusion(nn.Module):
             unsupported.append("num_residual_blocks<1")
         if unsupported:
             raise NotImplementedError("FinalBidirectionAttenfusion (HIP): unsupported options: " + ", ".join(unsupported)
-                                      + " -- every options/*.yml of the reference uses num_encoders=3 (num_block: any >= 1; the "
-                                      "YAMLs use 1, the reference ctor's default is 3)")
+                                      + " -- every options/*.yml of the reference uses num_encoders=3, num_block=1, skip_type='sum', "
+                                      "no norm (the reference ctor's own defaults, num_encoders=4 / num_block=3, build here too)")
         # recurrent_block_type / activation / use_first_dcn / use_reversed_voxel are accepted and
         # ignored, exactly like the reference (arch:59,92; rsm:251-257)
         self.img_chn, self.ev_chn, self.out_chn = img_chn, ev_chn, out_chn
         self.base_num_channels, self.num_residual_blocks = base_num_channels, num_residual_blocks
-        self.num_block = num_block
-        self._shapes = param_shapes(img_chn, ev_chn, out_chn, base_num_channels, num_residual_blocks, num_block)
+        self.num_block, self.num_encoders = num_block, num_encoders
+        self._shapes = param_shapes(img_chn, ev_chn, out_chn, base_num_channels, num_residual_blocks, num_block, num_encoders)
         self._engine = None
         self._grad_sync = None                 # optional callable(phase) run inside BPTT (refid_amd.dist.GradSync)
         self._params = {}
@@ -120,7 +121,7 @@ class FinalBidirectionAttenfusion(nn.Module):
                 all(p.data_ptr() == self._engine.arena.p(k).data_ptr() for k, p in self._params.items()):
             return
         eng = Engine(self.img_chn, self.ev_chn, self.out_chn, self.base_num_channels, self.num_residual_blocks,
-                     device=dev, compute_dtype=self.compute_dtype, num_block=self.num_block)
+                     device=dev, compute_dtype=self.compute_dtype, num_block=self.num_block, num_encoders=self.num_encoders)
         with torch.no_grad():
             for k, p in self._params.items():
                 if p.dtype != torch.float32:

@@ -33,7 +33,7 @@ from . import ops
 from ._lib import RefidHipError
 
 
-def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, num_block=1):
+def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, num_block=1, num_encoders=3):
     """State-dict inventory (names, shapes, registration order) of the reference network:
     XXNet_final_attenfusion_arch.py:90-128 + the sub-module ctors it calls."""
     b = base
@@ -45,8 +45,8 @@ def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, n
             sh[name + ".bias"] = (co,)
 
     conv("head.conv2d", b, ev_chn, 5)
-    enc_in = [b, 2 * b, 4 * b]
-    enc_out = [2 * b, 4 * b, 8 * b]
+    enc_in = [b * 2 ** i for i in range(num_encoders)]          # arch:49-56
+    enc_out = [b * 2 ** (i + 1) for i in range(num_encoders)]
 
     def evr(prefix, ci, co, fuse, atten):
         conv(prefix + ".conv.conv2d", co, ci, 3)
@@ -75,18 +75,18 @@ def param_shapes(img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, n
             conv(prefix + ".fuse_two_dir.conv2d", co, 2 * co, 1)
         sh[prefix + ".down.weight"] = (co, co, 4, 4)
 
-    for i in range(3):
+    for i in range(num_encoders):
         evr(f"encoders_backward.{i}", enc_in[i], enc_out[i], False, i == 1)
-    for i in range(3):
+    for i in range(num_encoders):
         evr(f"encoders_forward.{i}", enc_in[i], enc_out[i], True, i == 1)
     conv("head_img.conv2d", b, img_chn, 5)
-    for i in range(3):
+    for i in range(num_encoders):
         p = f"img_encoders.{i}"
         conv(p + ".identity", enc_out[i], enc_in[i], 1)
         conv(p + ".conv_1", enc_out[i], enc_in[i], 3)
         conv(p + ".conv_2", enc_out[i], enc_out[i], 3)
         sh[p + ".down.weight"] = (enc_out[i], enc_out[i], 4, 4)
-    cmax = 8 * b
+    cmax = b * 2 ** num_encoders
     for i in range(num_residual_blocks):
         conv(f"resblocks.{i}.conv1", cmax, cmax, 3)
         conv(f"resblocks.{i}.conv2", cmax, cmax, 3)
@@ -224,7 +224,7 @@ class _SideStreams:
 
 WGRAD_STREAM = _SideStreams()
 DEC_STREAM = _SideStreams()                  # the decoder chain of the forward-sweep pipeline (PIPELINE)
-LV_STREAMS = (_SideStreams(), _SideStreams())   # EvR levels 1 and 2 (level 0 runs on the caller's stream)
+LV_STREAMS = (_SideStreams(), _SideStreams(), _SideStreams())   # EvR levels 1, 2 (and 3: num_encoders = 4); level 0 runs on the caller's stream
 WGRAD_BATCH = int(os.environ.get("REFID_WGRAD_BATCH", "8"))     # deferred launches per cross-stream dependency
 # The weight gradients of up to this many consecutive time steps of one conv are ONE launch (the weights are shared over
 # T: their partial-sum slabs -- 134-537 MB of read-modify-write per launch at B=8 -- are then touched once per group
@@ -967,7 +967,12 @@ class Engine:
     """Forward + BPTT backward of FinalBidirectionAttenfusion on one GPU."""
 
     def __init__(self, img_chn, ev_chn=2, out_chn=3, base=32, num_residual_blocks=2, device="cuda",
-                 compute_dtype="fp32", num_block=1):
+                 compute_dtype="fp32", num_block=1, num_encoders=3):
+        if num_encoders not in (2, 3, 4):
+            # (level 1 is the EGACA level, so two at least; more than four levels would need more forward-wavefront streams and
+            #  H, W multiples of 32: nothing in the reference uses them)
+            raise ValueError("num_encoders must be 2, 3 or 4 (every options/*.yml of the reference: 3; the reference ctor's default: 4)")
+        self.NL = NL = num_encoders
         if base not in (8, 16, 32, 64):
             # EGACA's LayerNorm / depthwise / squeeze-excite kernels take 2*base in {16, 32, 64, 128} channels; every
             # options/*.yml of the reference uses 32
@@ -985,14 +990,14 @@ class Engine:
         self.img_chn, self.ev_chn, self.out_chn, self.base = img_chn, ev_chn, out_chn, base
         self.nres = num_residual_blocks
         self.device = torch.device(device)
-        self.shapes = param_shapes(img_chn, ev_chn, out_chn, base, num_residual_blocks, num_block)
+        self.shapes = param_shapes(img_chn, ev_chn, out_chn, base, num_residual_blocks, num_block, NL)
         self.arena = A = ParamArena(self.shapes, self.device)
         self.head_ev = ConvOp(A, "head.conv2d", need_dgrad=False, bf16=bf)
         self.head_img = ConvOp(A, "head_img.conv2d", need_dgrad=False, bf16=bf)
-        self.enc_b = [_EvrLevel(A, f"encoders_backward.{i}", i, False, dead_down=(i == 2), bf16=bf) for i in range(3)]
-        self.enc_f = [_EvrLevel(A, f"encoders_forward.{i}", i, True, bf16=bf) for i in range(3)]
+        self.enc_b = [_EvrLevel(A, f"encoders_backward.{i}", i, False, dead_down=(i == NL - 1), bf16=bf) for i in range(NL)]
+        self.enc_f = [_EvrLevel(A, f"encoders_forward.{i}", i, True, bf16=bf) for i in range(NL)]
         self.img = []
-        for i in range(3):
+        for i in range(NL):
             p = f"img_encoders.{i}"
             self.img.append(dict(identity=ConvOp(A, p + ".identity", bf16=bf), conv_1=ConvOp(A, p + ".conv_1", bf16=bf),
                                  conv_2=ConvOp(A, p + ".conv_2", bf16=bf),
@@ -1000,7 +1005,7 @@ class Engine:
         self.res = [(ConvOp(A, f"resblocks.{i}.conv1", bf16=bf), ConvOp(A, f"resblocks.{i}.conv2", bf16=bf))
                     for i in range(self.nres)]
         self.dec = []
-        for j in range(3):
+        for j in range(NL):
             p = f"decoders.{j}"
             self.dec.append(dict(t2=ConvOp(A, p + ".transposed_conv2d", kind="convT", bf16=bf),
                                  trunk=_Trunk(A, p + ".forward_trunk.main", bf16=bf)))
@@ -1250,12 +1255,12 @@ class Engine:
         if i == 0:
             src = a
             u = L.conv.fwd(a, slope_pre=0.04)                 # LeakyReLU(.2) twice (rsm:81-82,284-285)
-        elif i == 2:
-            if L.q_const is not None:                         # C3(a + x_blocks[1]) + bias = C3(a) + q_const
+        elif i >= 2:
+            if L.q_const is not None:                         # C3(a + x_blocks[i-1]) + bias = C3(a) + q_const
                 src = a
                 u = L.conv.fwd(a, res=L.q_const, slope_post=0.04, bias=False)
             else:
-                src = ops.add(a, xb[1])
+                src = ops.add(a, xb[i - 1])
                 u = L.conv.fwd(src, slope_pre=0.04)
         else:
             src = a
@@ -1284,8 +1289,9 @@ class Engine:
         if x.dtype != torch.float32 or event.dtype != torch.float32 or not x.is_cuda or not event.is_cuda:
             raise RefidHipError("forward: float32 CUDA tensors required")
         B, T, nb, H, W = event.shape
-        if H % 8 or W % 8:
-            raise RuntimeError(f"H and W must be multiples of 8, got {H}x{W}")   # reference: shape error
+        NL = self.NL
+        if H % (1 << NL) or W % (1 << NL):      # reference: a shape error at the first skip sum
+            raise RuntimeError(f"H and W must be multiples of {1 << NL}, got {H}x{W}")
         if x.shape != (B, self.img_chn, H, W) or nb != self.ev_chn:
             raise RuntimeError(f"unexpected input shapes x={tuple(x.shape)} event={tuple(event.shape)}")
         self.repack()
@@ -1298,7 +1304,7 @@ class Engine:
         e_all = self.head_ev.fwd(ev_in, slope_pre=0.2)                     # arch:149
         xb, img_saved = [], []
         g = head
-        for i in range(3):                                                 # rsm:41-49
+        for i in range(NL):                                                # rsm:41-49
             E = self.img[i]
             c1 = E["conv_1"].fwd(g, slope_pre=0.2)
             c2 = E["conv_2"].fwd(c1, slope_pre=0.2)
@@ -1313,8 +1319,8 @@ class Engine:
         # linearity split: the time-independent halves of the level-2 first conv and of pred (the fuse convs' follow the
         # backward sweep, which produces their operand)
         lin = LINEAR_SPLIT
-        for L in (self.enc_b[2], self.enc_f[2]):
-            L.q_const = L.conv.fwd(xb[1]) if lin else None                 # C3(x_blocks[1]) + bias
+        for L in self.enc_b[2:] + self.enc_f[2:]:                          # levels >= 2: C3(a + x_blocks[level - 1])
+            L.q_const = L.conv.fwd(xb[L.level - 1]) if lin else None       # C3(x_blocks[level - 1]) + bias
         for L in self.enc_f:
             L.p_fuse = None
         q_pred = None
@@ -1324,7 +1330,7 @@ class Engine:
 
         main = torch.cuda.current_stream()
         pipe = use_pipeline(B, H, W)
-        lvs = [main, LV_STREAMS[0].get(dev), LV_STREAMS[1].get(dev)] if pipe else [main, main, main]
+        lvs = [main] + ([LV_STREAMS[k].get(dev) for k in range(NL - 1)] if pipe else [main] * (NL - 1))
         for s_ in lvs[1:]:
             if s_ is not main:
                 s_.wait_stream(main)                   # image branch, event head: everything issued so far
@@ -1339,12 +1345,12 @@ class Engine:
             with torch.cuda.stream(lvs[i]):
                 return self._evr_fwd(L, cur, xb, h_prev, Sb_i, ip, st, plus)
 
-        hb = [None, None, None]
+        hb = [None] * NL
         steps_b = []
         for t in range(T - 1, -1, -1):                                     # arch:172-181
             cur = e_all[t * B:(t + 1) * B]
             sts = []
-            for i in range(3):
+            for i in range(NL):
                 st = {} if save else None
                 cur, hb[i] = level(self.enc_b[i], i, cur, hb[i], None, ip_b, st)
                 sts.append(st)
@@ -1365,8 +1371,8 @@ class Engine:
         out = torch.empty((B, T, self.out_chn, H, W), dtype=torch.float32, device=dev)
         # pred's NHWC outputs of all T steps (time-major); converted to the (B,T,C,H,W) stack in one launch after the loop
         out4 = torch.zeros((T * B, H, W, _pad4(self.out_chn)), dtype=torch.float32, device=dev)
-        hf = [None, None, None]
-        hd = [None, None, None]
+        hf = [None] * NL
+        hd = [None] * NL
         steps_f = []
         dstream = DEC_STREAM.get(dev) if pipe else None
         if dstream is not None:
@@ -1376,28 +1382,28 @@ class Engine:
 
         def decode(t, eb, sts, b0_in):
             bs = []
-            z = eb[2]
+            z = eb[NL - 1]
             di = None
             for i, (c1, c2) in enumerate(self.res):                        # arch:199-203, rsm:488-503
-                b0 = (b0_in if b0_in is not None else ops.add(z, xb[2])) if i == 0 else z
+                b0 = (b0_in if b0_in is not None else ops.add(z, xb[NL - 1])) if i == 0 else z
                 b1 = c1.fwd(b0, slope_pre=0.0)
                 if fuse and i == self.nres - 1:                            # decoder 0's input sum leaves with this tile
-                    z, di = c2.fwd(b1, res=b0, slope_post=0.0, plus=eb[2])
+                    z, di = c2.fwd(b1, res=b0, slope_post=0.0, plus=eb[NL - 1])
                 else:
                     z = c2.fwd(b1, res=b0, slope_post=0.0)
                 bs.append((b0, b1, z))
             ds = []
-            for j in range(3):                                             # arch:210-212, rsm:386-408
+            for j in range(NL):                                            # arch:210-212, rsm:386-408
                 D = self.dec[j]
                 if di is None:
-                    di = ops.add(z, eb[2 - j])
+                    di = ops.add(z, eb[NL - 1 - j])
                 q = D["t2"].fwd(di)
                 dst = {} if save else None
                 if save:
                     dst["di"] = di
                 di = None
-                if fuse and j < 2:                                         # the next decoder's input sum
-                    z, di = self._trunk_fwd(D["trunk"], q, hd[j], dst, plus=eb[1 - j])
+                if fuse and j < NL - 1:                                    # the next decoder's input sum
+                    z, di = self._trunk_fwd(D["trunk"], q, hd[j], dst, plus=eb[NL - 2 - j])
                 else:
                     z = self._trunk_fwd(D["trunk"], q, hd[j], dst)
                 hd[j] = z
@@ -1415,10 +1421,10 @@ class Engine:
             cur = e_all[t * B:(t + 1) * B]
             sts, eb = [], []
             b0_in = None
-            for i in range(3):
+            for i in range(NL):
                 st = {} if save else None
-                if fuse and i == 2:                    # b0 = e_blocks[2] + x_blocks[2] (arch:199-203) from the down tile
-                    cur, hf[i], b0_in = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st, plus=xb[2])
+                if fuse and i == NL - 1:               # b0 = e_blocks[-1] + x_blocks[-1] (arch:199-203) from the down tile
+                    cur, hf[i], b0_in = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st, plus=xb[NL - 1])
                 else:
                     cur, hf[i] = level(self.enc_f[i], i, cur, hf[i], Sb[i], ip_f, st)
                 sts.append(st)
@@ -1426,7 +1432,7 @@ class Engine:
             if dstream is None:
                 decode(t, eb, sts, b0_in)
             else:
-                for i in range(3):
+                for i in range(NL):
                     dstream.wait_stream(lvs[i])        # step t's encoder outputs
                     eb[i].record_stream(dstream)       # (allocated on another stream's pool)
                 if b0_in is not None:
@@ -1488,21 +1494,23 @@ class Engine:
         g_head = self.pred.dgrad(g4sum)
         # gradients of the image branch's x_blocks: with the linearity split they are assembled once per sweep from the kept
         # per-step tensors (ops.sum_n / one input-gradient launch on the summed gradient), never accumulated step by step
-        g_xb = [None, None, None] if lin else [zeros(t) for t in xb]
-        g_Sb = [None, None, None]
+        NL = self.NL
+        g_xb = [None] * NL if lin else [zeros(t) for t in xb]
+        g_Sb = [None] * NL
         g_e = torch.empty_like(e_all)
-        keep = dict(gy=[], gu=[], gb0=[], gf=([], [], []))     # per-step gradients the deferred sums read
+        # per-step gradients the deferred sums read (gu: per level >= 2, the constant operand x_blocks[level - 1]'s share)
+        keep = dict(gy=[], gu={i: [] for i in range(2, NL)}, gb0=[], gf=tuple([] for _ in range(NL)))
 
         # ---------------- forward sweep, t = T-1 .. 0 -------------------------------------------
-        g_hf = [None, None, None]
-        g_hd = [None, None, None]
+        g_hf = [None] * NL
+        g_hd = [None] * NL
         for t in range(T - 1, -1, -1):
             S = c["steps_f"][t]
             g4 = g4_all[t * B:(t + 1) * B]
             self.pred.wgrad(g4, S["pi"])
-            g_sd = self.pred.dgrad(g4, res=g_hd[2])           # + decoder 2's state gradient, fused
-            g_skip = [None, None, None]
-            for j in (2, 1, 0):
+            g_sd = self.pred.dgrad(g4, res=g_hd[NL - 1])      # + the last decoder's state gradient, fused
+            g_skip = [None] * NL
+            for j in range(NL - 1, -1, -1):
                 D, dst = self.dec[j], S["ds"][j]
                 g_q, g_hd[j] = self._trunk_bwd(D["trunk"], g_sd, dst)
                 D["t2"].wgrad(g_q, dst["di"])
@@ -1512,9 +1520,9 @@ class Engine:
                     g_di = D["t2"].dgrad(g_q)
                     if j > 0:
                         g_sd = g_di if g_hd[j - 1] is None else ops.add(g_di, g_hd[j - 1])
-                g_skip[2 - j] = g_di
+                g_skip[NL - 1 - j] = g_di
             # bottleneck
-            g_z = g_skip[2]                                   # decoder 0's di = z + e_blocks[2]
+            g_z = g_skip[NL - 1]                              # decoder 0's di = z + e_blocks[-1]
             for i in range(self.nres - 1, -1, -1):
                 c1, c2 = self.res[i]
                 b0, b1, z = S["bs"][i]
@@ -1525,15 +1533,15 @@ class Engine:
                 if i > 0:
                     g_z = c1.dgrad(g_b1, res=gz)              # b0 is the previous block's output
                 elif FUSE_SUMS:
-                    g_b0, g_o = c1.dgrad(g_b1, res=gz, plus=g_skip[2])     # level 2's output gradient leaves with the tile
+                    g_b0, g_o = c1.dgrad(g_b1, res=gz, plus=g_skip[NL - 1])     # the last level's output gradient leaves with the tile
                 else:
                     g_b0 = c1.dgrad(g_b1, res=gz)
-                    g_o = ops.add(g_b0, g_skip[2])
+                    g_o = ops.add(g_b0, g_skip[NL - 1])
             if lin:
                 keep["gb0"].append(g_b0)
             else:
-                ops.add(g_xb[2], g_b0, out=g_xb[2])
-            for i in (2, 1, 0):
+                ops.add(g_xb[NL - 1], g_b0, out=g_xb[NL - 1])
+            for i in range(NL - 1, -1, -1):
                 L, st = self.enc_f[i], S["lv"][i]
                 C = L.C
                 L.down.wgrad(g_o, st["f"])
@@ -1553,7 +1561,7 @@ class Engine:
         if lin:
             # the time-independent operands' shares, from the summed per-step gradients
             self.pred.wgrad(g4sum, head, bias=False)                      # (sum_t g4) (x) head; bias: the per-step calls
-            g_xb[2] = ops.sum_n(keep["gb0"])
+            g_xb[NL - 1] = ops.sum_n(keep["gb0"])
             for i, L in enumerate(self.enc_f):
                 gsum = ops.sum_n(keep["gf"][i])
                 if L.zero_s is None:
@@ -1561,7 +1569,10 @@ class Engine:
                 else:
                     L.fuse.wgrad(gsum, L.zero_s, Sb[i], bias=False)
                 g_Sb[i] = L.fuse.dgrad(gsum, rows=(L.C, L.C))             # dL/dS_b = W_b^T sum_t g_f
-            self._lin_level2_tail(self.enc_f[2], keep["gu"], xb, g_xb, first=True)
+            # (top level first: x_blocks[NL-1]'s gradient already holds the bottleneck's share, x_blocks[i-1] for i < NL-1... each
+            #  level >= 2 adds its constant operand's share to g_xb[level - 1]: the first writer of that slot overwrites)
+            for i in range(2, NL):
+                self._lin_level2_tail(self.enc_f[i], keep["gu"][i], xb, g_xb, first=g_xb[i - 1] is None)
             g_xb[0] = ops.sum_n(keep["gy"])
         # forward-sweep, bottleneck, decoder and pred weights are final from here on -- except the
         # folded EGACA convs, un-folded now so the early bucket is complete
@@ -1578,30 +1589,32 @@ class Engine:
         if ROWS_DEFER:
             ops.rows_sum_defer()
         # ---------------- backward sweep (executed t = T-1..0), BPTT in reverse: t = 0 .. T-1 ----
-        g_hb = [None, None, None]
+        NL = self.NL
+        g_hb = [None] * NL
         lin = c["lin"]
-        keep = dict(gy=[], gu=[])
+        keep = dict(gy=[], gu={i: [] for i in range(2, NL)})
         for t, sts in reversed(c["steps_b"]):
             g_o = None
-            for i in (2, 1, 0):
+            for i in range(NL - 1, -1, -1):
                 L, st = self.enc_b[i], sts[i]
                 carry = g_hb[i] if g_hb[i] is not None else g_Sb[i]     # t == 0: dL/dS_b,i
-                if i == 2:
+                if i == NL - 1:                                         # (its conv_down is dead: arch:181 discards the output)
                     g_s = carry
                 else:
                     L.down.wgrad(g_o, st["s"])
                     g_s = L.down.dgrad(g_o, res=carry)
                 g_o = self._evr_first_bwd(L, g_s, st, g_hb, g_xb, g_e, t, B, c["ip_b"], None, False, keep if lin else None)
         if lin:
-            self._lin_level2_tail(self.enc_b[2], keep["gu"], xb, g_xb, first=False)
+            for i in range(2, NL):
+                self._lin_level2_tail(self.enc_b[i], keep["gu"][i], xb, g_xb, first=False)
             ops.sum_n([g_xb[0]] + keep["gy"], out=g_xb[0])
 
         # ---------------- t-independent tails ----------------------------------------------------
         self._egaca_img_bwd(self.enc_b[1].att, xb[0], g_xb[0], c["ip_b"])
         gz_e = ops.act_bwd(g_e, e_all, 0.2, out=g_e)
         self.head_ev.wgrad(gz_e, c["ev_in"])
-        g = g_xb[2]
-        for i in (2, 1, 0):
+        g = g_xb[NL - 1]
+        for i in range(NL - 1, -1, -1):
             E = self.img[i]
             gin, c1, c2, sm = c["img_saved"][i]
             E["down"].wgrad(g, sm)
@@ -1623,14 +1636,16 @@ class Engine:
         self._egaca_fold_back(self.enc_b[1].att)
 
     def _lin_level2_tail(self, L, gu, xb, g_xb, first):
-        """Level-2 first conv, linearity split: the share of the constant operand x_blocks[1] -- its weight-gradient term
-        (sum_t g_u) (x) x_blocks[1] and its input gradient W^T sum_t g_u -- from ONE summed gradient per sweep."""
+        """First conv of a level >= 2, linearity split: the share of the constant operand x_blocks[level - 1] -- its
+        weight-gradient term (sum_t g_u) (x) x_blocks[level - 1] and its input gradient W^T sum_t g_u -- from ONE summed gradient
+        per sweep."""
+        k = L.level - 1
         gsum = ops.sum_n(gu)
-        L.conv.wgrad(gsum, xb[1], bias=False)
+        L.conv.wgrad(gsum, xb[k], bias=False)
         if first:
-            g_xb[1] = L.conv.dgrad(gsum)
+            g_xb[k] = L.conv.dgrad(gsum)
         else:
-            L.conv.dgrad(gsum, res=g_xb[1], out=g_xb[1])
+            L.conv.dgrad(gsum, res=g_xb[k], out=g_xb[k])
 
     def _evr_first_bwd(self, L, g_s, st, g_h, g_xb, g_e, t, B, ip, g_skip, first_writer, keep=None):
         """Trunk + first op of an EvR level; returns the gradient w.r.t. the level's input
@@ -1646,14 +1661,14 @@ class Engine:
             return g_in
         g_u, g_h[i] = self._trunk_bwd(L.trunk, g_s, st, mask_u=st["u"], slope_u=0.04)
         L.conv.wgrad(g_u, st["src"])
-        if i == 2:
+        if i >= 2:
             if lin:
-                keep["gu"].append(g_u)                        # x_blocks[1]'s share: _lin_level2_tail
-                return L.conv.dgrad(g_u, res=g_skip[1] if g_skip is not None else None)
+                keep["gu"][i].append(g_u)                     # x_blocks[i-1]'s share: _lin_level2_tail
+                return L.conv.dgrad(g_u, res=g_skip[i - 1] if g_skip is not None else None)
             g_a2 = L.conv.dgrad(g_u)
-            ops.add(g_xb[1], g_a2, out=g_xb[1])
+            ops.add(g_xb[i - 1], g_a2, out=g_xb[i - 1])
             if g_skip is not None:
-                g_a2 = ops.add(g_a2, g_skip[1], out=g_a2)
+                g_a2 = ops.add(g_a2, g_skip[i - 1], out=g_a2)
             return g_a2
         # level 0: the input is e_t = head(event_t); collect its gradient (both sweeps) for the
         # event head's weight gradient.  The forward-sweep BPTT runs first and writes every slice.

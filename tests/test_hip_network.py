@@ -16,7 +16,8 @@ RTOL, ATOL = 1e-3, 1e-4
 def build(img_chn, base, P):
     from refid_amd.archs import define_network
     nb = 1 + max(int(k.split(".main.2.")[1].split(".")[0]) for k in P if ".main.2." in k)      # num_block of this state dict
-    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=3,
+    ne = 1 + max(int(k.split(".")[1]) for k in P if k.startswith("encoders_forward."))          # ... and its num_encoders
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=img_chn, ev_chn=2, num_encoders=ne,
                               base_num_channels=base, num_block=nb, num_residual_blocks=2))
     net.load_state_dict(P, strict=True)
     return net.cuda()
@@ -26,12 +27,14 @@ def load(golden_dir, name):
     z = np.load(os.path.join(golden_dir, name + ".npz"))
     img_chn, base, B, T, H, W, seed = [int(v) for v in z["meta"][:7]]
     nb = int(z["meta"][7]) if len(z["meta"]) > 7 else 1                   # num_block (tiny26_nb2_train: 2)
-    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, num_block=nb)
+    ne = int(z["meta"][8]) if len(z["meta"]) > 8 else 3                   # num_encoders (tiny26_default_ctor_train: 4, tiny6_ne2_train: 2)
+    P = O.make_params(img_chn, base_num_channels=base, mode="hash", seed=seed, num_block=nb, num_encoders=ne)
     x, ev, gt = O.make_inputs(B, T, H, W, img_chn, seed=seed, mode="hash")
     return z, P, x, ev, gt, img_chn, base
 
 
-@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train", "odd26_fwd", "full26_train", "tiny26_nb2_train"])
+@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train", "odd26_fwd", "full26_train", "tiny26_nb2_train",
+                                  "tiny26_default_ctor_train", "tiny6_ne2_train"])
 def test_forward_matches_reference_golden(golden_dir, name):
     z, P, x, ev, gt, img_chn, base = load(golden_dir, name)
     net = build(img_chn, base, P)
@@ -113,13 +116,13 @@ def _grad_check(net, P, grads_ref, rtol=2e-3):
     assert worst[0][0] < rtol, f"largest relative gradient errors: {worst[:5]}"
 
 
-@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train", "tiny26_nb2_train"])
+@pytest.mark.parametrize("name", ["tiny26_train", "tiny6_train", "tiny26_nb2_train", "tiny26_default_ctor_train", "tiny6_ne2_train"])
 def test_backward_matches_oracle_and_golden(golden_dir, name):
     z, P, x, ev, gt, img_chn, base = load(golden_dir, name)
     net = build(img_chn, base, P)
     Pc = {k: v.clone() for k, v in P.items()}
     st = O.TrainState(Pc)
-    loss_ref, gnorm_ref, grads_ref, _ = O.train_step(Pc, st, x, ev, gt)
+    loss_ref, gnorm_ref, grads_ref, _ = O.train_step(Pc, st, x, ev, gt, num_encoders=net.num_encoders)
     pred = net(x=x.cuda(), event=ev.cuda())
     loss = torch.sqrt((pred - gt.cuda()) ** 2 + 1e-12).mean()        # torch only as the test's loss
     loss = loss + 0 * sum(p.sum() for p in net.parameters())          # the reference's DDP trick

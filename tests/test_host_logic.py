@@ -78,7 +78,7 @@ def test_state_dict_keys_shapes_and_counts(img_chn, count):
 def test_unsupported_options_fail_loudly():
     from refid_amd.archs import define_network
     base = dict(type="FinalBidirectionAttenfusion", img_chn=6, ev_chn=2, num_encoders=3, num_block=1)
-    for bad in (dict(num_encoders=4), dict(num_block=0), dict(skip_type="concat"), dict(norm="BN"),
+    for bad in (dict(num_encoders=5), dict(num_encoders=1), dict(num_block=0), dict(skip_type="concat"), dict(norm="BN"),
                 dict(use_recurrent_upsample_conv=False)):
         with pytest.raises(NotImplementedError):
             define_network({**base, **bad})
@@ -89,6 +89,11 @@ def test_unsupported_options_fail_loudly():
     assert len(keys) == 183 + 2 * 6 * 4 and "encoders_forward.2.recurrent_block.forward_trunk.main.2.2.conv2.bias" in keys
     assert "decoders.0.forward_trunk.main.2.1.conv1.weight" not in keys
     assert keys == list(O.param_shapes(6, base_num_channels=8, num_block=3).keys())
+    # the reference ctor's own defaults (arch:90-92: num_encoders=4, num_block=3) build, with the reference's keys (pinned to the
+    # reference by tests/golden/tiny26_default_ctor_train.npz: oracle/make_golden.py asserts key order and shapes against it)
+    dflt = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=6, ev_chn=2, base_num_channels=8))
+    assert dflt.num_encoders == 4 and dflt.num_block == 3
+    assert list(dflt.state_dict().keys()) == list(O.param_shapes(6, base_num_channels=8, num_block=3, num_encoders=4).keys())
     with pytest.raises(AssertionError):
         define_network({**base, "img_chn": 0})
     # ignored-by-the-reference keywords are accepted

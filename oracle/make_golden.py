@@ -243,6 +243,8 @@ def run_host_logic(arch, out_dir):
         "MultiStepRestartLR_warm": (dict(milestones=[8, 16, 30], gamma=0.5, restarts=[0, 20], restart_weights=[1, 0.5]), 4, None),
         "CosineAnnealingRestartLR": (dict(periods=[10, 10, 20], restart_weights=[1, 0.5, 0.25], eta_min=1e-7), -1, None),
         "LinearLR": ({}, -1, 40),
+        "VibrateLR": ({}, -1, 800),                      # lr_scheduler.py:71-112: T = total_iter // 80 = 10, Th = 5
+        "VibrateLR_warm": ({}, 5, 1600),
     }
     for name, (cfg, warm, total) in cases.items():
         kind = name.split("_")[0]
@@ -254,6 +256,8 @@ def run_host_logic(arch, out_dir):
             sch = lrs.MultiStepRestartLR(opt, **cfg)
         elif kind == "CosineAnnealingRestartLR":
             sch = lrs.CosineAnnealingRestartLR(opt, **cfg)
+        elif kind == "VibrateLR":
+            sch = lrs.VibrateLR(opt, total)
         else:
             sch = lrs.LinearLR(opt, total)
         seq = []

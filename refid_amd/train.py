@@ -54,10 +54,33 @@ def scheduler_lr(kind, cfg, epoch, base_lr, prev_lr, total_iter=None):
         return eta + weights[idx] * 0.5 * (base_lr - eta) * (1 + math.cos(math.pi * (epoch - near) / periods[idx]))
     if kind == "LinearLR":                                # lr_scheduler.py:48-67
         return (1 - epoch / total_iter) * base_lr
+    if kind == "VibrateLR":                               # lr_scheduler.py:71-112: a sawtooth of period total_iter // 80 under a
+        process = epoch / total_iter                      # three-stage envelope (1 -> 0 over the first 3/8, then 0.2, then 0.1)
+        f = 0.1
+        if process < 3 / 8:
+            f = 1 - process * 8 / 3
+        elif process < 5 / 8:
+            f = 0.2
+        period = total_iter // 80
+        half = period // 2
+        t = epoch % period
+        f2 = t / half
+        if t >= half:
+            f2 = 2 - f2
+        weight = f * f2
+        if epoch < half:
+            weight = max(0.1, weight)
+        return weight * base_lr
     raise NotImplementedError(f"Scheduler {kind} is not implemented yet.")
 
 
-SCHEDULERS = ("TrueCosineAnnealingLR", "MultiStepLR", "MultiStepRestartLR", "CosineAnnealingRestartLR", "LinearLR")
+def scheduler_initial_lr(kind, cfg, base_lr, total_iter=None):
+    """The lr a freshly built scheduler leaves in the optimizer (torch's _LRScheduler.__init__ steps once: last_epoch = 0).
+    Every scheduler above returns base_lr there except VibrateLR, whose sawtooth starts at its floor (0.1 base_lr)."""
+    return scheduler_lr(kind, cfg, 0, base_lr, base_lr, total_iter) if kind == "VibrateLR" else base_lr
+
+
+SCHEDULERS = ("TrueCosineAnnealingLR", "MultiStepLR", "MultiStepRestartLR", "CosineAnnealingRestartLR", "LinearLR", "VibrateLR")
 
 
 class TwoImageEventRecurrentRestorationModel:
@@ -102,7 +125,7 @@ class TwoImageEventRecurrentRestorationModel:
         if self.sched_type == "TrueCosineAnnealingLR":
             sch = dict(T_max=int(sch["T_max"]), eta_min=float(sch.get("eta_min", 0.0)))
         elif self.sched_type not in SCHEDULERS + ("none",):
-            # base_model.py:77-108 also knows VibrateLR (unused by any options/*.yml); everything else raises there too
+            # (base_model.py:77-108: everything else raises there too)
             raise NotImplementedError(f"Scheduler {self.sched_type} is not implemented yet. (supported: {SCHEDULERS})")
         self.sched_cfg = sch
         self.total_iter = train_opt.get("total_iter")
@@ -114,11 +137,11 @@ class TwoImageEventRecurrentRestorationModel:
         self.exp_avg_sq = torch.zeros_like(eng.arena.flat_p)
         self.sqnorm = torch.zeros(ops.SQNORM_WORDS, dtype=torch.float64, device=self.device)
         self.step_count = 0
-        self.cur_lr = self.base_lr
+        self.cur_lr = scheduler_initial_lr(self.sched_type, self.sched_cfg, self.base_lr, self.total_iter)
         # the reference's optimizer has a SECOND, empty param group at lr * 0.1 ('module.offsets' / 'module.dcns' parameters,
         # which this network does not have: twoImage_event_recurrent_model.py:72-90); its lr is tracked only so that a
         # reference-layout `.state` carries the two groups / two-entry scheduler lists torch's load_state_dict insists on
-        self.cur_lr_low = self.base_lr * self.LOWLR_RATIO
+        self.cur_lr_low = self.cur_lr * self.LOWLR_RATIO
         self.sched_epoch = 0
         # the collectives also run in a 1-rank process group (REFID_FORCE_GRADSYNC=1): lets a single-GPU box
         # exercise the exact RCCL code path of the multi-GPU job

@@ -273,11 +273,12 @@ def test_schedulers_match_reference_sequences(golden_dir):
     from refid_amd import train
     z = np.load(os.path.join(golden_dir, "host_logic.npz"))
     names = [k[3:] for k in z.files if k.startswith("lr/")]
-    assert len(names) == 6
+    assert len(names) == 8 and "VibrateLR" in names
     for name in names:
         kind, cfg, warm, total = ast.literal_eval(str(z["lrcfg/" + name]))
         m = train.TwoImageEventRecurrentRestorationModel.__new__(train.TwoImageEventRecurrentRestorationModel)
-        m.base_lr = m.cur_lr = 2e-4
+        m.base_lr = 2e-4
+        m.cur_lr = train.scheduler_initial_lr(kind, cfg, 2e-4, total)      # (what init_training_settings sets)
         m.sched_type, m.sched_cfg, m.sched_epoch, m.total_iter = kind, cfg, 0, total
         seq = []
         for it in range(1, 40):

@@ -697,6 +697,8 @@ def main(argv=None, claim_stdout=False):
         }
         if not args.dry_run:
             out["launch"] = "hipGraph replay" if replayed else "eager launches"
+            if getattr(model, "graph_fallback", None):
+                out["launch"] += f" (graph capture failed, fell back: {model.graph_fallback})"
             out["h2d"] = ("prefetched, in timed region (pinned host batch -> HBM on a side stream during the previous step; "
                           "feed_data inside the loop)") if args.h2d == "prefetch" else "resident (fed once before the timed region)"
             out["h2d_ms_exposed"] = h2d["exposed_ms"]

@@ -267,7 +267,20 @@ class TwoImageEventRecurrentRestorationModel:
             # (an eager call at a larger geometry since the capture replaced a split-K workspace / weight-gradient slab
             #  buffer whose address the graphs hold: capture again)
             self._graph = None
-            g = self._graph = self._graph_capture()
+            try:
+                g = self._graph = self._graph_capture()
+            except Exception as ex:                  # noqa: BLE001
+                # "auto" must never cost a run: a capture that fails (before any parameter update or collective of this step:
+                # the capture's warm-up pass runs without either) sends this and every later step down the eager path; an
+                # explicit set_graph_mode(True) raises
+                if not getattr(self, "_graph_auto", False):
+                    raise
+                import warnings
+                warnings.warn(f"graph_replay auto: capture failed ({type(ex).__name__}: {ex}); continuing with eager launches")
+                self.set_graph_mode(False)
+                self.graph_fallback = f"{type(ex).__name__}: {ex}"
+                torch.cuda.synchronize()
+                return False
         else:
             g["lq"].copy_(self.lq, non_blocking=True)
             g["voxel"].copy_(self.voxel, non_blocking=True)
@@ -329,8 +342,8 @@ class TwoImageEventRecurrentRestorationModel:
                 self.set_graph_mode(small)
                 self._graph_auto = True
         if getattr(self, "graph_on", False):
-            self._step_graph()
-            return self._mark_step_end()
+            if self._step_graph() is not False:
+                return self._mark_step_end()
         eng = self.net_g.engine
         eng.zero_grad()                                          # optimizer_g.zero_grad()
         pred = eng.forward(self.lq, self.voxel, save=True)       # net_g(x=lq, event=voxel)

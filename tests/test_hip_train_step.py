@@ -247,6 +247,40 @@ def test_six_steps_track_the_oracle_loss_curve():
         assert (sd[k].double().cpu() - P[k].double()).abs().max().item() <= 0.03 * disp + 1e-9, k
 
 
+def test_graph_auto_falls_back_to_eager_when_capture_fails(monkeypatch):
+    """`train.graph_replay: auto` / `bench.py --graph auto` must never cost a run: a capture that raises (before any parameter
+    update of that step) sends this and every later step down the eager path -- same bits as a run that never tried; an
+    explicit set_graph_mode(True) still raises."""
+    from refid_amd.train import TwoImageEventRecurrentRestorationModel
+    P = O.make_params(26, base_num_channels=8, mode="hash", seed=5)
+    batches = [O.make_inputs(1, 3, 32, 32, 26, seed=30 + i, mode="hash") for i in range(3)]
+
+    def run(mode, broken):
+        m = TwoImageEventRecurrentRestorationModel(_opt(26, 8, T_max=6))
+        m.net_g.load_state_dict(P)
+        if broken:
+            monkeypatch.setattr(m, "_graph_capture", lambda: (_ for _ in ()).throw(RuntimeError("capture refused")))
+        m.set_graph_mode(mode)
+        for it, (x, ev, gt) in enumerate(batches, start=1):
+            m.update_learning_rate(it)
+            m.feed_data({"lq": x, "voxel": ev, "gt": gt})
+            m.optimize_parameters(it)
+        return m, {k: v.cpu() for k, v in m.net_g.state_dict().items()}
+
+    me, sde = run(False, False)
+    with pytest.warns(UserWarning, match="capture failed"):
+        ma, sda = run("auto", True)
+    assert ma.graph_on is False and "capture refused" in ma.graph_fallback and ma.step_count == 3
+    for k in sde:
+        assert torch.equal(sde[k], sda[k]), k
+    with pytest.raises(RuntimeError, match="capture refused"):
+        run(True, True)
+    mg, sdg = run("auto", False)                             # ... and a working capture is used (B H W = 1024 <= 2 x 256^2)
+    assert mg.graph_on is True and mg._graph is not None
+    for k in sde:
+        assert torch.equal(sde[k], sdg[k]), k
+
+
 def test_graph_replayed_steps_equal_eager_steps():
     """the train step captured into a hipGraph (zero_grad .. AdamW, weight-gradient side stream forked and
     joined inside the capture, lr / bias corrections read from device memory) and replayed == the same steps launched

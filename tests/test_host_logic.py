@@ -436,6 +436,22 @@ def test_batched_finish_always_flushes_and_fallback_packs_stay_out_of_the_plan(m
     assert eng.pred.wp6 is not None and eng.pred.f_algo == 0 and not eng.pred.wp_lazy      # thin output on the Winograd x six form
 
 
+def test_weight_gradient_group_is_capped_by_free_memory():
+    """engine.wgrad_group_cap: a waiting weight-gradient call keeps its step's tensors alive (~4.9 KB per pixel and
+    step); the group shrinks when the operands of `n` steps would not fit into half of the free HBM instead of running out of
+    memory at a larger crop / T / batch.  Config 2 (B=8, 256 x 256) on a 288 GB part keeps all 23 steps."""
+    from refid_amd import engine
+    pix = 8 * 256 * 256
+    per = pix * engine.WGRAD_KEEP_BYTES_PER_PIXEL_STEP
+    assert engine.wgrad_group_cap(23, pix, "cpu", free_bytes=160 << 30) == 23          # what is free when config-2 BPTT starts
+    assert engine.wgrad_group_cap(23, pix, "cpu", free_bytes=2 * per * 8) == 8
+    assert engine.wgrad_group_cap(23, pix, "cpu", free_bytes=per) == 1                 # never below one step per launch
+    assert engine.wgrad_group_cap(23, 4 * pix, "cpu", free_bytes=160 << 30) == 8       # four times the pixels: a third of the steps
+    assert engine.wgrad_group_cap(1, pix, "cpu", free_bytes=0) == 1 and engine.wgrad_group_cap(23, 0, "cpu") == 23
+    assert engine.wgrad_group_cap(23, pix, "cpu") == 23                                # (no CUDA device: unchanged)
+    assert engine.WGRAD_GROUP == (8 if engine.OVERLAP_WGRAD else 24)                   # derived from overlap_wgrad(), not the raw env string
+
+
 def test_streaming_weight_gradient_eligibility_mirrors_the_library():
     """ConvOp._pws_plan_ok (Python) decides which weight gradients are handed to the streaming kernel; the library decides the
     same thing again (refid_wgrad_pws_ok) and would reject a mismatch at launch.  No GPU needed: refid_wgrad_workspace_bytes is

@@ -50,6 +50,14 @@
 #include "common.h"
 #include "conv_args.h"
 
+// tools/probes/split_ablate.py builds this file with -DREFID_SPLIT_ABLATE=n (one piece of the kernel removed, results wrong) to
+// price the pieces: 1 = no MFMAs, 2 = no operand split (raw registers stored as planes), 3 = global loads of chunk 0 in every
+// stage (cache resident), 4 = no global loads in the K loop, 5 = no K loop, 6 = no epilogue traffic (no residual / mask loads,
+// no stores), 7 = 5 + 6, 8 = no LDS fragment reads in the K loop (operands from registers).  Never in the product.
+#ifndef REFID_SPLIT_ABLATE
+#define REFID_SPLIT_ABLATE 0
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -238,7 +246,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     // the KS * (2*A_ITEMS + B_ITEMS) loads of a stage are issued in NSTEP*KS parts, one per MFMA step of the previous stage
     // (a wave that issues them back to back sits in the vector-memory issue queue: tools/probes/split_trace.py)
     constexpr int NLD = 2 * C::A_ITEMS + C::B_ITEMS;
-    auto load_part = [&](int ch, int part) {
+    auto load_part = [&](int chReal, int part) {
+        const int ch = REFID_SPLIT_ABLATE == 3 ? 0 : chReal;
 #pragma unroll
         for (int sub = 0; sub < KS; ++sub) {
             // MODE 1: stage ch = (8-channel group ch >> 1, row position ch & 1), sub = column position
@@ -315,7 +324,8 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
             for (int it = 0; it < C::A_ITEMS; ++it) {
                 const int hp = tid + it * NTH;
                 f32x4 pl[PL];
-                if constexpr (F16) split8h(ra[sub][it][0] * sc, ra[sub][it][1] * sc, pl);
+                if (REFID_SPLIT_ABLATE == 2) { pl[0] = ra[sub][it][0]; if constexpr (PL >= 2) pl[1] = ra[sub][it][1]; if constexpr (PL == 3) pl[2] = ra[sub][it][0]; }
+                else if constexpr (F16) split8h(ra[sub][it][0] * sc, ra[sub][it][1] * sc, pl);
                 else split8<PL>(ra[sub][it][0], ra[sub][it][1], pl);
                 if (hp < HP) {
 #pragma unroll
@@ -370,24 +380,26 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
     __syncthreads();
     SPLIT_STAMP(1);
 
-    for (int ch = 0; ch < a.nchunks; ++ch) {
+    for (int ch = 0; ch < ((REFID_SPLIT_ABLATE == 5 || REFID_SPLIT_ABLATE == 7) ? 0 : a.nchunks); ++ch) {
         const bool more = ch + 1 < a.nchunks;
         SPLIT_KSTAMP(ch, 0);
         SPLIT_KSTAMP(ch, 1);
 #pragma unroll
         for (int sj = 0; sj < NSTEP * KS; ++sj) {
             const int sub = sj / NSTEP, j = sj % NSTEP;
-            if (more) load_part(ch + 1, sj);
+            if (more && REFID_SPLIT_ABLATE != 4) load_part(ch + 1, sj);
             f32x4 af[PL][MT], bf[PL][NT];
 #pragma unroll
             for (int p = 0; p < PL; ++p) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m) af[p][m] = sA[(sub * PL + p) * C::A_SLOTS + m * HWD + aoff[j]];
+                for (int m = 0; m < MT; ++m)
+                    af[p][m] = REFID_SPLIT_ABLATE == 8 ? ra[0][0][m & 1] : sA[(sub * PL + p) * C::A_SLOTS + m * HWD + aoff[j]];
 #pragma unroll
-                for (int nn = 0; nn < NT; ++nn) bf[p][nn] = pB[((sub * PL + p) * NTAP + 2 * j) * BN + nn * 32];
+                for (int nn = 0; nn < NT; ++nn)
+                    bf[p][nn] = REFID_SPLIT_ABLATE == 8 ? rb[0][0] : pB[((sub * PL + p) * NTAP + 2 * j) * BN + nn * 32];
             }
 #pragma unroll
-            for (int e = 0; e < TERMS; ++e)
+            for (int e = 0; e < (REFID_SPLIT_ABLATE == 1 ? 0 : TERMS); ++e)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
         const int oy = oy0 + wave * MT + m;
         // residual / mask of this row are requested before the turn-around so their latency hides behind it
         f32x4 pres[EIT], pmask[EIT];
-        const bool pre = a.vecOK && (a.res != nullptr || a.mask != nullptr);
+        const bool pre = a.vecOK && (a.res != nullptr || a.mask != nullptr) && REFID_SPLIT_ABLATE != 6 && REFID_SPLIT_ABLATE != 7;
         if (pre) {
 #pragma unroll
             for (int it = 0; it < EIT; ++it) {
@@ -485,6 +497,10 @@ __global__ __launch_bounds__(NTH, 2) void conv_split_kernel(const ConvKArgs a) {
             }
             v += bv;
             lrelu4(v, a.slopePre, a.slopePre != 1.f);
+            if (REFID_SPLIT_ABLATE == 6 || REFID_SPLIT_ABLATE == 7) {
+                if (v[0] == 12345.678f) a.out[op * a.ldO + j0] = v[1];
+                continue;
+            }
             if (vec) {
                 if (a.res) v += pres[it];
                 lrelu4(v, a.slopePost, a.slopePost != 1.f);

@@ -166,6 +166,45 @@ def test_config2_oracle_crop_gradients(policy):
     assert abs(gn - float(gnorm_ref)) < 1e-4 * float(gnorm_ref), (gn, float(gnorm_ref))
 
 
+def test_default_constructor_full_width_gradients():
+    """The reference's OWN constructor defaults (arch:90-92: num_encoders=4, num_block=3; every YAML overrides them with 3 / 1) at
+    full width (base 32: 64 .. 512 channels, 1024 -> 512 trunk convs at the fourth level), one sample at 128 x 128, two time steps:
+    output and all 282 parameter gradients against the oracle (per-tensor max-normalised), exactly as the config-2 crop test."""
+    from refid_amd.archs import define_network
+    torch.manual_seed(11)
+    P = O.make_params(26, mode="init", seed=11, num_block=3, num_encoders=4)
+    for k in P:
+        if k.endswith((".beta", ".gamma")):
+            P[k] = torch.randn_like(P[k]) * 0.1
+    x, ev, gt = O.make_inputs(1, 2, 128, 128, 26, seed=12, mode="rng")
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    Pc = {k: v.clone() for k, v in P.items()}
+    loss_ref, gnorm_ref, grads_ref, pred_ref = O.train_step(Pc, O.TrainState(Pc), x, ev, gt, num_encoders=4)
+    net = define_network(dict(type="FinalBidirectionAttenfusion", img_chn=26, ev_chn=2))       # every other keyword: the ctor default
+    assert net.num_encoders == 4 and net.num_block == 3 and len(net.state_dict()) == len(P) == 282
+    net.load_state_dict(P, strict=True)
+    net = net.cuda()
+    pred = net(x=x.cuda(), event=ev.cuda())
+    loss = torch.sqrt((pred - gt.cuda()) ** 2 + 1e-12).mean()
+    loss.backward()
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), pred_ref.numpy(), rtol=1e-3, atol=1e-4)
+    assert abs(loss.item() - float(loss_ref)) < 1e-5 * float(loss_ref)
+    worst = []
+    for k, p in net.named_parameters():
+        r = grads_ref[k].double()
+        scale = float(r.abs().max())
+        if scale == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+            continue
+        worst.append((float((p.grad.double().cpu() - r).abs().max()) / scale, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 2e-3, worst[:5]
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())))
+    assert abs(gn - float(gnorm_ref)) < 1e-4 * float(gnorm_ref), (gn, float(gnorm_ref))
+    with pytest.raises(RuntimeError, match="multiples of 16"):
+        net(x=x[..., :120, :].cuda(), event=ev[..., :120, :].cuda())
+
+
 def test_config3_bf16_workload():
     """configs[2] per-GPU workload: B=4, T=25 (11+3 -> 2*11+3), 256x256, bf16 compute, one fused train step; quality
     parity of the bf16 forward against the oracle's fp32 output on one full-length sample (PSNR criterion, SURVEY 8d:
